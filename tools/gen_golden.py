@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""
+Generate the golden fixtures under tests/golden/ by importing and running the UNMODIFIED
+reference planner (jnez71/lqRRT, /root/reference) in the build container.
+
+The reference itself ships no tests or golden vectors, so these
+fixtures are the parity pin for the oracle (oracle/) and, through it, for the HIP path.
+Only DATA is written (inputs + expected outputs); no reference source text is stored.
+
+  python tools/gen_golden.py            # operator-level + small/medium trajectory fixtures
+  python tools/gen_golden.py --long     # additionally the 10k-node boat_advanced run (~20 min)
+
+Tie order: the reference's np.argsort(costs) leaves the order of exactly-equal costs
+unspecified; the fixtures pin it to "lowest node id first" (see ref_loader._StableSortNumpy).
+
+Determinism recipe: obstacle seed 0 before the demo's definition section,
+np.random.seed(1) right before update_plan, fake clock, xrand_gen=10, exit on max_nodes.
+"""
+import argparse
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_loader as rl  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+PLAN_SEED = 1
+OBS_SEED = 0
+
+
+def pid_hash(pid):
+    return hashlib.sha1(np.array(pid, np.int64).tobytes()).hexdigest()[:16]
+
+
+# --------------------------------------------------------------------------- operator level
+
+def random_states(name, ns, rng, count):
+    """States spread over (and beyond) the region the planner visits, incl. wrapped headings."""
+    n = ns["nstates"]
+    if name == "pendulum":
+        x = rng.uniform(-4.0, 4.0, (count, n))
+        x[:, 2:] *= 2.0
+        return x
+    x = np.zeros((count, n))
+    x[:, 0] = rng.uniform(-10, 70, count)
+    x[:, 1] = rng.uniform(-10, 70, count)
+    x[:, 2] = rng.uniform(-7.0, 7.0, count)           # beyond +-pi on purpose
+    x[:, 3:] = rng.uniform(-1.5, 1.5, (count, n - 3))
+    # exact zeros / sign edges exercised by the drag-sign and "no reverse" branches
+    x[::7, 3] = 0.0
+    x[3::11, 3] = -x[3::11, 3]
+    return x
+
+
+def boundary_states(name, ns, rng, count):
+    """States whose hull lies close to an obstacle rim, so is_feasible straddles both outcomes."""
+    n = ns["nstates"]
+    obs = np.array([o for o in ns.get("obs", [])], dtype=np.float64).reshape(-1, 3)
+    real = obs[obs[:, 2] > 0]
+    x = random_states(name, ns, rng, count)
+    if len(real) == 0:
+        return x
+    for i in range(count):
+        ob = real[rng.randint(len(real))]
+        ang = rng.uniform(-np.pi, np.pi)
+        reach = rng.uniform(0.0, 6.0)
+        x[i, 0] = ob[0] + (ob[2] + reach) * np.cos(ang)
+        x[i, 1] = ob[1] + (ob[2] + reach) * np.sin(ang)
+        if n >= 6 and name == "boat_advanced":
+            # keep most of them inside the planning speed box so collisions decide
+            x[i, 3] = rng.uniform(0.0, 1.0)
+            x[i, 4] = rng.uniform(-0.35, 0.35)
+            x[i, 5] = rng.uniform(-0.18, 0.18)
+    return x
+
+
+def gen_ops(name):
+    lq = rl.import_reference()
+    ns = rl.load_demo(name, OBS_SEED)
+    cfg = rl.DEMOS[name]
+    rng = np.random.RandomState(12345)
+    n, m = ns["nstates"], ns["ncontrols"]
+    B = 256
+    out = {}
+
+    # tables the systems are parameterised by
+    if "obs" in ns:
+        out["obs"] = np.array([o for o in ns["obs"]], dtype=np.float64).reshape(-1, 3)
+    if "vps" in ns:
+        out["vps"] = np.array(ns["vps"], dtype=np.float64)
+    for key in ("B", "invB", "D_pos", "D_neg", "D", "invM", "u_max", "thrust_max", "kp", "kd",
+                "velmax_pos", "velmax_neg", "velmax", "velmax_pos_plan", "velmax_neg_plan",
+                "boat_length", "goal", "goal_buffer", "error_tol", "sample_space", "goal_bias"):
+        if key in ns:
+            out["tbl_" + key] = np.array(ns[key], dtype=np.float64)
+    out["x0"] = np.array(rl.x0_of(name, ns), dtype=np.float64)
+    out["dt"] = np.float64(cfg["dt"])
+
+    # erf
+    xg = random_states(name, ns, rng, B)
+    x = random_states(name, ns, rng, B)
+    out["erf_xg"], out["erf_x"] = xg, x
+    out["erf_e"] = np.array([ns["erf"](np.copy(a), np.copy(b)) for a, b in zip(xg, x)])
+
+    # lqr (K only varies; S is a constant diagonal in every shipped demo)
+    xs = random_states(name, ns, rng, B)
+    SK = [ns["lqr"](np.copy(a), np.zeros(m)) for a in xs]
+    out["lqr_x"] = xs
+    out["lqr_S"] = np.array(SK[0][0], dtype=np.float64)
+    out["lqr_K"] = np.array([k for (_, k) in SK], dtype=np.float64)
+
+    # dynamics (u spans well past the actuator limits so saturation branches fire)
+    xs = random_states(name, ns, rng, B)
+    if name == "pendulum":
+        us = rng.uniform(-300, 300, (B, m))
+    else:
+        us = rng.uniform(-1.0, 1.0, (B, m)) * np.array([1500.0, 1500.0, 4000.0])[[0, 2] if m == 2 else [0, 1, 2]]
+    out["dyn_x"], out["dyn_u"] = xs, us
+    out["dyn_xnext"] = np.array([ns["dynamics"](np.copy(a), np.copy(b), cfg["dt"]) for a, b in zip(xs, us)])
+
+    # feasibility: random + rim-straddling
+    xs = np.vstack((random_states(name, ns, rng, B), boundary_states(name, ns, rng, 2 * B)))
+    us = rng.uniform(-1, 1, (len(xs), m)) * 500.0
+    out["feas_x"], out["feas_u"] = xs, us
+    out["feas_ok"] = np.array([bool(ns["is_feasible"](np.copy(a), np.copy(b))) for a, b in zip(xs, us)])
+
+    # cost-to-go against a frozen node table (planner.py:340-350)
+    planner = rl.make_planner(name, ns, 10)
+    import tree as reftree
+    nodes = random_states(name, ns, rng, 512)
+    t = reftree.Tree(nodes[0], ns["lqr"](nodes[0], np.zeros(m)))
+    t.state = np.array(nodes)
+    t.size = len(nodes)
+    planner.tree = t
+    qs = random_states(name, ns, rng, 8)
+    out["ctg_nodes"], out["ctg_x"] = nodes, qs
+    out["ctg_costs"] = np.array([planner._costs_to_go(np.copy(q)) for q in qs])
+
+    path = os.path.join(OUT, "ops_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, "feasible fraction %.2f" % out["feas_ok"].mean())
+
+
+# --------------------------------------------------------------------------- trajectory level
+
+def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None):
+    ns = rl.load_demo(name, OBS_SEED)
+    planner = rl.make_planner(name, ns, max_nodes, min_time=min_time)
+    n = ns["nstates"]
+
+    xrands, nearest, slen, ties = [], [], [], []
+    ctg, steer = planner._costs_to_go, planner._steer
+
+    def ctg_spy(x):
+        xrands.append(np.copy(x))
+        c = ctg(x)
+        ties.append(int(np.sum(c == c.min())) > 1)
+        return c
+
+    def steer_spy(ID, xtar, force_arrive=False):
+        r = steer(ID, xtar, force_arrive)
+        nearest.append(int(ID))
+        slen.append(len(r[0]))
+        return r
+
+    planner._costs_to_go = ctg_spy
+    planner._steer = steer_spy
+
+    np.random.seed(PLAN_SEED)
+    t0 = time.time()
+    ret = planner.update_plan(rl.x0_of(name, ns), ns["sample_space"], goal_bias=ns["goal_bias"], xrand_gen=10)
+    wall = time.time() - t0
+
+    # how many (n+1)-double sampler candidates were consumed from the legacy global stream
+    probe = np.random.sample()
+    rs = np.random.RandomState(PLAN_SEED)
+    stream = rs.random_sample((len(xrands) * 12 + 64) * (n + 1))
+    pos = int(np.flatnonzero(stream == probe)[0])
+    assert pos % (n + 1) == 0
+    n_candidates = pos // (n + 1)
+
+    tree = planner.tree
+    iters = len(nearest)
+    # the fallback plan evaluates one extra _costs_to_go-like contraction inline, not via the spy
+    assert len(xrands) == iters
+    edge_len = np.array([len(s) for s in tree.x_seq], dtype=np.int32)
+    last_u = np.array([np.array(s[-1], dtype=np.float64) for s in tree.u_seq])
+    out = dict(
+        max_nodes=np.int64(max_nodes), min_time=np.float64(planner.min_time), iterations=np.int64(iters), n_candidates=np.int64(n_candidates),
+        returned=np.bool_(ret), reached_goal=np.bool_(planner.plan_reached_goal),
+        pID=np.array(tree.pID, dtype=np.int32), state=np.array(tree.state, dtype=np.float64),
+        K=np.array([lk[1] for lk in tree.lqr], dtype=np.float64),
+        edge_len=edge_len, last_u=last_u,
+        nearest=np.array(nearest, dtype=np.int32), steer_len=np.array(slen, dtype=np.int16),
+        xrand_head=np.array(xrands[:keep_xrand], dtype=np.float64),
+        node_seq=np.array(planner.node_seq, dtype=np.int32),
+        plan_x=np.array(planner.x_seq, dtype=np.float64), plan_u=np.array(planner.u_seq, dtype=np.float64),
+        plan_T=np.float64(planner.T), pid_hash=np.array(pid_hash(tree.pID)),
+        state_sum=np.float64(tree.state.sum()), ref_wall_s=np.float64(wall),
+        tie_iterations=np.int64(np.sum(ties)),
+    )
+    # a few complete edges (first, a middle one, the last) to pin x_seq/u_seq contents
+    for tagid, ID in (("a", 1), ("b", tree.size // 2), ("c", tree.size - 1)):
+        out["edge_%s_id" % tagid] = np.int32(ID)
+        out["edge_%s_x" % tagid] = np.array(tree.x_seq[ID], dtype=np.float64)
+        out["edge_%s_u" % tagid] = np.array(tree.u_seq[ID], dtype=np.float64)
+    path = os.path.join(OUT, "traj_%s_%s.npz" % (name, tag or str(max_nodes)))
+    np.savez_compressed(path, **out)
+    print("wrote %s: iters=%d cand=%d nodes=%d hash=%s sum=%r goal=%s ties=%d wall=%.1fs" % (
+        path, iters, n_candidates, tree.size, out["pid_hash"], float(out["state_sum"]),
+        bool(planner.plan_reached_goal), int(np.sum(ties)), wall))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--long", action="store_true", help="also run boat_advanced to 10k nodes (~20 min)")
+    ap.add_argument("--only", default=None, help="comma list: ops,traj")
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    what = set((args.only or "ops,traj").split(","))
+    if args.long:
+        run_traj("boat_advanced", 10000, keep_xrand=64, tag="10k")
+        return
+    if "ops" in what:
+        for name in rl.DEMOS:
+            gen_ops(name)
+    if "traj" in what:
+        run_traj("boat_advanced", 200)
+        run_traj("boat_intermediate", 300)
+        run_traj("boat_novice", 300)
+        run_traj("car", 500)
+        run_traj("pendulum", 150)
+        run_traj("car", 2000, keep_xrand=64)
+        run_traj("car", 2000, keep_xrand=64, tag="firstgoal", min_time=0)
+        run_traj("boat_novice", 1000, keep_xrand=64, tag="firstgoal", min_time=0)
+        run_traj("boat_advanced", 3000, keep_xrand=64)
+
+
+if __name__ == "__main__":
+    main()
