@@ -1,0 +1,243 @@
+/*
+ * lqrrt_hip.h -- C ABI of the MI355X (gfx950) lqRRT expansion engine.
+ *
+ * This is the drop-in boundary for the reference's extend path.  The reference
+ * (jnez71/lqRRT) has no FFI: its hot path is Python calling user callbacks.  Each entry
+ * point below names the reference code it replaces (file:line relative to the reference
+ * tree); INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (LQRRT_E_*); the message is
+ *     available from lqrrt_last_error(); nothing throws or aborts across the ABI;
+ *   - all floating point is IEEE double; node/sample indices are int32;
+ *   - "dev" pointers are device (HBM) addresses, e.g. torch tensor.data_ptr();
+ *     "host" pointers are ordinary process memory;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); launches are
+ *     asynchronous on it unless the function returns data to the host;
+ *   - an engine handle owns its device buffers; handles are independent (no globals).
+ *
+ * Layouts (all in HBM)
+ *   tree state   : SoA, component d of node i at state[d*capacity + i]   (coalesced scans)
+ *   tree trig    : cos/sin of every wrapped (angular) state, [2*NW][capacity]
+ *   tree gains   : K of node i at K[i*m*n .. ) row-major m x n            (planner.py:373)
+ *   tree edges   : node i owns xedge[i][H][n], uedge[i][H][m] + edge_len[i] (tree.py:69-70,90-93)
+ *   ignore set   : 1 bit per node, 64 nodes per uint64 word               (planner.py:173,270)
+ *   wave records : one fixed-size record per sample, see lqrrt_record_layout()
+ */
+#ifndef LQRRT_HIP_H
+#define LQRRT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LQRRT_ABI_VERSION 1
+
+/* error codes */
+#define LQRRT_OK            0
+#define LQRRT_E_ARG        -1   /* bad argument (the reference raises ValueError) */
+#define LQRRT_E_HIP        -2   /* HIP runtime failure */
+#define LQRRT_E_NODEVICE   -3   /* no usable gfx950 device */
+#define LQRRT_E_CAPACITY   -4   /* tree / pool capacity exceeded */
+#define LQRRT_E_STATE      -5   /* call sequence error (e.g. no goal, no tree) */
+
+/* problem plugins compiled into the engine (the callbacks defined in the reference's demo scripts) */
+#define LQRRT_MODEL_BOAT_ADVANCED      1  /* demos/demo_boat_advanced.py:78-225     */
+#define LQRRT_MODEL_BOAT_INTERMEDIATE  2  /* demos/demo_boat_intermediate.py:48-210 */
+#define LQRRT_MODEL_BOAT_NOVICE        3  /* demos/demo_boat_novice.py:45-164       */
+#define LQRRT_MODEL_CAR                4  /* demos/demo_car.py:46-180               */
+#define LQRRT_MODEL_PENDULUM           5  /* demos/demo_pendulum.py:54-157          */
+#define LQRRT_MODEL_DOUBLE_INTEGRATOR  6  /* BASELINE.json config 5 (not in the reference) */
+
+#define LQRRT_MAX_STATES   12
+#define LQRRT_MAX_CONTROLS 6
+#define LQRRT_MAX_PARAMS   96
+
+typedef struct lqrrt_engine lqrrt_engine;
+
+/* Plain-data description of a problem: replaces the python callables handed to
+ * Planner.__init__ / Constraints.__init__ (planner.py:85-100, constraints.py:31-35). */
+typedef struct {
+    int32_t model;                    /* LQRRT_MODEL_*                                  */
+    int32_t nstates, ncontrols;       /* constraints.py:32-33                            */
+    int32_t n_params;                 /* doubles used in params[]                        */
+    double  params[LQRRT_MAX_PARAMS]; /* model constants, layout in lqrrt_amd/systems.py */
+    int32_t n_vertices;               /* V: body-frame hull points, vps is 2 x V row-major */
+    int32_t n_obstacles;              /* O: rows of obs                                  */
+    int32_t obs_stride;               /* doubles per obstacle: 3 = circle [x,y,r], 6 = box [lo3,hi3] */
+    int32_t reserved;
+    const double* vps;                /* host, may be NULL when V == 0                   */
+    const double* obs;                /* host, may be NULL when O == 0                   */
+} lqrrt_system_desc;
+
+/* Resolution + goal (Planner.set_resolution planner.py:517-553, set_goal :468-487). */
+typedef struct {
+    double  dt;                          /* planner.py:86                                 */
+    double  FPR;                         /* failed-path retention, planner.py:394-395     */
+    int32_t horizon_iters;               /* int(horizon/dt), planner.py:549               */
+    int32_t has_goal;
+    double  error_tol[LQRRT_MAX_STATES]; /* planner.py:428,533                            */
+    double  goal[LQRRT_MAX_STATES];      /* planner.py:476                                */
+    double  goal_lo[LQRRT_MAX_STATES];   /* goal - buffer, strict test planner.py:442-447 */
+    double  goal_hi[LQRRT_MAX_STATES];   /* goal + buffer                                 */
+} lqrrt_resolution;
+
+/* Default sampler description (planner.py:176-211). */
+typedef struct {
+    double  centers[LQRRT_MAX_STATES];   /* mean(sample_space,1), planner.py:197          */
+    double  spans[LQRRT_MAX_STATES];     /* diff(sample_space),   planner.py:198          */
+    double  goal_bias[LQRRT_MAX_STATES]; /* planner.py:179-185                            */
+    int32_t tries_limit;                 /* planner.py:188-191                            */
+    int32_t reserved;
+} lqrrt_sampler_desc;
+
+/* Counters returned by lqrrt_engine_extend (host side). */
+typedef struct {
+    int64_t attempts;        /* extension attempts committed (= reference loop iterations) */
+    int64_t accepted;        /* nodes appended                                             */
+    int64_t candidates;      /* (n+1)-double sampler rows consumed from the MT19937 stream */
+    int64_t waves;           /* waves launched                                             */
+    int64_t fix_rounds;      /* exact-mode repair rounds (beyond the speculative pass)     */
+    int64_t resteers;        /* samples re-steered in repair rounds                        */
+    int64_t goal_hits;       /* accepted nodes inside the goal region                      */
+    int64_t speculated;      /* samples evaluated (>= attempts: discarded tails included)  */
+    int32_t tree_size;       /* nodes after the call                                       */
+    int32_t stop_reason;     /* LQRRT_STOP_*                                               */
+} lqrrt_extend_stats;
+
+#define LQRRT_STOP_ATTEMPTS  1  /* max_attempts reached                                  */
+#define LQRRT_STOP_NODES     2  /* tree.size > max_nodes (planner.py:311)                */
+#define LQRRT_STOP_TARGET    3  /* tree.size >= until_size                                */
+#define LQRRT_STOP_GOAL      4  /* a goal hit was committed and stop_on_goal was set      */
+
+/* ---------------------------------------------------------------- lifecycle ---------- */
+
+const char* lqrrt_last_error(void);
+int lqrrt_abi_version(void);
+
+/* Number of usable HIP devices (0 when there is no GPU: every compute call then fails). */
+int lqrrt_device_count(void);
+
+/* Creates an engine on `device`.  capacity = max nodes the tree may hold,
+ * max_wave = largest wave size W.  Replaces Planner.set_system (planner.py:557-592). */
+int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int capacity, int max_wave,
+                        lqrrt_engine** out);
+int lqrrt_engine_destroy(lqrrt_engine* e);
+
+/* Changing horizon_iters re-lays out the edge pools: call lqrrt_tree_reset afterwards. */
+int lqrrt_engine_set_resolution(lqrrt_engine* e, const lqrrt_resolution* r);
+
+/* Constant dense cost-to-go matrix S = lqr(x,u)[0] of the system (host, n x n row-major);
+ * NULL = identity, which is what every demo of the reference returns (e.g.
+ * demo_boat_advanced.py:149).  Used by lqrrt_nn_argmin / lqrrt_costs_to_go / the waves. */
+int lqrrt_engine_set_dense_S(lqrrt_engine* e, const double* S_host);
+int lqrrt_engine_set_sampler(lqrrt_engine* e, const lqrrt_sampler_desc* s);
+
+/* Legacy MT19937 state of numpy.random (planner.py:204-205 draws np.random.sample):
+ * key[624] + position, exactly np.random.get_state()[1:3]. */
+int lqrrt_engine_set_mt19937(lqrrt_engine* e, const uint32_t* key624, int pos);
+int lqrrt_engine_get_mt19937(lqrrt_engine* e, uint32_t* key624, int* pos);
+
+/* ---------------------------------------------------------------- tree --------------- */
+
+/* Tree(seed_state, lqr(seed)) -- tree.py:50-73 via planner.py:172.  Clears the ignore set. */
+int lqrrt_tree_reset(lqrrt_engine* e, const double* x0_host, void* stream);
+int lqrrt_tree_size(lqrrt_engine* e);
+
+/* Host copies of tree features (planner.tree.state / .pID / .lqr / .x_seq / .u_seq). */
+int lqrrt_tree_get_states(lqrrt_engine* e, int first, int count, double* out_host /*[count][n]*/);
+int lqrrt_tree_get_gains(lqrrt_engine* e, int first, int count, double* out_host /*[count][m][n]*/);
+int lqrrt_tree_get_parents(lqrrt_engine* e, int first, int count, int32_t* out_host);
+int lqrrt_tree_get_edge_lengths(lqrrt_engine* e, int first, int count, int32_t* out_host);
+/* edge of one node: x [len][n], u [len][m]; returns len (root: 1, tree.py:69-70) */
+int lqrrt_tree_get_edge(lqrrt_engine* e, int id, double* x_host, double* u_host);
+int lqrrt_tree_get_ignored(lqrrt_engine* e, int first, int count, uint8_t* out_host);
+
+/* ---------------------------------------------------------------- operators ---------- */
+
+/* Constraints.is_feasible over a batch (constraints.py:53-61, plugins e.g.
+ * demo_boat_advanced.py:209-225).  x [B][n], u [B][m] (NULL = zeros) -> ok [B] (0/1). */
+int lqrrt_feasible_batch(lqrrt_engine* e, const double* x_dev, const double* u_dev, int B,
+                         uint8_t* ok_dev, void* stream);
+
+/* dynamics(x,u,dt) over a batch (e.g. demo_boat_advanced.py:78-130). x [B][n], u [B][m]. */
+int lqrrt_dynamics_batch(lqrrt_engine* e, const double* x_dev, const double* u_dev, int B,
+                         double* xnext_dev, void* stream);
+
+/* lqr(x,u)[1] over a batch (e.g. demo_boat_advanced.py:139-151): K [B][m][n]. */
+int lqrrt_gain_batch(lqrrt_engine* e, const double* x_dev, const double* u_dev, int B,
+                     double* K_dev, void* stream);
+
+/* erf(xgoal,x) over a batch (e.g. demo_boat_advanced.py:153-164): e [B][n]. */
+int lqrrt_erf_batch(lqrrt_engine* e, const double* xg_dev, const double* x_dev, int B,
+                    double* e_dev, void* stream);
+
+/* Planner._costs_to_go + nearest selection (planner.py:239-247, 340-350) for W samples
+ * against the current tree: id[W] = lowest-cost non-ignored node (lowest id on ties; the
+ * overall best when every node is ignored), cost[W] its cost.  S_dev: NULL = the system's
+ * own S; else a dense n x n matrix used for every sample (planner.py:313-318 guide search).
+ * use_ignore = 0 reproduces pruning=False (np.argmin, planner.py:247). */
+int lqrrt_nn_argmin(lqrrt_engine* e, const double* xs_dev /*[W][n]*/, int W, const double* S_dev,
+                    int use_ignore, int32_t* id_dev, double* cost_dev, void* stream);
+
+/* Full cost vector of one sample against the tree (planner.py:340-350), cost [tree_size]. */
+int lqrrt_costs_to_go(lqrrt_engine* e, const double* x_dev /*[n]*/, const double* S_dev,
+                      double* cost_dev, void* stream);
+
+/* Planner._steer(ID, xtar, force_arrive=False) for W problems (planner.py:354-438), one per
+ * wavefront.  Outputs: len[W] recorded steps, xseq [W][H][n], useq [W][H][m] (first len rows
+ * valid), xend [W][n] (= xseq[len-1]), Kend [W][m][n] = lqr(xend, ulast)[1]. Any output may
+ * be NULL. */
+int lqrrt_steer_batch(lqrrt_engine* e, const int32_t* parent_dev, const double* xtar_dev, int W,
+                      int32_t* len_dev, double* xseq_dev, double* useq_dev, double* xend_dev,
+                      double* Kend_dev, void* stream);
+
+/* ---------------------------------------------------------------- wave engine -------- */
+
+/* Doubles per wave record and field offsets (for the RCCL all-gather of records):
+ * layout[0]=record doubles, [1]=off_cost, [2]=off_parent, [3]=off_len, [4]=off_flags,
+ * [5]=off_xend, [6]=off_trig, [7]=off_K, [8]=off_xseq, [9]=off_useq, [10]=off_xrand. */
+int lqrrt_record_layout(lqrrt_engine* e, int32_t* layout11);
+
+/* Device address of the engine's wave record buffer [max_wave][record doubles]. */
+int lqrrt_wave_records(lqrrt_engine* e, void** dev_ptr);
+
+/* Phase A of a wave (shardable): prepares samples [k0, k0+W) of the sample stream if needed,
+ * then runs the speculative nearest-neighbour + steer for the slice [lo,hi) of the wave
+ * against the current tree and writes records lo..hi-1.  Other ranks fill the rest
+ * (all-gather of the record buffer), then every rank calls lqrrt_wave_commit. */
+int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void* stream);
+
+/* Phase B (replicated): exact-mode validation/repair of the W records in sample order,
+ * then append.  max_commit caps the attempts committed from this wave; node_limit is the
+ * reference's max_nodes (stop once size > max_nodes, planner.py:311).  Advances the sample
+ * cursor by the number of committed attempts.  Returns stats for this wave. */
+int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_limit,
+                      int pruning, lqrrt_extend_stats* out, void* stream);
+
+/* The planner loop body planner.py:233-290 run natively for many waves on one GPU:
+ * grows the tree until max_attempts more attempts were committed, or size > node_limit, or
+ * size >= until_size (0 = off), or (stop_on_goal) a goal hit was committed. wave = W cap. */
+int lqrrt_engine_extend(lqrrt_engine* e, int wave, int64_t max_attempts, int64_t node_limit,
+                        int until_size, int pruning, int stop_on_goal,
+                        lqrrt_extend_stats* out, void* stream);
+
+/* Goal bookkeeping (planner.py:260-283): number of goal hits so far and the node id of
+ * the best (shortest, first on ties) plan end, its length in steps; -1 if none. */
+int lqrrt_plan_best(lqrrt_engine* e, int32_t* end_node, int64_t* steps, int64_t* hits);
+
+/* Total attempts / candidate rows consumed since the last tree reset. */
+int lqrrt_engine_counters(lqrrt_engine* e, lqrrt_extend_stats* out);
+
+/* Timing of the dominant kernel (NN scan) accumulated with HIP events on `stream`
+ * when enabled: total ms, launches, algorithmic bytes (sum of W*N*(8n+1)). */
+int lqrrt_profile_enable(lqrrt_engine* e, int on);
+int lqrrt_profile_read(lqrrt_engine* e, double* nn_ms, int64_t* nn_launches, double* nn_bytes,
+                       double* steer_ms, int64_t* steer_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LQRRT_HIP_H */

@@ -1,0 +1,49 @@
+"""
+Constraints -- same class surface as the reference's lqrrt/constraints.py:17-61: state and
+effort dimensionality, the goal buffer, and the feasibility function.  The feasibility
+function must be the `.is_feasible` plugin handle of a native system (lqrrt_amd.systems):
+the collision sweep runs inside the HIP steer kernel, one problem per wavefront.
+"""
+import numpy as np
+
+from .systems import plugin_system
+
+
+class Constraints:
+    """
+    To initialize, provide...
+
+    nstates: The dimensionality of the state space.
+
+    ncontrols: The dimensionality of the effort space.
+
+    goal_buffer: Half-edge lengths of box defining goal region.
+
+    is_feasible: The `.is_feasible` handle of an lqrrt_amd.systems object
+                 (callable as is_feasible(x, u) -> bool, evaluated on the GPU).
+
+    """
+
+    def __init__(self, nstates, ncontrols, goal_buffer, is_feasible):
+        self.nstates = nstates
+        self.ncontrols = ncontrols
+        self.set_buffers(goal_buffer)
+        self.set_feasibility_function(is_feasible)
+
+    def set_buffers(self, goal_buffer=None):
+        """Arguments not given are not modified (constraints.py:39-49)."""
+        if goal_buffer is not None:
+            if len(goal_buffer) == self.nstates:
+                self.goal_buffer = np.abs(goal_buffer).astype(np.float64)
+            else:
+                raise ValueError("The goal_buffer must have same dimensionality as state.")
+
+    def set_feasibility_function(self, is_feasible):
+        """constraints.py:53-61, restricted to native plugin handles."""
+        if not hasattr(is_feasible, '__call__'):
+            raise ValueError("Expected is_feasible to be a function.")
+        system = plugin_system(is_feasible, "is_feasible")
+        if system.nstates != self.nstates or system.ncontrols != self.ncontrols:
+            raise ValueError("The feasibility plugin is for a %d-state/%d-effort system." % (system.nstates, system.ncontrols))
+        self.is_feasible = is_feasible
+        self.system = system

@@ -1,0 +1,1001 @@
+// Host side of the MI355X lqRRT expansion engine: device buffers, the sample stream
+// (NumPy-compatible MT19937), wave orchestration (speculate -> exact-mode repair -> append)
+// and the C ABI declared in include/lqrrt_hip.h.
+//
+// Reference mapping: this file plays the role of Planner.update_plan's loop body
+// (planner.py:233-290) and of Tree (tree.py) for problems whose plugins are compiled in
+// (systems.hpp).  There is no CPU compute path: without a HIP device every compute entry
+// point returns LQRRT_E_NODEVICE.
+#include "../../include/lqrrt_hip.h"
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace lq;
+
+// --------------------------------------------------------------------------------------------
+// error plumbing
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(call)                                                                         \
+    do {                                                                                     \
+        hipError_t err__ = (call);                                                           \
+        if (err__ != hipSuccess)                                                             \
+            return fail(LQRRT_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+#define TRY(call)                 \
+    do {                          \
+        int rc__ = (call);        \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+// --------------------------------------------------------------------------------------------
+// MT19937 exactly as numpy.random's legacy generator (np.random.sample, planner.py:204-205)
+
+struct MT {
+    uint32_t key[624];
+    int pos = 624;
+    void gen() {
+        const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MAG = 0x9908b0dfu;
+        int i;
+        uint32_t y;
+        for (i = 0; i < 624 - 397; ++i) {
+            y = (key[i] & UPPER) | (key[i + 1] & LOWER);
+            key[i] = key[i + 397] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
+        }
+        for (; i < 623; ++i) {
+            y = (key[i] & UPPER) | (key[i + 1] & LOWER);
+            key[i] = key[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
+        }
+        y = (key[623] & UPPER) | (key[0] & LOWER);
+        key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
+        pos = 0;
+    }
+    uint32_t next32() {
+        if (pos >= 624) gen();
+        uint32_t y = key[pos++];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        return y;
+    }
+    double next_double() {   // 53-bit resolution, the legacy random_sample
+        const uint32_t a = next32() >> 5, b = next32() >> 6;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+};
+
+// --------------------------------------------------------------------------------------------
+
+struct EvPair { hipEvent_t a, b; double bytes; int kind; };
+
+struct lqrrt_engine {
+    int device = 0;
+    int model = 0, n = 0, m = 0, nw = 0;
+    int cap = 0, maxW = 0, H = 0;
+    Params P;
+    Geo geo{};
+    Res res{};
+    bool has_res = false, has_goal = false, has_sampler = false;
+    lqrrt_sampler_desc smp{};
+    double goal[MAXN];
+    double* d_vps = nullptr;
+    double* d_obs = nullptr;
+    double* d_S = nullptr;        // dense system S (n x n) or null = identity
+
+    // tree
+    TreeView tv{};
+    int N = 0;
+    std::vector<int> h_pid, h_elen;
+    std::vector<unsigned long long> h_ign;
+    bool ign_dirty = false;
+    int64_t goal_hits = 0;
+    int best_end = -1;
+    int64_t best_steps = -1;
+
+    // wave buffers
+    RecLayout L{};
+    double* d_rec = nullptr;
+    double *d_pcost = nullptr, *d_pcost_all = nullptr, *d_wcost = nullptr;
+    int *d_pidx = nullptr, *d_pidx_all = nullptr, *d_wid = nullptr;
+    int *d_par_done = nullptr, *d_par_want = nullptr, *d_list = nullptr, *d_rank = nullptr;
+    unsigned char *d_changed = nullptr, *d_stale = nullptr, *d_need = nullptr;
+    unsigned long long* d_wmask = nullptr;
+    int* d_summary = nullptr;     // [2 + 3*maxW]
+    int* h_summary = nullptr;     // pinned
+    int* h_rank = nullptr;        // pinned
+    static constexpr int MAXCH = 256;
+
+    // sample stream
+    MT mt_gen, mt_base;
+    int64_t base_row = 0;         // candidate-row index mt_base is positioned at
+    int64_t gen_row = 0;          // rows generated so far (mt_gen position)
+    int64_t committed_row = 0;    // rows consumed by committed attempts
+    int64_t cursor = 0;           // next sample index to attempt
+    int64_t pool_base = 0;        // sample index of pool[0]
+    std::vector<double> pool;     // [count][n] prepared samples
+    std::vector<int64_t> pool_rows_end;  // candidate rows consumed through each pooled sample
+    int tries_carry = 0;          // tries already spent on the sample under construction
+    std::vector<double> carry_row;
+    double* d_pool = nullptr;     // device mirror of the samples [cursor_at_upload ..)
+    int64_t d_pool_base = 0, d_pool_count = 0;
+    int64_t d_pool_cap = 0;
+    double* d_cand = nullptr;
+    unsigned char* d_flags = nullptr;
+    int cand_cap = 0;
+
+    // counters
+    lqrrt_extend_stats tot{};
+
+    // profiling
+    bool prof = false;
+    std::vector<EvPair> evs;
+    double nn_ms = 0, nn_bytes = 0, steer_ms = 0;
+    int64_t nn_launches = 0, steer_launches = 0;
+};
+
+// --------------------------------------------------------------------------------------------
+// model dispatch
+
+#define DISPATCH(e, ...)                                                                          \
+    switch ((e)->model) {                                                                         \
+        case LQRRT_MODEL_BOAT_ADVANCED:     { using S = BoatAdvanced;     __VA_ARGS__; } break;   \
+        case LQRRT_MODEL_BOAT_INTERMEDIATE: { using S = BoatIntermediate; __VA_ARGS__; } break;   \
+        case LQRRT_MODEL_BOAT_NOVICE:       { using S = BoatNovice;       __VA_ARGS__; } break;   \
+        case LQRRT_MODEL_CAR:               { using S = Car;              __VA_ARGS__; } break;   \
+        case LQRRT_MODEL_PENDULUM:          { using S = Pendulum;         __VA_ARGS__; } break;   \
+        case LQRRT_MODEL_DOUBLE_INTEGRATOR: { using S = DoubleIntegratorT<6>; __VA_ARGS__; } break; \
+        default: return fail(LQRRT_E_ARG, "unknown model %d", (e)->model);                        \
+    }
+
+static bool model_dims(int model, int* n, int* m, int* nw) {
+    switch (model) {
+        case LQRRT_MODEL_BOAT_ADVANCED:
+        case LQRRT_MODEL_BOAT_INTERMEDIATE:
+        case LQRRT_MODEL_BOAT_NOVICE: *n = 6; *m = 3; *nw = 1; return true;
+        case LQRRT_MODEL_CAR: *n = 5; *m = 2; *nw = 1; return true;
+        case LQRRT_MODEL_PENDULUM: *n = 4; *m = 1; *nw = 2; return true;
+        case LQRRT_MODEL_DOUBLE_INTEGRATOR: *n = 12; *m = 6; *nw = 0; return true;
+    }
+    return false;
+}
+
+static int use_device(lqrrt_engine* e) {
+    HIPCHK(hipSetDevice(e->device));
+    return 0;
+}
+
+template <class T>
+static int dalloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIPCHK(hipMalloc((void**)p, count * sizeof(T)));
+    return 0;
+}
+
+static NodeView tree_view(const lqrrt_engine* e, bool use_ignore) {
+    NodeView v;
+    v.x = e->tv.state; v.trig = e->tv.trig;
+    v.sn = 1; v.sd = e->cap; v.tn = 1; v.td = e->cap;
+    v.ignore = use_ignore ? e->tv.ignore : nullptr;
+    v.count = e->N; v.pad = 0;
+    return v;
+}
+
+static NodeView record_view(const lqrrt_engine* e, int W) {
+    NodeView v;
+    v.x = e->d_rec + e->L.off_xend; v.trig = e->d_rec + e->L.off_trig;
+    v.sn = e->L.R; v.sd = 1; v.tn = e->L.R; v.td = 1;
+    v.ignore = e->d_wmask;
+    v.count = W; v.pad = 0;
+    return v;
+}
+
+// --------------------------------------------------------------------------------------------
+// profiling helpers
+
+static void prof_begin(lqrrt_engine* e, hipStream_t st, EvPair* ev) {
+    if (!e->prof) return;
+    (void)hipEventCreate(&ev->a);
+    (void)hipEventCreate(&ev->b);
+    (void)hipEventRecord(ev->a, st);
+}
+static void prof_end(lqrrt_engine* e, hipStream_t st, EvPair* ev, int kind, double bytes) {
+    if (!e->prof) return;
+    (void)hipEventRecord(ev->b, st);
+    ev->kind = kind; ev->bytes = bytes;
+    e->evs.push_back(*ev);
+}
+static void prof_flush(lqrrt_engine* e) {
+    for (auto& ev : e->evs) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(ev.b);
+        (void)hipEventElapsedTime(&ms, ev.a, ev.b);
+        if (ev.kind == 0) { e->nn_ms += ms; e->nn_bytes += ev.bytes; e->nn_launches++; }
+        else { e->steer_ms += ms; e->steer_launches++; }
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    e->evs.clear();
+}
+
+// --------------------------------------------------------------------------------------------
+// kernel launch wrappers
+
+static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
+    const int groups = (W + 63) / 64;
+    int want = 4096 / (groups > 0 ? groups : 1);
+    want = std::max(1, std::min(want, (int)lqrrt_engine::MAXCH));
+    int c = (count + want - 1) / want;
+    c = std::max(c, 8);
+    *chunk = c;
+    *n_chunks = std::max(1, (count + c - 1) / c);
+}
+
+// NN over a node table for W samples at xs (device, [W][n]); writes id/cost and/or records.
+static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int W, const double* Sd,
+                     bool tri, bool want_all, int* out_id, double* out_cost, double* rec, hipStream_t st,
+                     bool profile) {
+    if (W <= 0) return 0;
+    int chunk, n_chunks;
+    pick_chunks(nv.count, W, &chunk, &n_chunks);
+    dim3 grid((W + 63) / 64, n_chunks);
+    const double* S_use = Sd ? Sd : e->d_S;
+    double* pca = want_all ? e->d_pcost_all : nullptr;
+    int* pia = want_all ? e->d_pidx_all : nullptr;
+    EvPair ev;
+    if (profile) prof_begin(e, st, &ev);
+    if (S_use) {
+        DISPATCH(e, hipLaunchKernelGGL((k_nn_scan<S, true>), grid, dim3(64), 0, st, nv, xs, W, S_use, chunk,
+                                        tri ? 1 : 0, e->d_pcost, e->d_pidx, pca, pia));
+    } else {
+        DISPATCH(e, hipLaunchKernelGGL((k_nn_scan<S, false>), grid, dim3(64), 0, st, nv, xs, W, S_use, chunk,
+                                        tri ? 1 : 0, e->d_pcost, e->d_pidx, pca, pia));
+    }
+    if (profile) prof_end(e, st, &ev, 0, (double)W * (double)nv.count * (8.0 * e->n + 1.0));
+    hipLaunchKernelGGL(k_nn_reduce, dim3((W + 255) / 256), dim3(256), 0, st, e->d_pcost, e->d_pidx, pca, pia, W,
+                       n_chunks, out_id, out_cost, rec, e->L.R, e->L.off_cost, e->L.off_parent);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int launch_steer(lqrrt_engine* e, const double* xs, const int* list, int lo, int count,
+                        const int* par, hipStream_t st) {
+    if (count <= 0) return 0;
+    const size_t lds = (size_t)e->H * (e->n + e->m) * sizeof(double);
+    EvPair ev;
+    prof_begin(e, st, &ev);
+    DISPATCH(e, hipLaunchKernelGGL((k_steer<S>), dim3(count), dim3(64), lds, st, e->P, e->geo, e->res, e->tv,
+                                    e->d_rec, e->L, xs, list, lo, par));
+    prof_end(e, st, &ev, 1, 0.0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// lifecycle
+
+extern "C" const char* lqrrt_last_error(void) { return g_err.c_str(); }
+extern "C" int lqrrt_abi_version(void) { return LQRRT_ABI_VERSION; }
+
+extern "C" int lqrrt_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return c;
+}
+
+static void free_all(lqrrt_engine* e) {
+    void* ptrs[] = {e->d_vps, e->d_obs, e->d_S, e->tv.state, e->tv.trig, e->tv.K, e->tv.pID, e->tv.elen,
+                    e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_pcost_all, e->d_wcost,
+                    e->d_pidx, e->d_pidx_all, e->d_wid, e->d_par_done, e->d_par_want, e->d_list, e->d_rank,
+                    e->d_changed, e->d_stale, e->d_need, e->d_wmask, e->d_summary, e->d_pool, e->d_cand, e->d_flags};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e->h_summary) (void)hipHostFree(e->h_summary);
+    if (e->h_rank) (void)hipHostFree(e->h_rank);
+}
+
+static int alloc_wave(lqrrt_engine* e) {
+    // (re)allocates everything that depends on H (record size, edge pools)
+    void* old[] = {e->tv.xedge, e->tv.uedge, e->d_rec};
+    for (void* p : old)
+        if (p) (void)hipFree(p);
+    e->tv.xedge = e->tv.uedge = nullptr; e->d_rec = nullptr;
+    e->L = make_layout(e->n, e->m, e->nw, e->H);
+    e->tv.H = e->H;
+    TRY(dalloc(&e->tv.xedge, (size_t)e->cap * e->H * e->n));
+    TRY(dalloc(&e->tv.uedge, (size_t)e->cap * e->H * e->m));
+    TRY(dalloc(&e->d_rec, (size_t)e->maxW * e->L.R));
+    HIPCHK(hipMemset(e->d_rec, 0, (size_t)e->maxW * e->L.R * sizeof(double)));
+    return 0;
+}
+
+extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int capacity, int max_wave,
+                                   lqrrt_engine** out) {
+    if (!sys || !out) return fail(LQRRT_E_ARG, "null argument");
+    *out = nullptr;
+    int n, m, nw;
+    if (!model_dims(sys->model, &n, &m, &nw)) return fail(LQRRT_E_ARG, "unknown model %d", sys->model);
+    if (sys->nstates != n || sys->ncontrols != m)
+        return fail(LQRRT_E_ARG, "model %d expects nstates=%d ncontrols=%d, got %d/%d", sys->model, n, m,
+                    sys->nstates, sys->ncontrols);
+    if (capacity < 2 || max_wave < 1 || max_wave > 4096)
+        return fail(LQRRT_E_ARG, "capacity must be >= 2 and 1 <= max_wave <= 4096");
+    if (sys->n_params < 0 || sys->n_params > LQRRT_MAX_PARAMS) return fail(LQRRT_E_ARG, "bad n_params");
+    if (lqrrt_device_count() <= device || device < 0)
+        return fail(LQRRT_E_NODEVICE, "HIP device %d not available (found %d)", device, lqrrt_device_count());
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (prop.warpSize != 64) return fail(LQRRT_E_NODEVICE, "wavefront size %d != 64 (gfx950 expected)", prop.warpSize);
+
+    lqrrt_engine* e = new lqrrt_engine();
+    e->device = device; e->model = sys->model; e->n = n; e->m = m; e->nw = nw;
+    e->cap = ((capacity + 63) / 64) * 64; e->maxW = max_wave; e->H = 1;
+    memset(&e->P, 0, sizeof e->P);
+    memcpy(e->P.p, sys->params, sizeof(double) * sys->n_params);
+    int rc = 0;
+    auto up = [&](double** dst, const double* src, size_t cnt) -> int {
+        TRY(dalloc(dst, cnt));
+        if (cnt) HIPCHK(hipMemcpy(*dst, src, cnt * sizeof(double), hipMemcpyHostToDevice));
+        return 0;
+    };
+    e->geo.V = sys->n_vertices; e->geo.O = sys->n_obstacles;
+    e->geo.stride = sys->obs_stride > 0 ? sys->obs_stride : 3; e->geo.pad = 0;
+    if ((sys->n_vertices > 0 && !sys->vps) || (sys->n_obstacles > 0 && !sys->obs)) {
+        delete e;
+        return fail(LQRRT_E_ARG, "vps/obs pointer missing");
+    }
+    rc = up(&e->d_vps, sys->vps, (size_t)2 * sys->n_vertices);
+    if (!rc) rc = up(&e->d_obs, sys->obs, (size_t)sys->n_obstacles * e->geo.stride);
+    e->geo.vps = e->d_vps; e->geo.obs = e->d_obs;
+    e->tv.cap = e->cap;
+    if (!rc) rc = dalloc(&e->tv.state, (size_t)n * e->cap);
+    if (!rc) rc = dalloc(&e->tv.trig, (size_t)(2 * nw + 1) * e->cap);
+    if (!rc) rc = dalloc(&e->tv.K, (size_t)e->cap * m * n);
+    if (!rc) rc = dalloc(&e->tv.pID, (size_t)e->cap);
+    if (!rc) rc = dalloc(&e->tv.elen, (size_t)e->cap);
+    if (!rc) rc = dalloc(&e->tv.ignore, (size_t)e->cap / 64 + 1);
+    const size_t pw = (size_t)lqrrt_engine::MAXCH * e->maxW;
+    if (!rc) rc = dalloc(&e->d_pcost, pw);
+    if (!rc) rc = dalloc(&e->d_pcost_all, pw);
+    if (!rc) rc = dalloc(&e->d_pidx, pw);
+    if (!rc) rc = dalloc(&e->d_pidx_all, pw);
+    if (!rc) rc = dalloc(&e->d_wcost, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_wid, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_par_done, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_par_want, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_list, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_rank, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_changed, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_stale, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_need, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_wmask, (size_t)e->maxW / 64 + 1);
+    if (!rc) rc = dalloc(&e->d_summary, (size_t)2 + 3 * e->maxW);
+    if (!rc && hipHostMalloc((void**)&e->h_summary, sizeof(int) * (2 + 3 * (size_t)e->maxW)) != hipSuccess)
+        rc = fail(LQRRT_E_HIP, "hipHostMalloc failed");
+    if (!rc && hipHostMalloc((void**)&e->h_rank, sizeof(int) * (size_t)e->maxW) != hipSuccess)
+        rc = fail(LQRRT_E_HIP, "hipHostMalloc failed");
+    if (!rc) rc = alloc_wave(e);
+    if (rc) { free_all(e); delete e; return rc; }
+    e->h_pid.reserve(e->cap); e->h_elen.reserve(e->cap);
+    e->h_ign.assign((size_t)e->cap / 64 + 1, 0ull);
+    for (int i = 0; i < 624; ++i) e->mt_gen.key[i] = 0;
+    e->mt_gen.pos = 624;
+    e->mt_base = e->mt_gen;
+    *out = e;
+    return 0;
+}
+
+extern "C" int lqrrt_engine_destroy(lqrrt_engine* e) {
+    if (!e) return 0;
+    (void)hipSetDevice(e->device);
+    prof_flush(e);
+    free_all(e);
+    delete e;
+    return 0;
+}
+
+extern "C" int lqrrt_engine_set_dense_S(lqrrt_engine* e, const double* S_host) {
+    // constant dense cost-to-go matrix of the system (lqr(x,u)[0]); NULL restores identity
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    TRY(use_device(e));
+    if (e->d_S) { (void)hipFree(e->d_S); e->d_S = nullptr; }
+    if (S_host) {
+        TRY(dalloc(&e->d_S, (size_t)e->n * e->n));
+        HIPCHK(hipMemcpy(e->d_S, S_host, sizeof(double) * e->n * e->n, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+extern "C" int lqrrt_engine_set_resolution(lqrrt_engine* e, const lqrrt_resolution* r) {
+    if (!e || !r) return fail(LQRRT_E_ARG, "null argument");
+    if (r->horizon_iters < 1 || r->horizon_iters > 4096) return fail(LQRRT_E_ARG, "horizon_iters out of range");
+    if (!(r->dt > 0)) return fail(LQRRT_E_ARG, "dt must be positive");
+    TRY(use_device(e));
+    e->res.dt = r->dt; e->res.FPR = r->FPR; e->res.H = r->horizon_iters; e->res.pad = 0;
+    for (int d = 0; d < MAXN; ++d) {
+        e->res.tol[d] = r->error_tol[d];
+        e->res.goal_lo[d] = r->goal_lo[d];
+        e->res.goal_hi[d] = r->goal_hi[d];
+        e->goal[d] = r->goal[d];
+    }
+    const bool goal_changed = true;
+    e->has_goal = r->has_goal != 0;
+    e->has_res = true;
+    if (r->horizon_iters != e->H) {
+        e->N = 0;   // edge pools are re-laid out: the tree must be reset afterwards
+        e->H = r->horizon_iters;
+        TRY(alloc_wave(e));
+    }
+    if (goal_changed) {
+        // goal-biased samples depend on the goal: drop prepared-but-unused samples and rewind the generator
+        e->pool.clear(); e->pool_rows_end.clear();
+        e->pool_base = e->cursor;
+        MT g = e->mt_base;
+        for (int64_t i = 0; i < (e->committed_row - e->base_row) * (int64_t)(e->n + 1); ++i) (void)g.next_double();
+        e->mt_base = g; e->base_row = e->committed_row;
+        e->mt_gen = g; e->gen_row = e->committed_row;
+        e->tries_carry = 0; e->d_pool_count = 0;
+    }
+    return 0;
+}
+
+extern "C" int lqrrt_engine_set_sampler(lqrrt_engine* e, const lqrrt_sampler_desc* s) {
+    if (!e || !s) return fail(LQRRT_E_ARG, "null argument");
+    if (s->tries_limit < 1) return fail(LQRRT_E_ARG, "tries_limit must be >= 1");
+    e->smp = *s;
+    e->has_sampler = true;
+    // same invalidation as a goal change
+    e->pool.clear(); e->pool_rows_end.clear();
+    e->pool_base = e->cursor;
+    MT g = e->mt_base;
+    for (int64_t i = 0; i < (e->committed_row - e->base_row) * (int64_t)(e->n + 1); ++i) (void)g.next_double();
+    e->mt_base = g; e->base_row = e->committed_row;
+    e->mt_gen = g; e->gen_row = e->committed_row;
+    e->tries_carry = 0; e->d_pool_count = 0;
+    return 0;
+}
+
+extern "C" int lqrrt_engine_set_mt19937(lqrrt_engine* e, const uint32_t* key624, int pos) {
+    if (!e || !key624) return fail(LQRRT_E_ARG, "null argument");
+    if (pos < 0 || pos > 624) return fail(LQRRT_E_ARG, "bad MT19937 position");
+    memcpy(e->mt_gen.key, key624, sizeof(uint32_t) * 624);
+    e->mt_gen.pos = pos;
+    e->mt_base = e->mt_gen;
+    e->base_row = e->gen_row = e->committed_row = 0;
+    e->pool.clear(); e->pool_rows_end.clear();
+    e->pool_base = e->cursor;
+    e->tries_carry = 0; e->d_pool_count = 0;
+    return 0;
+}
+
+extern "C" int lqrrt_engine_get_mt19937(lqrrt_engine* e, uint32_t* key624, int* pos) {
+    if (!e || !key624 || !pos) return fail(LQRRT_E_ARG, "null argument");
+    MT g = e->mt_base;
+    for (int64_t i = 0; i < (e->committed_row - e->base_row) * (int64_t)(e->n + 1); ++i) (void)g.next_double();
+    e->mt_base = g; e->base_row = e->committed_row;
+    memcpy(key624, g.key, sizeof(uint32_t) * 624);
+    *pos = g.pos;
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// tree
+
+extern "C" int lqrrt_tree_reset(lqrrt_engine* e, const double* x0_host, void* stream) {
+    if (!e || !x0_host) return fail(LQRRT_E_ARG, "null argument");
+    TRY(use_device(e));
+    hipStream_t st = (hipStream_t)stream;
+    double* d_x0 = e->d_wcost;    // scratch (>= 1 double... need n): use pcost
+    d_x0 = e->d_pcost;
+    HIPCHK(hipMemcpyAsync(d_x0, x0_host, sizeof(double) * e->n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(e->tv.ignore, 0, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1), st));
+    DISPATCH(e, hipLaunchKernelGGL((k_tree_root<S>), dim3(1), dim3(64), 0, st, e->P, e->tv, d_x0));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    e->N = 1;
+    e->h_pid.assign(1, -1);
+    e->h_elen.assign(1, 1);
+    std::fill(e->h_ign.begin(), e->h_ign.end(), 0ull);
+    e->ign_dirty = false;
+    e->goal_hits = 0; e->best_end = -1; e->best_steps = -1;
+    memset(&e->tot, 0, sizeof e->tot);
+    e->tot.tree_size = 1;
+    return 0;
+}
+
+extern "C" int lqrrt_tree_size(lqrrt_engine* e) { return e ? e->N : LQRRT_E_ARG; }
+
+static int range_ok(lqrrt_engine* e, int first, int count) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    if (first < 0 || count < 0 || first + count > e->N)
+        return fail(LQRRT_E_ARG, "node range [%d,%d) outside the tree (size %d)", first, first + count, e->N);
+    return 0;
+}
+
+extern "C" int lqrrt_tree_get_states(lqrrt_engine* e, int first, int count, double* out) {
+    TRY(range_ok(e, first, count));
+    if (!count) return 0;
+    TRY(use_device(e));
+    std::vector<double> tmp((size_t)count);
+    for (int d = 0; d < e->n; ++d) {
+        HIPCHK(hipMemcpy(tmp.data(), e->tv.state + (size_t)d * e->cap + first, sizeof(double) * count, hipMemcpyDeviceToHost));
+        for (int i = 0; i < count; ++i) out[(size_t)i * e->n + d] = tmp[i];
+    }
+    return 0;
+}
+
+extern "C" int lqrrt_tree_get_gains(lqrrt_engine* e, int first, int count, double* out) {
+    TRY(range_ok(e, first, count));
+    if (!count) return 0;
+    TRY(use_device(e));
+    HIPCHK(hipMemcpy(out, e->tv.K + (size_t)first * e->m * e->n, sizeof(double) * count * e->m * e->n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int lqrrt_tree_get_parents(lqrrt_engine* e, int first, int count, int32_t* out) {
+    TRY(range_ok(e, first, count));
+    if (!count) return 0;
+    TRY(use_device(e));
+    HIPCHK(hipMemcpy(out, e->tv.pID + first, sizeof(int) * count, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int lqrrt_tree_get_edge_lengths(lqrrt_engine* e, int first, int count, int32_t* out) {
+    TRY(range_ok(e, first, count));
+    if (!count) return 0;
+    TRY(use_device(e));
+    HIPCHK(hipMemcpy(out, e->tv.elen + first, sizeof(int) * count, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int lqrrt_tree_get_edge(lqrrt_engine* e, int id, double* x_host, double* u_host) {
+    TRY(range_ok(e, id, 1));
+    TRY(use_device(e));
+    const int len = e->h_elen[id];
+    if (x_host) HIPCHK(hipMemcpy(x_host, e->tv.xedge + (size_t)id * e->H * e->n, sizeof(double) * len * e->n, hipMemcpyDeviceToHost));
+    if (u_host) HIPCHK(hipMemcpy(u_host, e->tv.uedge + (size_t)id * e->H * e->m, sizeof(double) * len * e->m, hipMemcpyDeviceToHost));
+    return len;
+}
+
+extern "C" int lqrrt_tree_get_ignored(lqrrt_engine* e, int first, int count, uint8_t* out) {
+    TRY(range_ok(e, first, count));
+    for (int i = 0; i < count; ++i) {
+        const int id = first + i;
+        out[i] = (uint8_t)((e->h_ign[id >> 6] >> (id & 63)) & 1ull);
+    }
+    return 0;
+}
+
+static int flush_ignore(lqrrt_engine* e, hipStream_t st) {
+    if (!e->ign_dirty) return 0;
+    HIPCHK(hipMemcpyAsync(e->tv.ignore, e->h_ign.data(), sizeof(unsigned long long) * ((size_t)e->N / 64 + 1),
+                          hipMemcpyHostToDevice, st));
+    e->ign_dirty = false;
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// batched operators
+
+extern "C" int lqrrt_feasible_batch(lqrrt_engine* e, const double* x, const double* u, int B, uint8_t* ok, void* stream) {
+    if (!e || !x || !ok || B < 0) return fail(LQRRT_E_ARG, "bad argument");
+    if (!B) return 0;
+    TRY(use_device(e));
+    DISPATCH(e, hipLaunchKernelGGL((k_feasible_batch<S>), dim3(B), dim3(64), 0, (hipStream_t)stream, e->P, e->geo, x, u, B, ok));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lqrrt_dynamics_batch(lqrrt_engine* e, const double* x, const double* u, int B, double* xn, void* stream) {
+    if (!e || !x || !u || !xn || B < 0) return fail(LQRRT_E_ARG, "bad argument");
+    if (!e->has_res) return fail(LQRRT_E_STATE, "set_resolution first (dt)");
+    if (!B) return 0;
+    TRY(use_device(e));
+    DISPATCH(e, hipLaunchKernelGGL((k_dynamics_batch<S>), dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, e->P, x, u, B, e->res.dt, xn));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lqrrt_gain_batch(lqrrt_engine* e, const double* x, const double* u, int B, double* K, void* stream) {
+    if (!e || !x || !K || B < 0) return fail(LQRRT_E_ARG, "bad argument");
+    if (!B) return 0;
+    TRY(use_device(e));
+    DISPATCH(e, hipLaunchKernelGGL((k_gain_batch<S>), dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, e->P, x, u, B, K));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lqrrt_erf_batch(lqrrt_engine* e, const double* xg, const double* x, int B, double* eo, void* stream) {
+    if (!e || !xg || !x || !eo || B < 0) return fail(LQRRT_E_ARG, "bad argument");
+    if (!B) return 0;
+    TRY(use_device(e));
+    DISPATCH(e, hipLaunchKernelGGL((k_erf_batch<S>), dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, xg, x, B, eo));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lqrrt_nn_argmin(lqrrt_engine* e, const double* xs, int W, const double* S_dev, int use_ignore,
+                               int32_t* id, double* cost, void* stream) {
+    if (!e || !xs || W < 0) return fail(LQRRT_E_ARG, "bad argument");
+    if (W > e->maxW) return fail(LQRRT_E_CAPACITY, "W=%d exceeds max_wave=%d", W, e->maxW);
+    if (e->N < 1) return fail(LQRRT_E_STATE, "no tree: call lqrrt_tree_reset");
+    TRY(use_device(e));
+    hipStream_t st = (hipStream_t)stream;
+    TRY(flush_ignore(e, st));
+    return launch_nn(e, tree_view(e, use_ignore != 0), xs, W, S_dev, false, true, id, cost, nullptr, st, true);
+}
+
+extern "C" int lqrrt_costs_to_go(lqrrt_engine* e, const double* x, const double* S_dev, double* cost, void* stream) {
+    if (!e || !x || !cost) return fail(LQRRT_E_ARG, "bad argument");
+    if (e->N < 1) return fail(LQRRT_E_STATE, "no tree: call lqrrt_tree_reset");
+    TRY(use_device(e));
+    NodeView nv = tree_view(e, false);
+    const double* S_use = S_dev ? S_dev : e->d_S;
+    dim3 grid((e->N + 255) / 256);
+    if (S_use) {
+        DISPATCH(e, hipLaunchKernelGGL((k_costs<S, true>), grid, dim3(256), 0, (hipStream_t)stream, nv, x, S_use, cost));
+    } else {
+        DISPATCH(e, hipLaunchKernelGGL((k_costs<S, false>), grid, dim3(256), 0, (hipStream_t)stream, nv, x, S_use, cost));
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+__global__ void k_unpack_steer(const double* __restrict__ rec, RecLayout L, int W, int n, int m, int H,
+                               int* __restrict__ len, double* __restrict__ xseq, double* __restrict__ useq,
+                               double* __restrict__ xend, double* __restrict__ Kend) {
+    const int t = blockIdx.x;
+    if (t >= W) return;
+    const double* my = rec + (size_t)t * L.R;
+    const int l = (int)my[L.off_len];
+    if (threadIdx.x == 0 && len) len[t] = l;
+    if (xseq) for (int q = threadIdx.x; q < H * n; q += blockDim.x) xseq[(size_t)t * H * n + q] = q < l * n ? my[L.off_xseq + q] : 0.0;
+    if (useq) for (int q = threadIdx.x; q < H * m; q += blockDim.x) useq[(size_t)t * H * m + q] = q < l * m ? my[L.off_useq + q] : 0.0;
+    if (xend) for (int q = threadIdx.x; q < n; q += blockDim.x) xend[(size_t)t * n + q] = l > 0 ? my[L.off_xend + q] : 0.0;
+    if (Kend) for (int q = threadIdx.x; q < m * n; q += blockDim.x) Kend[(size_t)t * m * n + q] = l > 0 ? my[L.off_K + q] : 0.0;
+}
+
+extern "C" int lqrrt_steer_batch(lqrrt_engine* e, const int32_t* parent, const double* xtar, int W, int32_t* len,
+                                 double* xseq, double* useq, double* xend, double* Kend, void* stream) {
+    if (!e || !parent || !xtar || W < 0) return fail(LQRRT_E_ARG, "bad argument");
+    if (W > e->maxW) return fail(LQRRT_E_CAPACITY, "W=%d exceeds max_wave=%d", W, e->maxW);
+    if (!e->has_res) return fail(LQRRT_E_STATE, "set_resolution first");
+    if (e->N < 1) return fail(LQRRT_E_STATE, "no tree: call lqrrt_tree_reset");
+    if (!W) return 0;
+    TRY(use_device(e));
+    hipStream_t st = (hipStream_t)stream;
+    TRY(launch_steer(e, xtar, nullptr, 0, W, parent, st));
+    hipLaunchKernelGGL(k_unpack_steer, dim3(W), dim3(64), 0, st, e->d_rec, e->L, W, e->n, e->m, e->H, len, xseq, useq, xend, Kend);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// sample stream (default sampler closure, planner.py:176-211)
+
+static int ensure_samples(lqrrt_engine* e, int64_t need_end, hipStream_t st) {
+    // makes samples [cursor, need_end) available on the device at d_pool (index - d_pool_base)
+    if (!e->has_sampler) return fail(LQRRT_E_STATE, "set_sampler first");
+    if (!e->has_goal) return fail(LQRRT_E_STATE, "no goal set");
+    const int n = e->n;
+    if (e->d_pool_count > 0 && e->cursor >= e->d_pool_base && need_end <= e->d_pool_base + e->d_pool_count) return 0;
+    // drop consumed samples from the host pool
+    if (e->cursor > e->pool_base) {
+        const int64_t drop = std::min<int64_t>(e->cursor - e->pool_base, (int64_t)e->pool_rows_end.size());
+        e->pool.erase(e->pool.begin(), e->pool.begin() + drop * n);
+        e->pool_rows_end.erase(e->pool_rows_end.begin(), e->pool_rows_end.begin() + drop);
+        e->pool_base += drop;
+    }
+    const int64_t target_end = std::max<int64_t>(need_end, e->cursor + 8 * (int64_t)e->maxW);
+    const int CH = 16384;
+    if (e->cand_cap < CH) {
+        if (e->d_cand) (void)hipFree(e->d_cand);
+        if (e->d_flags) (void)hipFree(e->d_flags);
+        TRY(dalloc(&e->d_cand, (size_t)CH * n));
+        TRY(dalloc(&e->d_flags, (size_t)CH));
+        e->cand_cap = CH;
+    }
+    std::vector<double> cand((size_t)CH * n);
+    std::vector<unsigned char> flags(CH);
+    while (e->pool_base + (int64_t)e->pool_rows_end.size() < target_end) {
+        for (int r = 0; r < CH; ++r) {
+            double* c = &cand[(size_t)r * n];
+            for (int d = 0; d < n; ++d) c[d] = e->smp.centers[d] + e->smp.spans[d] * (e->mt_gen.next_double() - 0.5);
+            const double gate = e->mt_gen.next_double();
+            for (int d = 0; d < n; ++d)
+                if (e->smp.goal_bias[d] > gate) c[d] = e->goal[d];
+        }
+        HIPCHK(hipMemcpyAsync(e->d_cand, cand.data(), sizeof(double) * CH * n, hipMemcpyHostToDevice, st));
+        DISPATCH(e, hipLaunchKernelGGL((k_feasible_batch<S>), dim3(CH), dim3(64), 0, st, e->P, e->geo, e->d_cand, nullptr, CH, e->d_flags));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(flags.data(), e->d_flags, CH, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int r = 0; r < CH; ++r) {
+            e->tries_carry++;
+            if (flags[r] || e->tries_carry >= e->smp.tries_limit) {
+                e->pool.insert(e->pool.end(), &cand[(size_t)r * n], &cand[(size_t)r * n] + n);
+                e->pool_rows_end.push_back(e->gen_row + r + 1);
+                e->tries_carry = 0;
+            }
+        }
+        e->gen_row += CH;
+    }
+    // upload [cursor, pool_end)
+    const int64_t off = e->cursor - e->pool_base;
+    const int64_t cnt = (int64_t)e->pool_rows_end.size() - off;
+    if (cnt > e->d_pool_cap) {
+        if (e->d_pool) (void)hipFree(e->d_pool);
+        e->d_pool_cap = cnt + cnt / 2;
+        TRY(dalloc(&e->d_pool, (size_t)e->d_pool_cap * n));
+    }
+    HIPCHK(hipMemcpyAsync(e->d_pool, e->pool.data() + off * n, sizeof(double) * cnt * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    e->d_pool_base = e->cursor;
+    e->d_pool_count = cnt;
+    return 0;
+}
+
+static const double* wave_samples(const lqrrt_engine* e) {
+    return e->d_pool + (size_t)(e->cursor - e->d_pool_base) * e->n;
+}
+
+// --------------------------------------------------------------------------------------------
+// wave engine
+
+extern "C" int lqrrt_record_layout(lqrrt_engine* e, int32_t* o) {
+    if (!e || !o) return fail(LQRRT_E_ARG, "null argument");
+    o[0] = e->L.R; o[1] = e->L.off_cost; o[2] = e->L.off_parent; o[3] = e->L.off_len; o[4] = e->L.off_flags;
+    o[5] = e->L.off_xend; o[6] = e->L.off_trig; o[7] = e->L.off_K; o[8] = e->L.off_xseq; o[9] = e->L.off_useq;
+    o[10] = -1;
+    return 0;
+}
+
+extern "C" int lqrrt_wave_records(lqrrt_engine* e, void** p) {
+    if (!e || !p) return fail(LQRRT_E_ARG, "null argument");
+    *p = e->d_rec;
+    return 0;
+}
+
+__global__ void k_init_wave(const double* __restrict__ rec, RecLayout L, int W, int lo, int hi, int* __restrict__ par_done,
+                            unsigned char* __restrict__ changed, unsigned char* __restrict__ stale) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W) return;
+    if (t >= lo && t < hi) par_done[t] = (int)rec[(size_t)t * L.R + L.off_parent];
+    changed[t] = 0;
+    stale[t] = 0;
+}
+
+extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void* stream) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    if (W < 1 || W > e->maxW || lo < 0 || hi > W || lo > hi) return fail(LQRRT_E_ARG, "bad wave slice");
+    if (!e->has_res) return fail(LQRRT_E_STATE, "set_resolution first");
+    if (e->N < 1) return fail(LQRRT_E_STATE, "no tree: call lqrrt_tree_reset");
+    if (e->N + W > e->cap) return fail(LQRRT_E_CAPACITY, "tree capacity %d too small for size %d + wave %d", e->cap, e->N, W);
+    TRY(use_device(e));
+    hipStream_t st = (hipStream_t)stream;
+    TRY(ensure_samples(e, e->cursor + W, st));
+    TRY(flush_ignore(e, st));
+    const double* xs = wave_samples(e);
+    const int cnt = hi - lo;
+    if (cnt > 0) {
+        // snapshot NN for the slice: records lo..hi-1 get (cost, parent)
+        TRY(launch_nn(e, tree_view(e, true), xs + (size_t)lo * e->n, cnt, nullptr, false, true, nullptr, nullptr,
+                      e->d_rec + (size_t)lo * e->L.R, st, true));
+    }
+    hipLaunchKernelGGL(k_init_wave, dim3((W + 255) / 256), dim3(256), 0, st, e->d_rec, e->L, W, lo, hi, e->d_par_done,
+                       e->d_changed, e->d_stale);
+    if (cnt > 0) TRY(launch_steer(e, xs, nullptr, lo, cnt, e->d_par_done, st));
+    HIPCHK(hipGetLastError());
+    e->tot.speculated += cnt;
+    return 0;
+}
+
+__global__ void k_par_from_records(const double* __restrict__ rec, RecLayout L, int W, int* __restrict__ par_done) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < W) par_done[t] = (int)rec[(size_t)t * L.R + L.off_parent];
+}
+
+extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_limit, int pruning,
+                                 lqrrt_extend_stats* out, void* stream) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    if (W < 1 || W > e->maxW) return fail(LQRRT_E_ARG, "bad wave size");
+    TRY(use_device(e));
+    hipStream_t st = (hipStream_t)stream;
+    const double* xs = wave_samples(e);
+    lqrrt_extend_stats ws;
+    memset(&ws, 0, sizeof ws);
+    ws.waves = 1;
+
+    // parents of records that came from other ranks (all-gather) are only in the records
+    hipLaunchKernelGGL(k_par_from_records, dim3((W + 255) / 256), dim3(256), 0, st, e->d_rec, e->L, W, e->d_par_done);
+    HIPCHK(hipMemsetAsync(e->d_changed, 0, W, st));
+    HIPCHK(hipMemsetAsync(e->d_stale, 0, W, st));
+
+    const int guard = 4 * W + 8;
+    int rounds = 0;
+    while (true) {
+        if (W > 1) {
+            hipLaunchKernelGGL(k_mask_from_records, dim3((W + 255) / 256), dim3(256), 0, st, e->d_rec, e->L, W, e->d_wmask);
+            TRY(launch_nn(e, record_view(e, W), xs, W, nullptr, true, false, e->d_wid, e->d_wcost, nullptr, st, false));
+        } else {
+            HIPCHK(hipMemsetAsync(e->d_wid, 0xff, sizeof(int), st));
+        }
+        hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, st, e->d_rec, e->L, W, e->d_wid, e->d_wcost, e->d_par_done,
+                           e->d_par_want, e->d_changed, e->d_stale, e->d_need, e->d_list, e->d_summary);
+        hipLaunchKernelGGL(k_summary, dim3((W + 255) / 256), dim3(256), 0, st, e->d_rec, e->L, W, e->d_par_done, e->d_summary + 2);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(e->h_summary, e->d_summary, sizeof(int) * (2 + 3 * (size_t)W), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const int n_list = e->h_summary[0], n_defer = e->h_summary[1];
+        if (n_list == 0 && n_defer == 0) break;
+        if (n_list == 0) return fail(LQRRT_E_STATE, "exact-mode repair made no progress (deferred=%d)", n_defer);
+        TRY(launch_steer(e, xs, e->d_list, 0, n_list, e->d_par_done, st));
+        ws.fix_rounds++;
+        ws.resteers += n_list;
+        if (++rounds > guard) return fail(LQRRT_E_STATE, "exact-mode repair did not converge");
+    }
+
+    // commit prefix: stop after the first goal hit, the node limit, or max_commit attempts
+    const int* len = e->h_summary + 2;
+    const int* flg = e->h_summary + 2 + W;
+    const int* par = e->h_summary + 2 + 2 * W;
+    int C = 0, acc = 0;
+    bool hit = false;
+    const int64_t room = node_limit + 1 - (int64_t)e->N;   // nodes that may still be added (size > max_nodes stops)
+    for (int t = 0; t < W; ++t) {
+        if ((int64_t)C >= max_commit) break;
+        if (node_limit >= 0 && (int64_t)acc >= room) break;
+        e->h_rank[t] = acc;
+        C = t + 1;
+        if (len[t] > 0) {
+            ++acc;
+            if (flg[t] & 1) { hit = true; break; }
+        }
+    }
+    for (int t = C; t < W; ++t) e->h_rank[t] = acc;
+    if (e->N + acc > e->cap) return fail(LQRRT_E_CAPACITY, "tree capacity exceeded");
+    const int base = e->N;
+    if (acc > 0) {
+        HIPCHK(hipMemcpyAsync(e->d_rank, e->h_rank, sizeof(int) * W, hipMemcpyHostToDevice, st));
+        DISPATCH(e, hipLaunchKernelGGL((k_append<S>), dim3(C), dim3(64), 0, st, e->tv, e->d_rec, e->L, C, base, e->d_rank, e->d_par_done));
+        HIPCHK(hipGetLastError());
+    }
+    // host mirrors + goal bookkeeping (planner.py:260-283)
+    for (int t = 0; t < C; ++t) {
+        if (len[t] <= 0) continue;
+        const int id = base + e->h_rank[t];
+        const int p = par[t] >= 0 ? par[t] : base + e->h_rank[~par[t]];
+        e->h_pid.push_back(p);
+        e->h_elen.push_back(len[t]);
+        (void)id;
+    }
+    e->N += acc;
+    if (hit) {
+        const int id = e->N - 1;                     // the goal hit is the last committed node
+        int64_t steps = 0;
+        for (int v = id; v != -1; v = e->h_pid[v]) {
+            steps += e->h_elen[v];
+            // ignores = union of succeeded paths, planner.py:270 (only consulted when pruning, :239)
+            if (pruning) e->h_ign[v >> 6] |= (1ull << (v & 63));
+        }
+        e->ign_dirty = pruning != 0;
+        e->goal_hits++;
+        ws.goal_hits = 1;
+        if (e->best_end < 0 || steps < e->best_steps) { e->best_end = id; e->best_steps = steps; }  // planner.py:276 (T < self.T)
+    }
+    // advance the stream
+    const int64_t last = e->cursor + C - 1;
+    if (C > 0) e->committed_row = e->pool_rows_end[(size_t)(last - e->pool_base)];
+    e->cursor += C;
+    ws.attempts = C; ws.accepted = acc; ws.tree_size = e->N;
+    ws.candidates = e->committed_row;
+    e->tot.attempts += C; e->tot.accepted += acc; e->tot.waves += 1; e->tot.fix_rounds += ws.fix_rounds;
+    e->tot.resteers += ws.resteers; e->tot.goal_hits += ws.goal_hits; e->tot.tree_size = e->N;
+    e->tot.candidates = e->committed_row;
+    if (out) *out = ws;
+    return 0;
+}
+
+static int pick_wave(const lqrrt_engine* e, int wave_cap) {
+    // conflicts (true parent born inside the wave) scale ~ W/N: keep W a fraction of the tree
+    int W = e->N / 6;
+    W = std::max(W, 8);
+    W = std::min(W, wave_cap);
+    W = std::min(W, e->maxW);
+    if (W >= 64) W = (W / 64) * 64;
+    return W;
+}
+
+extern "C" int lqrrt_engine_extend(lqrrt_engine* e, int wave, int64_t max_attempts, int64_t node_limit, int until_size,
+                                   int pruning, int stop_on_goal, lqrrt_extend_stats* out, void* stream) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    if (wave < 1) return fail(LQRRT_E_ARG, "wave must be >= 1");
+    lqrrt_extend_stats acc;
+    memset(&acc, 0, sizeof acc);
+    acc.stop_reason = 0;
+    const int64_t spec0 = e->tot.speculated;
+    while (true) {
+        if (max_attempts >= 0 && acc.attempts >= max_attempts) { acc.stop_reason = LQRRT_STOP_ATTEMPTS; break; }
+        if (node_limit >= 0 && (int64_t)e->N > node_limit) { acc.stop_reason = LQRRT_STOP_NODES; break; }
+        if (until_size > 0 && e->N >= until_size) { acc.stop_reason = LQRRT_STOP_TARGET; break; }
+        int W = pick_wave(e, wave);
+        int64_t cap_attempts = max_attempts >= 0 ? max_attempts - acc.attempts : (int64_t)W;
+        if ((int64_t)W > cap_attempts) W = (int)cap_attempts;
+        int64_t lim = node_limit;
+        if (until_size > 0) {
+            const int64_t l2 = (int64_t)until_size - 1;   // stop once size >= until_size  <=> size > until_size-1
+            lim = (lim < 0) ? l2 : std::min(lim, l2);
+        }
+        TRY(lqrrt_wave_speculate(e, W, 0, W, stream));
+        lqrrt_extend_stats ws;
+        TRY(lqrrt_wave_commit(e, W, cap_attempts, lim, pruning, &ws, stream));
+        acc.attempts += ws.attempts; acc.accepted += ws.accepted; acc.waves += 1;
+        acc.fix_rounds += ws.fix_rounds; acc.resteers += ws.resteers; acc.goal_hits += ws.goal_hits;
+        if (stop_on_goal && ws.goal_hits) { acc.stop_reason = LQRRT_STOP_GOAL; break; }
+    }
+    acc.tree_size = e->N;
+    acc.candidates = e->committed_row;
+    acc.speculated = e->tot.speculated - spec0;
+    if (out) *out = acc;
+    return 0;
+}
+
+extern "C" int lqrrt_plan_best(lqrrt_engine* e, int32_t* end_node, int64_t* steps, int64_t* hits) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    if (end_node) *end_node = e->best_end;
+    if (steps) *steps = e->best_steps;
+    if (hits) *hits = e->goal_hits;
+    return 0;
+}
+
+extern "C" int lqrrt_engine_counters(lqrrt_engine* e, lqrrt_extend_stats* out) {
+    if (!e || !out) return fail(LQRRT_E_ARG, "null argument");
+    *out = e->tot;
+    out->tree_size = e->N;
+    out->candidates = e->committed_row;
+    return 0;
+}
+
+extern "C" int lqrrt_profile_enable(lqrrt_engine* e, int on) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    prof_flush(e);
+    e->prof = on != 0;
+    e->nn_ms = e->nn_bytes = e->steer_ms = 0;
+    e->nn_launches = e->steer_launches = 0;
+    return 0;
+}
+
+extern "C" int lqrrt_profile_read(lqrrt_engine* e, double* nn_ms, int64_t* nn_launches, double* nn_bytes,
+                                  double* steer_ms, int64_t* steer_launches) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    prof_flush(e);
+    if (nn_ms) *nn_ms = e->nn_ms;
+    if (nn_launches) *nn_launches = e->nn_launches;
+    if (nn_bytes) *nn_bytes = e->nn_bytes;
+    if (steer_ms) *steer_ms = e->steer_ms;
+    if (steer_launches) *steer_launches = e->steer_launches;
+    return 0;
+}

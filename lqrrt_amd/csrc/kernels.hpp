@@ -1,0 +1,499 @@
+// HIP kernels of the lqRRT expansion engine (gfx950 / MI355X), templated on the problem plugin.
+//
+// Mapping to the reference (jnez71/lqRRT):
+//   k_nn_scan / k_nn_reduce  <- Planner._costs_to_go + nearest selection  planner.py:239-247,340-350
+//   k_costs                  <- Planner._costs_to_go (full vector)        planner.py:340-350
+//   k_steer                  <- Planner._steer(force_arrive=False)        planner.py:354-438
+//   k_feasible_batch         <- Constraints.is_feasible                   constraints.py:53-61
+//   k_tree_root / k_append   <- Tree.__init__ / Tree.add_node             tree.py:50-96
+//   k_mask_from_records, k_decide, k_rank  (build-only: exact-mode wave validation)
+//
+// Execution model choices (MI355X):
+//   * NN scan: one lane = one sample, the node loop index is wave-uniform so node data comes
+//     through the scalar path (s_load -> SGPR operands); no cross-lane traffic at all, each
+//     lane keeps its own running (min, argmin).  The grid is (sample groups) x (node chunks)
+//     so that >> 1024 wavefronts cover the 256 CUs x 4 SIMDs even though one wave of samples
+//     is only 16 wavefronts wide.  The node table is tiny (480 KB at 10k x 6) and lives in L2;
+//     the kernel is bound by fp64 VALU (the per-pair atan2), see DESIGN.md.
+//   * steer: one problem per wavefront (64-thread blocks); the scalar rollout is computed
+//     redundantly by all lanes (wave-uniform, no divergence) and the lanes split the
+//     hull x obstacle collision sweep; the edge under construction lives in LDS.
+#pragma once
+#include "systems.hpp"
+
+namespace lq {
+
+// Resolution / goal block (Planner.set_resolution / set_goal), passed by value.
+struct Res {
+    double dt, FPR;
+    double tol[MAXN];
+    double goal_lo[MAXN], goal_hi[MAXN];
+    int H, pad;
+};
+
+// A table of candidate parent nodes: either the tree (SoA) or the wave records (AoS).
+struct NodeView {
+    const double* x;        // component d of node i at x[i*sn + d*sd]
+    const double* trig;     // trig entry j of node i at trig[i*tn + j*td]
+    long long sn, sd, tn, td;
+    const unsigned long long* ignore;   // bit i set -> node i not eligible (may be null)
+    int count, pad;
+};
+
+struct TreeView {
+    double* state;          // [n][cap]
+    double* trig;           // [2*NW][cap]
+    double* K;              // [cap][m*n]
+    int* pID;               // [cap]
+    int* elen;              // [cap]
+    double* xedge;          // [cap][H][n]
+    double* uedge;          // [cap][H][m]
+    unsigned long long* ignore;  // [cap/64]
+    int cap, H;
+};
+
+// Wave record layout (doubles).  One record per sample of the wave.
+struct RecLayout {
+    int R, off_cost, off_parent, off_len, off_flags, off_xend, off_trig, off_K, off_xseq, off_useq;
+};
+
+__host__ __device__ inline RecLayout make_layout(int n, int m, int nw, int H) {
+    RecLayout L;
+    L.off_cost = 0; L.off_parent = 1; L.off_len = 2; L.off_flags = 3;
+    L.off_xend = 4;
+    L.off_trig = L.off_xend + n;
+    L.off_K = L.off_trig + 2 * nw;
+    L.off_xseq = L.off_K + m * n;
+    L.off_useq = L.off_xseq + H * n;
+    L.R = L.off_useq + H * m;
+    return L;
+}
+
+template <class S>
+__device__ __forceinline__ void trig_of(const double* x, double* trig) {
+#pragma unroll
+    for (int k = 0; k < S::NW; ++k) {
+        trig[2 * k] = cos(x[S::wd(k)]);
+        trig[2 * k + 1] = sin(x[S::wd(k)]);
+    }
+}
+
+// erf(xgoal, x) with cached trig of both arguments.
+template <class S>
+__device__ __forceinline__ void erf_cached(const double* xg, const double* gtrig, const double* x,
+                                           const double* trig, double* e) {
+#pragma unroll
+    for (int d = 0; d < S::N; ++d) e[d] = xg[d] - x[d];
+#pragma unroll
+    for (int k = 0; k < S::NW; ++k)
+        e[S::wd(k)] = wrap_err(gtrig[2 * k], gtrig[2 * k + 1], trig[2 * k], trig[2 * k + 1]);
+}
+
+// (v-x)' S (v-x) in the reference's evaluation order (planner.py:350):
+// np.sum(np.tensordot(diffs, S, axes=1) * diffs, axis=1)
+template <class S, bool DENSE>
+__device__ __forceinline__ double quad_cost(const double* e, const double* Sd) {
+    double prod[S::N];
+    if constexpr (!DENSE) {
+#pragma unroll
+        for (int k = 0; k < S::N; ++k) prod[k] = e[k] * e[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < S::N; ++k) {
+            double t = e[0] * Sd[k];
+#pragma unroll
+            for (int j = 1; j < S::N; ++j) t += e[j] * Sd[j * S::N + k];
+            prod[k] = t * e[k];
+        }
+    }
+    return numpy_row_sum<S::N>(prod);
+}
+
+// ------------------------------------------------------------------------------------------
+// NN scan.  grid = (ceil(W/64), n_chunks), block = 64.  Lane = sample, uniform loop over the
+// chunk's nodes.  tri != 0: only nodes with index < sample index are eligible (in-wave pass).
+// Output partial minima [chunk][W]: masked (respecting `ignore`) and unmasked.
+template <class S, bool DENSE>
+__global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __restrict__ xs, int W,
+                                                const double* __restrict__ Sd, int chunk, int tri,
+                                                double* __restrict__ pcost, int* __restrict__ pidx,
+                                                double* __restrict__ pcost_all, int* __restrict__ pidx_all) {
+    const int lane = threadIdx.x;
+    const int t = blockIdx.x * 64 + lane;
+    const int ts = t < W ? t : W - 1;
+    const int i0 = blockIdx.y * chunk;
+    int i1 = i0 + chunk;
+    if (i1 > nv.count) i1 = nv.count;
+    if (tri) {
+        const int tmax = blockIdx.x * 64 + 63;
+        if (i1 > tmax) i1 = tmax;
+    }
+    double xg[S::N], gtrig[2 * S::NW + 1];
+#pragma unroll
+    for (int d = 0; d < S::N; ++d) xg[d] = xs[(size_t)ts * S::N + d];
+    trig_of<S>(xg, gtrig);
+
+    double best = INFINITY, best_all = INFINITY;
+    int bidx = -1, bidx_all = -1;
+    for (int i = i0; i < i1; ++i) {
+        double x[S::N], trig[2 * S::NW + 1], e[S::N];
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) x[d] = nv.x[(long long)i * nv.sn + d * nv.sd];
+#pragma unroll
+        for (int j = 0; j < 2 * S::NW; ++j) trig[j] = nv.trig[(long long)i * nv.tn + j * nv.td];
+        erf_cached<S>(xg, gtrig, x, trig, e);
+        const double c = quad_cost<S, DENSE>(e, Sd);
+        const bool ign = nv.ignore ? ((nv.ignore[i >> 6] >> (i & 63)) & 1ull) != 0 : false;
+        const bool ok = tri ? (i < t) : true;
+        if (ok && c < best_all) { best_all = c; bidx_all = i; }
+        if (ok && !ign && c < best) { best = c; bidx = i; }
+    }
+    if (t < W) {
+        const size_t o = (size_t)blockIdx.y * W + t;
+        pcost[o] = best; pidx[o] = bidx;
+        if (pcost_all) { pcost_all[o] = best_all; pidx_all[o] = bidx_all; }
+    }
+}
+
+// Lexicographic (cost, id) minimum over the chunk partials; ascending chunk order + strict '<'
+// keeps the lowest node id among exactly equal costs (stable-argsort order, planner.py:240).
+// When every node is ignored the overall best is returned (planner.py:241,245 fallback).
+__global__ void k_nn_reduce(const double* __restrict__ pcost, const int* __restrict__ pidx,
+                            const double* __restrict__ pcost_all, const int* __restrict__ pidx_all,
+                            int W, int n_chunks, int* __restrict__ out_id, double* __restrict__ out_cost,
+                            double* __restrict__ rec, int R, int off_cost, int off_parent) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W) return;
+    double b = INFINITY, ba = INFINITY;
+    int bi = -1, bai = -1;
+    for (int c = 0; c < n_chunks; ++c) {
+        const size_t o = (size_t)c * W + t;
+        const double v = pcost[o];
+        if (v < b) { b = v; bi = pidx[o]; }
+        if (pcost_all) {
+            const double va = pcost_all[o];
+            if (va < ba) { ba = va; bai = pidx_all[o]; }
+        }
+    }
+    if (bi < 0 && pcost_all) { b = ba; bi = bai; }
+    if (out_id) out_id[t] = bi;
+    if (out_cost) out_cost[t] = b;
+    if (rec) {
+        rec[(size_t)t * R + off_cost] = b;
+        rec[(size_t)t * R + off_parent] = (double)bi;
+    }
+}
+
+// Full cost vector of one sample (planner.py:340-350); thread per node.
+template <class S, bool DENSE>
+__global__ void k_costs(NodeView nv, const double* __restrict__ xq, const double* __restrict__ Sd,
+                        double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv.count) return;
+    double xg[S::N], gtrig[2 * S::NW + 1], x[S::N], trig[2 * S::NW + 1], e[S::N];
+#pragma unroll
+    for (int d = 0; d < S::N; ++d) { xg[d] = xq[d]; x[d] = nv.x[(long long)i * nv.sn + d * nv.sd]; }
+    trig_of<S>(xg, gtrig);
+#pragma unroll
+    for (int j = 0; j < 2 * S::NW; ++j) trig[j] = nv.trig[(long long)i * nv.tn + j * nv.td];
+    erf_cached<S>(xg, gtrig, x, trig, e);
+    out[i] = quad_cost<S, DENSE>(e, Sd);
+}
+
+// ------------------------------------------------------------------------------------------
+// Batched plugin operators (thread per item unless noted).
+
+template <class S>
+__global__ __launch_bounds__(64) void k_feasible_batch(Params P, Geo g, const double* __restrict__ x,
+                                                       const double* __restrict__ u, int B,
+                                                       unsigned char* __restrict__ ok) {
+    const int b = blockIdx.x;                 // one wavefront per item
+    if (b >= B) return;
+    double xs[S::N], us[S::M], trig[2 * S::NW + 1];
+#pragma unroll
+    for (int d = 0; d < S::N; ++d) xs[d] = x[(size_t)b * S::N + d];
+#pragma unroll
+    for (int j = 0; j < S::M; ++j) us[j] = u ? u[(size_t)b * S::M + j] : 0.0;
+    trig_of<S>(xs, trig);
+    const bool f = S::feasible(P.p, g, xs, us, trig, threadIdx.x);
+    if (threadIdx.x == 0) ok[b] = f ? 1 : 0;
+}
+
+template <class S>
+__global__ void k_dynamics_batch(Params P, const double* __restrict__ x, const double* __restrict__ u,
+                                 int B, double dt, double* __restrict__ xn) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double xs[S::N], us[S::M], trig[2 * S::NW + 1], o[S::N];
+#pragma unroll
+    for (int d = 0; d < S::N; ++d) xs[d] = x[(size_t)b * S::N + d];
+#pragma unroll
+    for (int j = 0; j < S::M; ++j) us[j] = u[(size_t)b * S::M + j];
+    trig_of<S>(xs, trig);
+    S::step(P.p, xs, trig, us, dt, o);
+#pragma unroll
+    for (int d = 0; d < S::N; ++d) xn[(size_t)b * S::N + d] = o[d];
+}
+
+template <class S>
+__global__ void k_gain_batch(Params P, const double* __restrict__ x, const double* __restrict__ u,
+                             int B, double* __restrict__ K) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double xs[S::N], us[S::M], trig[2 * S::NW + 1], k[S::M * S::N];
+#pragma unroll
+    for (int d = 0; d < S::N; ++d) xs[d] = x[(size_t)b * S::N + d];
+#pragma unroll
+    for (int j = 0; j < S::M; ++j) us[j] = u ? u[(size_t)b * S::M + j] : 0.0;
+    trig_of<S>(xs, trig);
+    S::gain(P.p, xs, trig, us, k);
+#pragma unroll
+    for (int j = 0; j < S::M * S::N; ++j) K[(size_t)b * S::M * S::N + j] = k[j];
+}
+
+template <class S>
+__global__ void k_erf_batch(const double* __restrict__ xg, const double* __restrict__ x, int B,
+                            double* __restrict__ eo) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double g[S::N], gt[2 * S::NW + 1], xs[S::N], tr[2 * S::NW + 1], e[S::N];
+#pragma unroll
+    for (int d = 0; d < S::N; ++d) { g[d] = xg[(size_t)b * S::N + d]; xs[d] = x[(size_t)b * S::N + d]; }
+    trig_of<S>(g, gt);
+    trig_of<S>(xs, tr);
+    erf_cached<S>(g, gt, xs, tr, e);
+#pragma unroll
+    for (int d = 0; d < S::N; ++d) eo[(size_t)b * S::N + d] = e[d];
+}
+
+// ------------------------------------------------------------------------------------------
+// Steer: one problem per wavefront.  Items: list[item] (or lo+item) = sample index t in the wave.
+// par[t] >= 0: start at tree node par[t]; par[t] < 0: start at the end node of in-wave sample ~par[t]
+// (read from its record).  Results go to record t: len, flags (bit0 = in goal), xend, trig, K,
+// xseq[len][n], useq[len][m].  Dynamic LDS: H*(n+m) doubles.
+template <class S>
+__global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView tv, double* __restrict__ rec,
+                                              RecLayout L, const double* __restrict__ xs,
+                                              const int* __restrict__ list, int lo,
+                                              const int* __restrict__ par) {
+    extern __shared__ double hist[];
+    double* hx = hist;
+    double* hu = hist + (size_t)r.H * S::N;
+    const int lane = threadIdx.x;
+    const int t = list ? list[blockIdx.x] : lo + (int)blockIdx.x;
+    const int pref = par[t];
+    double* my = rec + (size_t)t * L.R;
+
+    double x[S::N], K[S::M * S::N], trig[2 * S::NW + 1], xt[S::N], ttrig[2 * S::NW + 1];
+#pragma unroll
+    for (int d = 0; d < S::N; ++d) xt[d] = xs[(size_t)t * S::N + d];
+    trig_of<S>(xt, ttrig);
+    if (pref >= 0) {
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) x[d] = tv.state[(size_t)d * tv.cap + pref];
+#pragma unroll
+        for (int j = 0; j < 2 * S::NW; ++j) trig[j] = tv.trig[(size_t)j * tv.cap + pref];
+#pragma unroll
+        for (int j = 0; j < S::M * S::N; ++j) K[j] = tv.K[(size_t)pref * S::M * S::N + j];
+    } else {
+        const double* pr = rec + (size_t)(~pref) * L.R;
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) x[d] = pr[L.off_xend + d];
+#pragma unroll
+        for (int j = 0; j < 2 * S::NW; ++j) trig[j] = pr[L.off_trig + j];
+#pragma unroll
+        for (int j = 0; j < S::M * S::N; ++j) K[j] = pr[L.off_K + j];
+    }
+
+    int cnt = 0, steps = 0;
+    while (true) {
+        double e[S::N], u[S::M], uc[S::M], xn[S::N], trn[2 * S::NW + 1];
+        erf_cached<S>(xt, ttrig, x, trig, e);                    // planner.py:386
+#pragma unroll
+        for (int i = 0; i < S::M; ++i) {                         // u = K.dot(e), planner.py:387
+            double a = K[i * S::N] * e[0];
+#pragma unroll
+            for (int j = 1; j < S::N; ++j) a += K[i * S::N + j] * e[j];
+            u[i] = a; uc[i] = a;
+        }
+        S::step(P.p, x, trig, uc, r.dt, xn);                     // planner.py:390 (dynamics gets copies)
+        trig_of<S>(xn, trn);
+        if (!S::feasible(P.p, g, xn, u, trn, lane)) {            // planner.py:393-396
+            cnt = (int)(r.FPR * (double)cnt);
+            break;
+        }
+        ++steps;                                                 // planner.py:414
+        bool conv = true;
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= r.tol[d]);
+        if (steps > r.H || conv) break;                          // planner.py:428
+        // record (planner.py:432-433): lane d keeps component d
+        {
+            double v = xn[0];
+#pragma unroll
+            for (int d = 1; d < S::N; ++d) v = (lane == d) ? xn[d] : v;
+            if (lane < S::N) hx[cnt * S::N + lane] = v;
+            double w = u[0];
+#pragma unroll
+            for (int j = 1; j < S::M; ++j) w = (lane == j) ? u[j] : w;
+            if (lane < S::M) hu[cnt * S::M + lane] = w;
+        }
+        ++cnt;
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) x[d] = xn[d];
+#pragma unroll
+        for (int j = 0; j < 2 * S::NW; ++j) trig[j] = trn[j];
+        S::gain(P.p, x, trig, u, K);                             // planner.py:436
+    }
+    __syncthreads();
+
+    int flags = 0;
+    if (cnt > 0) {
+        double ul[S::M];
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) x[d] = hx[(cnt - 1) * S::N + d];
+#pragma unroll
+        for (int j = 0; j < S::M; ++j) ul[j] = hu[(cnt - 1) * S::M + j];
+        trig_of<S>(x, trig);
+        S::gain(P.p, x, trig, ul, K);                            // planner.py:257: lqr(xnew, u_last)
+        bool in = true;                                          // planner.py:442-447 (strict)
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) in = in && (r.goal_lo[d] < x[d]) && (x[d] < r.goal_hi[d]);
+        flags = in ? 1 : 0;
+        for (int q = lane; q < cnt * S::N; q += 64) my[L.off_xseq + q] = hx[q];
+        for (int q = lane; q < cnt * S::M; q += 64) my[L.off_useq + q] = hu[q];
+        {
+            double v = x[0];
+#pragma unroll
+            for (int d = 1; d < S::N; ++d) v = (lane == d) ? x[d] : v;
+            if (lane < S::N) my[L.off_xend + lane] = v;
+            if constexpr (S::NW > 0) {
+                double w = trig[0];
+#pragma unroll
+                for (int j = 1; j < 2 * S::NW; ++j) w = (lane == j) ? trig[j] : w;
+                if (lane < 2 * S::NW) my[L.off_trig + lane] = w;
+            }
+            double kk = K[0];
+#pragma unroll
+            for (int j = 1; j < S::M * S::N; ++j) kk = (lane == j) ? K[j] : kk;
+            if (lane < S::M * S::N) my[L.off_K + lane] = kk;
+        }
+    }
+    if (lane == 0) {
+        my[L.off_len] = (double)cnt;
+        my[L.off_flags] = (double)flags;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Tree root (tree.py:50-73 via planner.py:172): state, trig, K = lqr(x0, 0)[1], pID -1, edge = [x0],[0].
+template <class S>
+__global__ void k_tree_root(Params P, TreeView tv, const double* __restrict__ x0) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double x[S::N], trig[2 * S::NW + 1], K[S::M * S::N], u0[S::M];
+    for (int d = 0; d < S::N; ++d) { x[d] = x0[d]; tv.state[(size_t)d * tv.cap] = x[d]; }
+    for (int j = 0; j < S::M; ++j) u0[j] = 0.0;
+    trig_of<S>(x, trig);
+    for (int j = 0; j < 2 * S::NW; ++j) tv.trig[(size_t)j * tv.cap] = trig[j];
+    S::gain(P.p, x, trig, u0, K);
+    for (int j = 0; j < S::M * S::N; ++j) tv.K[j] = K[j];
+    tv.pID[0] = -1;
+    tv.elen[0] = 1;
+    for (int d = 0; d < S::N; ++d) tv.xedge[d] = x[d];
+    for (int j = 0; j < S::M; ++j) tv.uedge[j] = 0.0;
+}
+
+// bit s of mask = 1 when sample s produced no node (len == 0) -> not a candidate parent.
+__global__ void k_mask_from_records(const double* __restrict__ rec, RecLayout L, int W,
+                                    unsigned long long* __restrict__ mask) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool dead = (t < W) ? (rec[(size_t)t * L.R + L.off_len] <= 0.0) : true;
+    const unsigned long long b = __ballot(dead);
+    if ((threadIdx.x & 63) == 0 && (t >> 6) < ((W + 63) >> 6)) mask[t >> 6] = b;
+}
+
+// Exact-mode decision step (single workgroup, strided over the wave).  For every sample:
+//   want = in-wave winner s (if its cost beats the snapshot cost strictly) else snapshot parent;
+//   redo when want differs from the parent the record was computed with, when that in-wave
+//   parent was itself recomputed last round, or when a redo was deferred.
+// A redo whose in-wave parent is also redone this round is deferred (its start state is
+// about to change).  Outputs: list of samples to re-steer now, counts[0]=listed, counts[1]=deferred.
+__global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ rec, RecLayout L, int W,
+                                                 const int* __restrict__ win_id, const double* __restrict__ win_cost,
+                                                 int* __restrict__ par_done, int* __restrict__ par_want,
+                                                 unsigned char* __restrict__ changed, unsigned char* __restrict__ stale,
+                                                 unsigned char* __restrict__ need, int* __restrict__ list,
+                                                 int* __restrict__ counts) {
+    __shared__ int n_list, n_defer;
+    if (threadIdx.x == 0) { n_list = 0; n_defer = 0; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < W; t += blockDim.x) {
+        const double csnap = rec[(size_t)t * L.R + L.off_cost];
+        const int psnap = (int)rec[(size_t)t * L.R + L.off_parent];
+        const int s = win_id[t];
+        const int want = (s >= 0 && win_cost[t] < csnap) ? ~s : psnap;
+        bool nd = (want != par_done[t]) || (stale[t] != 0);
+        if (want < 0 && changed[~want]) nd = true;
+        par_want[t] = want;
+        need[t] = nd ? 1 : 0;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < W; t += blockDim.x) {
+        unsigned char ch = 0;
+        if (need[t]) {
+            const int want = par_want[t];
+            if (want < 0 && need[~want]) {
+                stale[t] = 1;
+                atomicAdd(&n_defer, 1);
+            } else {
+                stale[t] = 0;
+                par_done[t] = want;
+                list[atomicAdd(&n_list, 1)] = t;
+                ch = 1;
+            }
+        }
+        changed[t] = ch;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { counts[0] = n_list; counts[1] = n_defer; }
+}
+
+// Summary for the host after convergence: len, flags and parent of every sample (int32 x3 x W).
+__global__ void k_summary(const double* __restrict__ rec, RecLayout L, int W, const int* __restrict__ par_done,
+                          int* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W) return;
+    out[t] = (int)rec[(size_t)t * L.R + L.off_len];
+    out[W + t] = (int)rec[(size_t)t * L.R + L.off_flags];
+    out[2 * W + t] = par_done[t];
+}
+
+// Append the first C samples' accepted records to the tree (tree.py:77-96).  rank[t] = number of
+// accepted samples before t (computed on the host from the summary, uploaded).  One wavefront
+// per sample.  In-wave parents resolve to base + rank[parent sample].
+template <class S>
+__global__ __launch_bounds__(64) void k_append(TreeView tv, const double* __restrict__ rec, RecLayout L,
+                                               int C, int base, const int* __restrict__ rank,
+                                               const int* __restrict__ par_done) {
+    const int t = blockIdx.x;
+    if (t >= C) return;
+    const double* my = rec + (size_t)t * L.R;
+    const int len = (int)my[L.off_len];
+    if (len <= 0) return;
+    const int id = base + rank[t];
+    const int lane = threadIdx.x;
+    if (lane < S::N) tv.state[(size_t)lane * tv.cap + id] = my[L.off_xend + lane];
+    if (lane < 2 * S::NW) tv.trig[(size_t)lane * tv.cap + id] = my[L.off_trig + lane];
+    if (lane < S::M * S::N) tv.K[(size_t)id * S::M * S::N + lane] = my[L.off_K + lane];
+    if (lane == 0) {
+        const int p = par_done[t];
+        tv.pID[id] = p >= 0 ? p : base + rank[~p];
+        tv.elen[id] = len;
+    }
+    double* xe = tv.xedge + (size_t)id * tv.H * S::N;
+    double* ue = tv.uedge + (size_t)id * tv.H * S::M;
+    for (int q = lane; q < len * S::N; q += 64) xe[q] = my[L.off_xseq + q];
+    for (int q = lane; q < len * S::M; q += 64) ue[q] = my[L.off_useq + q];
+}
+
+}  // namespace lq

@@ -1,0 +1,346 @@
+// Device-side problem plugins for the lqRRT expansion engine (gfx950).
+//
+// The reference keeps dynamics / lqr / erf / is_feasible as Python callbacks defined in its
+// demo scripts; a GPU cannot call Python, so each shipped problem is restated here as a set of
+// inlined device functions with the SAME operation order in IEEE double (the file is compiled
+// with -ffp-contract=off, so a*b+c is two roundings exactly as in NumPy).  Remaining
+// differences to NumPy are the last-ulp behaviour of sin/cos/atan2/tanh/sqrt (ocml vs
+// glibc/SVML) and BLAS summation order inside the demos' tiny `.dot` calls.
+//
+// Every system S provides
+//   S::N, S::M            state / effort sizes
+//   S::NW, S::wd(k)       number and index of angular (wrapped) states
+//   S::gain(P,x,trig,u,K)         lqr(x,u)[1]                       (K row-major M x N)
+//   S::step(P,x,trig,u,dt,xn)     dynamics(x,u,dt); u is the caller's scratch copy
+//   S::feasible(P,G,x,u,trig,lane) Constraints.is_feasible, cooperative over one wavefront,
+//                                  returns a wave-uniform bool
+// where trig[2k],trig[2k+1] = cos,sin of x[wd(k)] (computed once per state and shared by
+// erf / dynamics / lqr / feasibility, which all need it).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace lq {
+
+constexpr int MAXN = 12;
+constexpr int MAXM = 6;
+constexpr int MAXP = 96;
+
+struct Params { double p[MAXP]; };
+
+// Collision geometry tables in HBM (uniform, read through the scalar/L1 path).
+struct Geo {
+    const double* vps;   // [2][V] body-frame hull points
+    const double* obs;   // [O][stride]
+    int V, O, stride, pad;
+};
+
+__device__ __forceinline__ double clipd(double v, double lo, double hi) {
+    // np.clip = minimum(maximum(v, lo), hi)
+    double t = v < lo ? lo : v;
+    return t > hi ? hi : t;
+}
+
+// The demos' angle error: atan2(sg*c - cg*s, cg*c + sg*s)  (e.g. demo_boat_advanced.py:159-164)
+__device__ __forceinline__ double wrap_err(double cg, double sg, double c, double s) {
+    return atan2(sg * c - cg * s, cg * c + sg * s);
+}
+
+// np.sum over the last axis of a C-contiguous (N,n) array: plain left-to-right loop for n < 8,
+// 8-lane unrolled pairwise block for n >= 8 (numpy/core/src/umath/loops_utils.h pairwise sum).
+template <int n>
+__device__ __forceinline__ double numpy_row_sum(const double* a) {
+    if constexpr (n < 8) {
+        double r = a[0];
+#pragma unroll
+        for (int i = 1; i < n; ++i) r += a[i];
+        return r;
+    } else {
+        double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8) {
+            r0 += a[i + 0]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+            r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+        }
+        double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+}
+
+// Hull-vs-circles sweep shared by the planar vehicles (demo_boat_advanced.py:216-224):
+// verts = p + R(h) vps ; collision iff any ||vert - c|| <= r.  `extra2p` adds the car's
+// accidental vertex at 2p (demo_car.py:175).  One wavefront cooperates: lanes span the
+// obstacles when there are many of them, otherwise the hull points.
+__device__ __forceinline__ bool hull_hits(const Geo& g, double px, double py, double c, double s,
+                                          bool extra2p, int lane) {
+    bool hit = false;
+    const double ms = -s;
+    if (g.O >= 32) {
+        for (int o = lane; o < g.O; o += 64) {
+            const double ox = g.obs[o * g.stride + 0], oy = g.obs[o * g.stride + 1], r = g.obs[o * g.stride + 2];
+            for (int v = 0; v < g.V; ++v) {
+                const double bx = g.vps[v], by = g.vps[g.V + v];
+                const double vx = px + (c * bx + ms * by);
+                const double vy = py + (s * bx + c * by);
+                const double dx = vx - ox, dy = vy - oy;
+                hit |= (sqrt(dx * dx + dy * dy) <= r);
+            }
+            if (extra2p) {
+                const double dx = (px + px) - ox, dy = (py + py) - oy;
+                hit |= (sqrt(dx * dx + dy * dy) <= r);
+            }
+        }
+    } else {
+        const int nv = g.V + (extra2p ? 1 : 0);
+        for (int v = lane; v < nv; v += 64) {
+            double vx, vy;
+            if (v < g.V) {
+                const double bx = g.vps[v], by = g.vps[g.V + v];
+                vx = px + (c * bx + ms * by);
+                vy = py + (s * bx + c * by);
+            } else {
+                vx = px + px;
+                vy = py + py;
+            }
+            for (int o = 0; o < g.O; ++o) {
+                const double dx = vx - g.obs[o * g.stride + 0], dy = vy - g.obs[o * g.stride + 1];
+                hit |= (sqrt(dx * dx + dy * dy) <= g.obs[o * g.stride + 2]);
+            }
+        }
+    }
+    return __any(hit) != 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Planar boats: state [x, y, h, vx, vy, vh], effort [ux, uy, uh].
+
+struct BoatCommon {
+    static constexpr int N = 6, M = 3, NW = 1;
+    __device__ static constexpr int wd(int) { return 2; }
+
+    // K = [kp R(h)' | kd] with diagonal kp, kd (demo_boat_advanced.py:139-151)
+    __device__ static void gain_pd(const double* kp, const double* kd, const double* trig, double* K) {
+        const double c = trig[0], s = trig[1];
+        K[0] = kp[0] * c;    K[1] = kp[0] * s;  K[2] = kp[0] * 0.0;  K[3] = kd[0]; K[4] = 0.0;   K[5] = 0.0;
+        K[6] = kp[1] * (-s); K[7] = kp[1] * c;  K[8] = kp[1] * 0.0;  K[9] = 0.0;   K[10] = kd[1]; K[11] = 0.0;
+        K[12] = kp[2] * 0.0; K[13] = kp[2] * 0.0; K[14] = kp[2] * 1.0; K[15] = 0.0; K[16] = 0.0;  K[17] = kd[2];
+    }
+
+    // "Heading controller trying to keep us car-like" (demo_boat_advanced.py:101-108)
+    __device__ static double rudder_term(double gainv, const double* x, double c, double s) {
+        const double vw0 = c * x[3] + (-s) * x[4];
+        const double vw1 = s * x[3] + c * x[4];
+        const double ang = atan2(vw1, vw0);
+        const double cg = cos(ang), sg = sin(ang);
+        return gainv * wrap_err(cg, sg, c, s);
+    }
+
+    // xdot = [R v ; invM*(u - D*v)], xnext = x + xdot*dt  (demo_boat_advanced.py:114-117)
+    __device__ static void euler(const double* invM, const double* Dpos, const double* Dneg,
+                                 const double* x, double c, double s, const double* u, double dt, double* xn) {
+        double xdot[6];
+        xdot[0] = c * x[3] + (-s) * x[4];
+        xdot[1] = s * x[3] + c * x[4];
+        xdot[2] = x[5];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double v = x[3 + i];
+            const double D = (v >= 0.0) ? Dpos[i] : Dneg[i];
+            xdot[3 + i] = invM[i] * (u[i] - D * v);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xn[i] = x[i] + xdot[i] * dt;
+    }
+
+    // "not turning in place" + "not driving backwards" (demo_boat_advanced.py:120-128)
+    __device__ static void carlike(const double* x, double vpos0, double vneg0, double* xn) {
+        if (x[3] > 0.0)      xn[5] = clipd(fabs(xn[3] / vpos0), 0.0, 1.0) * xn[5];
+        else if (x[3] < 0.0) xn[5] = clipd(fabs(xn[3] / vneg0), 0.0, 1.0) * xn[5];
+        if (xn[3] < 0.0) xn[3] = 0.0;
+    }
+};
+
+struct BoatAdvanced : BoatCommon {
+    // params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 B[3][4] | 21 invB[4][3] | 33 thrust_max[4]
+    //         37 rudder | 38 velmax_pos0 | 39 velmax_neg0 | 40 kp[3] | 43 kd[3]
+    //         46 velmax_pos_plan[3] | 49 velmax_neg_plan[3]
+    __device__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
+        gain_pd(P + 40, P + 43, trig, K);
+    }
+    __device__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+        const double c = trig[0], s = trig[1];
+        u[2] = u[2] + rudder_term(P[37], x, c, s);
+        // u = B.dot(clip(invB.dot(u), -thrust_max, thrust_max))   (demo_boat_advanced.py:111)
+        double t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double a = P[21 + 3 * j] * u[0];
+            a += P[21 + 3 * j + 1] * u[1];
+            a += P[21 + 3 * j + 2] * u[2];
+            t[j] = clipd(a, -P[33 + j], P[33 + j]);
+        }
+        double us[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double a = P[9 + 4 * i] * t[0];
+            a += P[9 + 4 * i + 1] * t[1];
+            a += P[9 + 4 * i + 2] * t[2];
+            a += P[9 + 4 * i + 3] * t[3];
+            us[i] = a;
+        }
+        euler(P + 0, P + 3, P + 6, x, c, s, us, dt, xn);
+        carlike(x, P[38], P[39], xn);
+    }
+    __device__ static bool feasible(const double* P, const Geo& g, const double* x, const double*, const double* trig, int lane) {
+        // planning speed box first (demo_boat_advanced.py:211-213)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (x[3 + i] > P[46 + i] || x[3 + i] < P[49 + i]) return false;
+        return !hull_hits(g, x[0], x[1], trig[0], trig[1], false, lane);
+    }
+};
+
+struct BoatIntermediate : BoatCommon {
+    // params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 u_max[3] | 12 rudder | 13 velmax_pos0
+    //         14 velmax_neg0 | 15 kp[3] | 18 kd[3]
+    __device__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
+        gain_pd(P + 15, P + 18, trig, K);
+    }
+    __device__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+        const double c = trig[0], s = trig[1];
+        u[2] = u[2] + rudder_term(P[12], x, c, s);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)          // per-axis saturation (demo_boat_intermediate.py:74-77)
+            if (fabs(u[i]) > P[9 + i]) u[i] = P[9 + i] * (u[i] > 0.0 ? 1.0 : -1.0);
+        euler(P + 0, P + 3, P + 6, x, c, s, u, dt, xn);
+        carlike(x, P[13], P[14], xn);
+    }
+    __device__ static bool feasible(const double*, const Geo& g, const double* x, const double*, const double* trig, int lane) {
+        return !hull_hits(g, x[0], x[1], trig[0], trig[1], false, lane);
+    }
+};
+
+struct BoatNovice : BoatCommon {
+    // params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 u_max[3] | 12 kp[3] | 15 kd[3] | 18 boat_length/2
+    __device__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
+        gain_pd(P + 12, P + 15, trig, K);
+    }
+    __device__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)          // demo_boat_novice.py:67-69
+            if (fabs(u[i]) > P[9 + i]) u[i] = P[9 + i] * (u[i] > 0.0 ? 1.0 : -1.0);
+        euler(P + 0, P + 3, P + 6, x, trig[0], trig[1], u, dt, xn);
+    }
+    __device__ static bool feasible(const double* P, const Geo& g, const double* x, const double*, const double*, int lane) {
+        // centre point vs circles inflated by half the boat length (demo_boat_novice.py:160-164)
+        bool hit = false;
+        for (int o = lane; o < g.O; o += 64) {
+            const double dx = x[0] - g.obs[o * g.stride + 0], dy = x[1] - g.obs[o * g.stride + 1];
+            hit |= (sqrt(dx * dx + dy * dy) <= P[18] + g.obs[o * g.stride + 2]);
+        }
+        return __any(hit) == 0;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Car: state [x, y, h, vx, vh], effort [ux, uh]  (demos/demo_car.py)
+
+struct Car {
+    static constexpr int N = 5, M = 2, NW = 1;
+    __device__ static constexpr int wd(int) { return 2; }
+    // params: 0 invM[2] | 2 D[2] | 4 u_lo[2] | 6 u_hi[2] | 8 velmax0 | 9 kp[2] | 11 kd[2]
+    __device__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
+        // K = [kp * rows(0,2) of R' | kd]  (demo_car.py:98-113)
+        const double c = trig[0], s = trig[1];
+        K[0] = P[9] * c;    K[1] = P[9] * s;    K[2] = P[9] * 0.0;  K[3] = P[11]; K[4] = 0.0;
+        K[5] = P[10] * 0.0; K[6] = P[10] * 0.0; K[7] = P[10] * 1.0; K[8] = 0.0;   K[9] = P[12];
+    }
+    __device__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+        const double vwx = trig[0] * x[3], vwy = trig[1] * x[3];
+        const double u0 = clipd(u[0], P[4], P[6]), u1 = clipd(u[1], P[5], P[7]);
+        double xdot[5];
+        xdot[0] = vwx; xdot[1] = vwy; xdot[2] = x[4];
+        xdot[3] = P[0] * (u0 - P[2] * x[3]);
+        xdot[4] = P[1] * (u1 - P[3] * x[4]);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) xn[i] = x[i] + xdot[i] * dt;
+        if (xn[3] < 0.0) xn[3] = 0.0;                                   // demo_car.py:66-67
+        xn[4] = clipd(fabs(xn[3] / P[8]), 0.0, 1.0) * xn[4];            // demo_car.py:70
+    }
+    __device__ static bool feasible(const double*, const Geo& g, const double* x, const double*, const double* trig, int lane) {
+        return !hull_hits(g, x[0], x[1], trig[0], trig[1], true, lane);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Double pendulum: state [q1, q2, w1, w2], effort [tau1]  (demos/demo_pendulum.py)
+
+struct Pendulum {
+    static constexpr int N = 4, M = 1, NW = 2;
+    __device__ static constexpr int wd(int k) { return k; }
+    // params: 0 a=(m0+m1)L0^2+m1L1^2 | 1 b2=2 m1 L0 L1 | 2 m1 L1^2 | 3 h=m1 L0 L1 | 4 g0=g(m0+m1)L0
+    //         5 g1=m1 g L1 | 6 d[2] | 8 b[2] | 10 c[2] | 12 umax | 13 umax_plan | 14 K[4]
+    __device__ static void gain(const double* P, const double*, const double*, const double*, double* K) {
+        K[0] = P[14]; K[1] = P[15]; K[2] = P[16]; K[3] = P[17];          // demo_pendulum.py:119-126
+    }
+    __device__ static void step(const double* P, const double* q, const double* trig, double* u, double dt, double* qn) {
+        // manipulator equation, demo_pendulum.py:54-100
+        const double c1 = trig[2], s1 = trig[3], c0 = trig[0];
+        const double c01 = cos(q[0] + q[1]);
+        const double M00 = P[0] + P[1] * c1;
+        const double M01 = P[2] + P[3] * c1;
+        const double M11 = P[2];
+        const double V0 = (-P[3]) * ((2.0 * q[2]) * q[3] + q[3] * q[3]) * s1;
+        const double V1 = (P[3] * (q[2] * q[2])) * s1;
+        const double G0 = P[4] * c0 + P[5] * c01;
+        const double G1 = P[5] * c01;
+        const double D0 = P[6] * q[2], D1 = P[7] * q[3];
+        const double F0 = P[8] * tanh(P[10] * q[2]), F1 = P[9] * tanh(P[11] * q[3]);
+        const double tau = clipd(u[0], -P[12], P[12]);
+        const double r0 = (((tau - V0) - G0) - D0) - F0;
+        const double r1 = (((0.0 - V1) - G1) - D1) - F1;
+        const double det = M00 * M11 - M01 * M01;
+        const double a0 = (M11 * r0 - M01 * r1) / det;
+        const double a1 = (M00 * r1 - M01 * r0) / det;
+        qn[0] = q[0] + q[2] * dt;
+        qn[1] = q[1] + q[3] * dt;
+        qn[2] = q[2] + a0 * dt;
+        qn[3] = q[3] + a1 * dt;
+    }
+    __device__ static bool feasible(const double* P, const Geo&, const double*, const double* u, const double*, int) {
+        return !(fabs(u[0]) > P[13]);                                   // demo_pendulum.py:154-157
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic double integrator (BASELINE.json config 5): q,qdot in R^D, u in R^D, boxes on q[0:3].
+
+template <int D>
+struct DoubleIntegratorT {
+    static constexpr int N = 2 * D, M = D, NW = 0;
+    __device__ static constexpr int wd(int) { return 0; }
+    // params: 0 dt of the model | 1 K[D][2D] constant DARE gain (row-major)
+    __device__ static void gain(const double* P, const double*, const double*, const double*, double* K) {
+#pragma unroll
+        for (int j = 0; j < D * 2 * D; ++j) K[j] = P[1 + j];
+    }
+    __device__ static void step(const double* P, const double* x, const double*, double* u, double, double* xn) {
+        const double h = P[0];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            xn[i] = x[i] + h * x[D + i];
+            xn[D + i] = x[D + i] + h * u[i];
+        }
+    }
+    __device__ static bool feasible(const double*, const Geo& g, const double* x, const double*, const double*, int lane) {
+        bool hit = false;
+        for (int o = lane; o < g.O; o += 64) {
+            const double* b = g.obs + (size_t)o * g.stride;
+            hit |= (x[0] >= b[0]) & (x[0] <= b[3]) & (x[1] >= b[1]) & (x[1] <= b[4]) & (x[2] >= b[2]) & (x[2] <= b[5]);
+        }
+        return __any(hit) == 0;
+    }
+};
+
+}  // namespace lq

@@ -1,0 +1,266 @@
+"""
+Thin object wrapper over the C ABI (include/lqrrt_hip.h).  Device memory for the operator
+inputs/outputs is owned by PyTorch-ROCm tensors whose data_ptr() is handed to the HIP
+library; launches go onto torch's current HIP stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise nat.NativeError(nat.E_NODEVICE, "torch sees no HIP device: lqrrt_amd needs an MI355X (no CPU fallback)")
+    return torch
+
+
+class Engine(object):
+    """One native engine handle = one problem on one GPU."""
+
+    def __init__(self, system, capacity, max_wave=1024, device=0):
+        nat.require_device()
+        self.system = system
+        self.n, self.m = system.nstates, system.ncontrols
+        self.device = device
+        self.capacity = int(capacity)
+        self.max_wave = int(max_wave)
+        desc, keep = system.desc()
+        self._keep = keep
+        h = C.c_void_p()
+        nat.check(nat.lib().lqrrt_engine_create(C.byref(desc), device, self.capacity, self.max_wave, C.byref(h)))
+        self.h = h
+        if system.S is not None:
+            S = nat.as_f64(system.S, (self.n, self.n))
+            nat.check(nat.lib().lqrrt_engine_set_dense_S(self.h, nat.ptr(S)))
+        self.horizon_iters = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            nat.lib().lqrrt_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration -------------------------------------------------------------------------
+    def set_resolution(self, dt, FPR, horizon_iters, error_tol, goal, goal_buffer):
+        r = nat.Resolution()
+        r.dt, r.FPR, r.horizon_iters = float(dt), float(FPR), int(horizon_iters)
+        tol = np.broadcast_to(np.asarray(error_tol, dtype=np.float64), (self.n,))
+        for i in range(nat.MAX_STATES):
+            r.error_tol[i] = tol[i] if i < self.n else np.inf
+            r.goal[i] = 0.0
+            r.goal_lo[i], r.goal_hi[i] = -np.inf, np.inf
+        r.has_goal = 0
+        if goal is not None:
+            g = np.asarray(goal, dtype=np.float64)
+            b = np.asarray(goal_buffer, dtype=np.float64)
+            r.has_goal = 1
+            for i in range(self.n):
+                r.goal[i] = g[i]
+                r.goal_lo[i] = g[i] - b[i]        # planner.py:482-484
+                r.goal_hi[i] = g[i] + b[i]
+        nat.check(nat.lib().lqrrt_engine_set_resolution(self.h, C.byref(r)))
+        self.horizon_iters = int(horizon_iters)
+
+    def set_sampler(self, centers, spans, goal_bias, tries_limit):
+        s = nat.SamplerDesc()
+        for i in range(self.n):
+            s.centers[i], s.spans[i], s.goal_bias[i] = centers[i], spans[i], goal_bias[i]
+        s.tries_limit = int(tries_limit)
+        nat.check(nat.lib().lqrrt_engine_set_sampler(self.h, C.byref(s)))
+
+    def set_mt19937(self, key, pos):
+        key = np.ascontiguousarray(key, dtype=np.uint32)
+        nat.check(nat.lib().lqrrt_engine_set_mt19937(self.h, nat.ptr(key), int(pos)))
+
+    def get_mt19937(self):
+        key = np.zeros(624, dtype=np.uint32)
+        pos = C.c_int()
+        nat.check(nat.lib().lqrrt_engine_get_mt19937(self.h, nat.ptr(key), C.byref(pos)))
+        return key, pos.value
+
+    def seed_from_numpy_global(self):
+        st = np.random.get_state()
+        self.set_mt19937(st[1], st[2])
+
+    def sync_numpy_global(self):
+        """Leaves np.random exactly where the reference's sampler would have left it."""
+        key, pos = self.get_mt19937()
+        st = np.random.get_state()
+        np.random.set_state((st[0], key, pos, 0, 0.0))
+
+    # -- tree -----------------------------------------------------------------------------------
+    def tree_reset(self, x0):
+        x0 = nat.as_f64(x0, (self.n,))
+        nat.check(nat.lib().lqrrt_tree_reset(self.h, nat.ptr(x0), nat.current_stream()))
+
+    @property
+    def size(self):
+        return nat.check(nat.lib().lqrrt_tree_size(self.h))
+
+    def states(self, first=0, count=None):
+        count = self.size - first if count is None else count
+        out = np.empty((count, self.n))
+        nat.check(nat.lib().lqrrt_tree_get_states(self.h, first, count, nat.ptr(out)))
+        return out
+
+    def gains(self, first=0, count=None):
+        count = self.size - first if count is None else count
+        out = np.empty((count, self.m, self.n))
+        nat.check(nat.lib().lqrrt_tree_get_gains(self.h, first, count, nat.ptr(out)))
+        return out
+
+    def parents(self, first=0, count=None):
+        count = self.size - first if count is None else count
+        out = np.empty(count, dtype=np.int32)
+        nat.check(nat.lib().lqrrt_tree_get_parents(self.h, first, count, nat.ptr(out)))
+        return out
+
+    def edge_lengths(self, first=0, count=None):
+        count = self.size - first if count is None else count
+        out = np.empty(count, dtype=np.int32)
+        nat.check(nat.lib().lqrrt_tree_get_edge_lengths(self.h, first, count, nat.ptr(out)))
+        return out
+
+    def edge(self, ID):
+        H = max(self.horizon_iters or 1, 1)
+        x = np.empty((H, self.n))
+        u = np.empty((H, self.m))
+        ln = nat.check(nat.lib().lqrrt_tree_get_edge(self.h, int(ID), nat.ptr(x), nat.ptr(u)))
+        return x[:ln].copy(), u[:ln].copy()
+
+    def ignored(self, first=0, count=None):
+        count = self.size - first if count is None else count
+        out = np.empty(count, dtype=np.uint8)
+        nat.check(nat.lib().lqrrt_tree_get_ignored(self.h, first, count, nat.ptr(out)))
+        return out.astype(bool)
+
+    # -- batched operators (host arrays in, host arrays out; device memory via torch) ----------
+    def _dev(self, a, shape):
+        torch = _torch()
+        a = nat.as_f64(a, shape)
+        return torch.from_numpy(a).to("cuda:%d" % self.device)
+
+    def feasible_batch(self, x, u=None):
+        torch = _torch()
+        B = len(x)
+        dx = self._dev(x, (B, self.n))
+        du = self._dev(u, (B, self.m)) if u is not None else None
+        ok = torch.empty(B, dtype=torch.uint8, device=dx.device)
+        nat.check(nat.lib().lqrrt_feasible_batch(self.h, dx.data_ptr(), du.data_ptr() if du is not None else None,
+                                                 B, ok.data_ptr(), nat.current_stream()))
+        return ok.cpu().numpy().astype(bool)
+
+    def dynamics_batch(self, x, u):
+        torch = _torch()
+        B = len(x)
+        dx, du = self._dev(x, (B, self.n)), self._dev(u, (B, self.m))
+        out = torch.empty_like(dx)
+        nat.check(nat.lib().lqrrt_dynamics_batch(self.h, dx.data_ptr(), du.data_ptr(), B, out.data_ptr(), nat.current_stream()))
+        return out.cpu().numpy()
+
+    def gain_batch(self, x, u=None):
+        torch = _torch()
+        B = len(x)
+        dx = self._dev(x, (B, self.n))
+        du = self._dev(u, (B, self.m)) if u is not None else None
+        K = torch.empty((B, self.m, self.n), dtype=torch.float64, device=dx.device)
+        nat.check(nat.lib().lqrrt_gain_batch(self.h, dx.data_ptr(), du.data_ptr() if du is not None else None,
+                                             B, K.data_ptr(), nat.current_stream()))
+        return K.cpu().numpy()
+
+    def erf_batch(self, xg, x):
+        torch = _torch()
+        B = len(x)
+        dg, dx = self._dev(xg, (B, self.n)), self._dev(x, (B, self.n))
+        e = torch.empty_like(dx)
+        nat.check(nat.lib().lqrrt_erf_batch(self.h, dg.data_ptr(), dx.data_ptr(), B, e.data_ptr(), nat.current_stream()))
+        return e.cpu().numpy()
+
+    def nn_argmin(self, xs, S=None, use_ignore=True):
+        torch = _torch()
+        W = len(xs)
+        dxs = self._dev(xs, (W, self.n))
+        dS = self._dev(S, (self.n, self.n)) if S is not None else None
+        ids = torch.empty(W, dtype=torch.int32, device=dxs.device)
+        cost = torch.empty(W, dtype=torch.float64, device=dxs.device)
+        nat.check(nat.lib().lqrrt_nn_argmin(self.h, dxs.data_ptr(), W, dS.data_ptr() if dS is not None else None,
+                                            1 if use_ignore else 0, ids.data_ptr(), cost.data_ptr(), nat.current_stream()))
+        return ids.cpu().numpy(), cost.cpu().numpy()
+
+    def costs_to_go(self, x, S=None):
+        torch = _torch()
+        dx = self._dev(x, (self.n,))
+        dS = self._dev(S, (self.n, self.n)) if S is not None else None
+        cost = torch.empty(self.size, dtype=torch.float64, device=dx.device)
+        nat.check(nat.lib().lqrrt_costs_to_go(self.h, dx.data_ptr(), dS.data_ptr() if dS is not None else None,
+                                              cost.data_ptr(), nat.current_stream()))
+        return cost.cpu().numpy()
+
+    def steer_batch(self, parents, xtar):
+        torch = _torch()
+        W = len(xtar)
+        H = self.horizon_iters
+        dev = "cuda:%d" % self.device
+        dp = torch.from_numpy(np.ascontiguousarray(parents, dtype=np.int32)).to(dev)
+        dx = self._dev(xtar, (W, self.n))
+        ln = torch.empty(W, dtype=torch.int32, device=dev)
+        xs = torch.empty((W, H, self.n), dtype=torch.float64, device=dev)
+        us = torch.empty((W, H, self.m), dtype=torch.float64, device=dev)
+        xe = torch.empty((W, self.n), dtype=torch.float64, device=dev)
+        Ke = torch.empty((W, self.m, self.n), dtype=torch.float64, device=dev)
+        nat.check(nat.lib().lqrrt_steer_batch(self.h, dp.data_ptr(), dx.data_ptr(), W, ln.data_ptr(), xs.data_ptr(),
+                                              us.data_ptr(), xe.data_ptr(), Ke.data_ptr(), nat.current_stream()))
+        return ln.cpu().numpy(), xs.cpu().numpy(), us.cpu().numpy(), xe.cpu().numpy(), Ke.cpu().numpy()
+
+    # -- wave engine -----------------------------------------------------------------------------
+    def record_layout(self):
+        lay = np.zeros(11, dtype=np.int32)
+        nat.check(nat.lib().lqrrt_record_layout(self.h, nat.ptr(lay)))
+        return lay
+
+    def wave_records_ptr(self):
+        p = C.c_void_p()
+        nat.check(nat.lib().lqrrt_wave_records(self.h, C.byref(p)))
+        return p.value
+
+    def wave_speculate(self, W, lo, hi):
+        nat.check(nat.lib().lqrrt_wave_speculate(self.h, W, lo, hi, nat.current_stream()))
+
+    def wave_commit(self, W, max_commit, node_limit, pruning=True):
+        st = nat.ExtendStats()
+        nat.check(nat.lib().lqrrt_wave_commit(self.h, W, int(max_commit), int(node_limit), 1 if pruning else 0,
+                                              C.byref(st), nat.current_stream()))
+        return st
+
+    def extend(self, wave, max_attempts=-1, node_limit=-1, until_size=0, pruning=True, stop_on_goal=False):
+        st = nat.ExtendStats()
+        nat.check(nat.lib().lqrrt_engine_extend(self.h, int(wave), int(max_attempts), int(node_limit), int(until_size),
+                                                1 if pruning else 0, 1 if stop_on_goal else 0, C.byref(st),
+                                                nat.current_stream()))
+        return st
+
+    def plan_best(self):
+        end, steps, hits = C.c_int32(), C.c_int64(), C.c_int64()
+        nat.check(nat.lib().lqrrt_plan_best(self.h, C.byref(end), C.byref(steps), C.byref(hits)))
+        return end.value, steps.value, hits.value
+
+    def counters(self):
+        st = nat.ExtendStats()
+        nat.check(nat.lib().lqrrt_engine_counters(self.h, C.byref(st)))
+        return st
+
+    def profile_enable(self, on=True):
+        nat.check(nat.lib().lqrrt_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        a, b, c, d, f = C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_int64()
+        nat.check(nat.lib().lqrrt_profile_read(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(f)))
+        return dict(nn_ms=a.value, nn_launches=b.value, nn_bytes=c.value, steer_ms=d.value, steer_launches=f.value)

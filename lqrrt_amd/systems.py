@@ -1,0 +1,431 @@
+"""
+Native problem plugins.
+
+In the reference every problem-specific piece -- dynamics(x,u,dt), lqr(x,u), erf(xgoal,x),
+Constraints.is_feasible(x,u) -- is a Python callable defined in a demo script
+(planner.py:35-59, constraints.py:27).  A GPU cannot call Python, so lqrrt_amd ships the
+reference's demo problems as device code (csrc/systems.hpp) and this module provides, per
+problem, a *system object* that
+
+  * builds the constant tables on the host (NumPy: hull grid, thruster map, drag, gains ...)
+    exactly as the demo's definition section does and packs them into the parameter block
+    the device code reads (layout documented per class; mirrored in csrc/systems.hpp);
+  * exposes `.dynamics`, `.lqr`, `.erf`, `.is_feasible` as *plugin handles*: callables with
+    the reference's signatures, evaluated on the GPU through the batched C-ABI operators, so
+    user code written against the reference (e.g. the demos' tracking simulation, which calls
+    dynamics/erf/lqr after planning) keeps working;
+  * is recognised by lqrrt_amd.Planner / Constraints, which then run the whole extend path
+    on the device.  Plain Python callables are rejected loudly: there is no CPU path.
+
+  BoatAdvanced      demos/demo_boat_advanced.py:21-238
+  BoatIntermediate  demos/demo_boat_intermediate.py:24-221
+  BoatNovice        demos/demo_boat_novice.py:21-175
+  Car               demos/demo_car.py:26-193
+  DoublePendulum    demos/demo_pendulum.py:23-165
+  DoubleIntegrator  BASELINE.json config 5 (not in the reference)
+"""
+import ctypes as C
+
+import numpy as np
+import numpy.linalg as npl
+
+from . import _native as nat
+
+
+# --------------------------------------------------------------------------- table builders
+
+def hull_grid(length, width, buffer, spacing):
+    """2 x V lattice of body-frame hull points (demo_boat_advanced.py:60-68)."""
+    half_l, half_w = (length + buffer) / 2, (width + buffer) / 2
+    gx, gy = np.mgrid[slice(-half_l, half_l + spacing, spacing), slice(-half_w, half_w + spacing, spacing)]
+    return np.ascontiguousarray(np.vstack((gx.ravel(), gy.ravel())), dtype=np.float64)
+
+
+def obstacle_grid(seed, goal, x0, clearance, spacing=12, lo=5, hi=60):
+    """
+    The demos' jittered 6x6 circle field (demo_boat_advanced.py:190-202): centres rounded to cm,
+    radius 1; lattice points closer than `clearance` to start or goal become the placeholder
+    [-9999,-9999,-9999] (negative radius: can never collide).  RandomState(seed).rand(2) per point
+    reproduces `np.random.seed(seed)` followed by the demo's draws.
+    """
+    rs = np.random.RandomState(seed)
+    gx, gy = np.mgrid[slice(lo, hi + spacing, spacing), slice(lo, hi + spacing, spacing)]
+    gx, gy = gx.ravel(), gy.ravel()
+    goal = np.asarray(goal, dtype=np.float64)
+    x0 = np.asarray(x0, dtype=np.float64)
+    obs = np.full((gx.size, 3), -9999.0)
+    for i in range(gx.size):
+        p = np.round([gx[i], gy[i]] + 3 * (rs.rand(2) - 0.5), 2)
+        if npl.norm(p - goal[:2]) > clearance and npl.norm(np.array(p - x0[:2])) > clearance:
+            obs[i] = (p[0], p[1], 1.0)
+    return obs
+
+
+# --------------------------------------------------------------------------- plugin handles
+
+class _Plugin(object):
+    """A callable bound to a native system; `kind` in dynamics|lqr|erf|is_feasible."""
+
+    def __init__(self, system, kind):
+        self.system = system
+        self.kind = kind
+        self.__name__ = kind
+
+    def __call__(self, *args):
+        return getattr(self.system, "_eval_" + self.kind)(*args)
+
+    def __repr__(self):
+        return "<lqrrt_amd %s plugin of %s>" % (self.kind, type(self.system).__name__)
+
+
+def plugin_system(fn, kind):
+    """Returns the native system behind a plugin handle, or raises the boundary's ValueError."""
+    if isinstance(fn, _Plugin) and fn.kind == kind:
+        return fn.system
+    raise ValueError(
+        "Expected %s to be a native plugin (e.g. lqrrt_amd.systems.BoatAdvanced().%s): lqrrt_amd "
+        "evaluates the problem on the GPU and cannot call arbitrary Python functions." % (kind, kind))
+
+
+class NativeSystem(object):
+    """Base class: owns the parameter block and a small engine used to evaluate the handles."""
+    model = None
+    nstates = ncontrols = 0
+    wrap_dims = ()
+    S = None          # dense constant S (n x n) or None = identity
+
+    def __init__(self):
+        self.dynamics = _Plugin(self, "dynamics")
+        self.lqr = _Plugin(self, "lqr")
+        self.erf = _Plugin(self, "erf")
+        self.is_feasible = _Plugin(self, "is_feasible")
+        self.vps = np.zeros((2, 0))
+        self.obs = np.zeros((0, 3))
+        self.obs_stride = 3
+        self._ops = None
+        self._ops_dt = None
+
+    # -- packing -------------------------------------------------------------------------------
+    def params(self):
+        raise NotImplementedError
+
+    def desc(self):
+        """lqrrt_system_desc (include/lqrrt_hip.h) + the arrays it points to (keep alive)."""
+        d = nat.SystemDesc()
+        p = np.ascontiguousarray(self.params(), dtype=np.float64)
+        if p.size > nat.MAX_PARAMS:
+            raise ValueError("too many parameters")
+        d.model, d.nstates, d.ncontrols, d.n_params = self.model, self.nstates, self.ncontrols, p.size
+        for i, v in enumerate(p):
+            d.params[i] = v
+        vps = np.ascontiguousarray(self.vps, dtype=np.float64)
+        obs = np.ascontiguousarray(self.obs, dtype=np.float64).reshape(-1, self.obs_stride)
+        d.n_vertices, d.n_obstacles, d.obs_stride = vps.shape[1], obs.shape[0], self.obs_stride
+        d.vps = vps.ctypes.data_as(C.POINTER(C.c_double)) if vps.size else None
+        d.obs = obs.ctypes.data_as(C.POINTER(C.c_double)) if obs.size else None
+        return d, (vps, obs, p)
+
+    def Smatrix(self):
+        return np.eye(self.nstates) if self.S is None else np.asarray(self.S, dtype=np.float64)
+
+    # -- host evaluation of the handles through the device operators ----------------------------
+    def _engine(self, dt=None):
+        from .engine import Engine
+        if self._ops is None:
+            self._ops = Engine(self, capacity=64, max_wave=64)
+        if dt is not None and dt != self._ops_dt:
+            self._ops.set_resolution(dt=dt, FPR=0.0, horizon_iters=1, error_tol=np.zeros(self.nstates),
+                                     goal=None, goal_buffer=None)
+            self._ops_dt = dt
+        return self._ops
+
+    def _eval_dynamics(self, x, u, dt):
+        return self._engine(dt).dynamics_batch(np.atleast_2d(x), np.atleast_2d(u))[0]
+
+    def _eval_lqr(self, x, u):
+        K = self._engine().gain_batch(np.atleast_2d(x), np.atleast_2d(np.asarray(u, dtype=np.float64)))[0]
+        return (self.Smatrix(), K)
+
+    def _eval_erf(self, xgoal, x):
+        return self._engine().erf_batch(np.atleast_2d(xgoal), np.atleast_2d(x))[0]
+
+    def _eval_is_feasible(self, x, u):
+        return bool(self._engine().feasible_batch(np.atleast_2d(x), np.atleast_2d(np.asarray(u, dtype=np.float64)))[0])
+
+
+# --------------------------------------------------------------------------- boats
+
+class _Boat(NativeSystem):
+    nstates, ncontrols = 6, 3
+    wrap_dims = (2,)
+
+    def _objectives(self, goal_buffer_xy, tol_div, obstacle_seed):
+        self.x0 = np.array([0, 0, np.deg2rad(0), 0, 0, 0])
+        self.goal = [40, 40, np.deg2rad(90), 0, 0, 0]
+        self.goal_buffer = [goal_buffer_xy, goal_buffer_xy, np.inf, np.inf, np.inf, np.inf]
+        self.error_tol = np.copy(self.goal_buffer) / tol_div
+        self.boat_length = 210 * 0.0254
+        self.boat_width = 96 * 0.0254
+        self.obs = obstacle_grid(obstacle_seed, self.goal, self.x0, 2 * self.boat_length)
+
+
+class BoatAdvanced(_Boat):
+    """
+    4-thruster boat with per-thruster saturation and a planning speed box.
+    params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 B[3][4] | 21 invB[4][3] | 33 thrust_max[4] |
+            37 rudder | 38 velmax_pos0 | 39 velmax_neg0 | 40 kp[3] | 43 kd[3] |
+            46 velmax_pos_plan[3] | 49 velmax_neg_plan[3]
+    """
+    model = nat.MODEL_BOAT_ADVANCED
+    plan_kwargs = dict(horizon=2, dt=0.1, FPR=0.9)          # demo_boat_advanced.py:245-249
+
+    def __init__(self, obstacle_seed=0, obstacles=None):
+        NativeSystem.__init__(self)
+        m, I = 500, 500
+        self.invM = np.array([1 / m, 1 / m, 1 / I])
+        self.velmax_pos = np.array([2.5, 1, 0.7])
+        self.velmax_neg = np.array([-0.8, -1, -0.7])
+        self.thrust_max = np.array([220, 220, 220, 220])
+        positions = np.array([[-1.9000, 1.0000, -0.0123], [-1.9000, -1.0000, -0.0123],
+                              [1.6000, 0.6000, -0.0123], [1.6000, -0.6000, -0.0123]])
+        directions = np.array([[0.7071, 0.7071, 0.0000], [0.7071, -0.7071, 0.0000],
+                               [0.7071, -0.7071, 0.0000], [0.7071, 0.7071, 0.0000]])
+        levers = np.cross(positions, directions)
+        self.B = np.concatenate((directions.T, levers.T))[[0, 1, 5]]      # demo_boat_advanced.py:44
+        self.invB = npl.pinv(self.B)                                      # :45
+        Fx_max = self.B.dot(self.thrust_max * [1, 1, 1, 1])[0]
+        Fy_max = self.B.dot(self.thrust_max * [1, -1, -1, 1])[1]
+        Mz_max = self.B.dot(self.thrust_max * [-1, 1, -1, 1])[2]
+        self.D_pos = np.abs([Fx_max, Fy_max, Mz_max] / self.velmax_pos)
+        self.D_neg = np.abs([Fx_max, Fy_max, Mz_max] / self.velmax_neg)
+        self._objectives(8, 8, obstacle_seed)
+        if obstacles is not None:
+            self.obs = np.asarray(obstacles, dtype=np.float64).reshape(-1, 3)
+        self.vps = hull_grid(self.boat_length, self.boat_width, 0.25, 1)
+        self.magic_rudder = 4000
+        self.kp = np.diag([120, 20, 0])
+        self.kd = np.diag([120, 20, 0])
+        self.velmax_pos_plan = np.array([1.1, 0.4, 0.2])
+        self.velmax_neg_plan = np.array([-0.65, -0.4, -0.2])
+        self.sample_space = [(self.x0[0], self.goal[0]), (self.x0[1], self.goal[1]), (0, 0),
+                             (0.9 * self.velmax_pos_plan[0], self.velmax_pos_plan[0]),
+                             (-abs(self.velmax_neg_plan[1]), self.velmax_pos_plan[1]),
+                             (-abs(self.velmax_neg_plan[2]), self.velmax_pos_plan[2])]
+        self.goal_bias = [0.2, 0.2, 0, 0, 0, 0]
+
+    def params(self):
+        return np.concatenate((self.invM, self.D_pos, self.D_neg, self.B.ravel(), self.invB.ravel(),
+                               self.thrust_max, [self.magic_rudder, self.velmax_pos[0], self.velmax_neg[0]],
+                               np.diag(self.kp), np.diag(self.kd), self.velmax_pos_plan, self.velmax_neg_plan))
+
+
+class BoatIntermediate(_Boat):
+    """
+    Wrench-saturated boat with the heading "rudder" and a dense hull grid.
+    params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 u_max[3] | 12 rudder | 13 velmax_pos0 |
+            14 velmax_neg0 | 15 kp[3] | 18 kd[3]
+    """
+    model = nat.MODEL_BOAT_INTERMEDIATE
+    plan_kwargs = dict(horizon=2, dt=0.1, FPR=0.5)          # demo_boat_intermediate.py:228-232
+
+    def __init__(self, obstacle_seed=0, obstacles=None):
+        NativeSystem.__init__(self)
+        m, I = 500, 500
+        self.invM = np.array([1 / m, 1 / m, 1 / I])
+        self.velmax_pos = [1.1, 0.45, 0.2]
+        self.velmax_neg = [0.68, 0.45, 0.2]
+        thrust_max, thrust_lever = 220, 2.15
+        self.u_max = np.array([2 * np.sqrt(2) * thrust_max, 0.2 * np.sqrt(2) * thrust_max,
+                               4 * thrust_lever * thrust_max])
+        self.D_pos = np.abs(self.u_max / self.velmax_pos)
+        self.D_neg = np.abs(self.u_max / self.velmax_neg)
+        self._objectives(8, 8, obstacle_seed)
+        if obstacles is not None:
+            self.obs = np.asarray(obstacles, dtype=np.float64).reshape(-1, 3)
+        self.vps = hull_grid(self.boat_length, self.boat_width, 2, 0.5)
+        self.rudder = 5000
+        self.kp = np.diag([120, 120, 0])
+        self.kd = np.diag([120, 120, 0])
+        self.sample_space = [(self.x0[0], self.goal[0]), (self.x0[1], self.goal[1]), (0, 0),
+                             (0.9 * self.velmax_pos[0], self.velmax_pos[0]),
+                             (-self.velmax_neg[1], self.velmax_pos[1]),
+                             (-self.velmax_neg[2], self.velmax_pos[2])]
+        self.goal_bias = [0.2, 0.2, 0, 0, 0, 0]
+
+    def params(self):
+        return np.concatenate((self.invM, self.D_pos, self.D_neg, self.u_max,
+                               [self.rudder, self.velmax_pos[0], self.velmax_neg[0]],
+                               np.diag(self.kp), np.diag(self.kd)))
+
+
+class BoatNovice(_Boat):
+    """
+    Holonomic boat, centre-point collision model.
+    params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 u_max[3] | 12 kp[3] | 15 kd[3] | 18 boat_length/2
+    """
+    model = nat.MODEL_BOAT_NOVICE
+    plan_kwargs = dict(horizon=2, dt=0.1, FPR=0.5)          # demo_boat_novice.py:182-186
+
+    def __init__(self, obstacle_seed=0, obstacles=None):
+        NativeSystem.__init__(self)
+        m, I = 500, 500
+        self.invM = np.array([1 / m, 1 / m, 1 / I])
+        self.velmax_pos = [1.1, 0.45, 0.2]
+        self.velmax_neg = [0.68, 0.45, 0.2]
+        thrust_max, thrust_lever = 220, 2.15
+        self.u_max = np.array([2 * np.sqrt(2) * thrust_max, 2 * np.sqrt(2) * thrust_max,
+                               4 * thrust_lever * thrust_max])
+        self.D_pos = np.abs(self.u_max / self.velmax_pos)
+        self.D_neg = np.abs(self.u_max / self.velmax_neg)
+        self._objectives(6, 2, obstacle_seed)
+        if obstacles is not None:
+            self.obs = np.asarray(obstacles, dtype=np.float64).reshape(-1, 3)
+        self.kp = np.diag([120, 120, 350])
+        self.kd = np.diag([120, 120, 100])
+        self.sample_space = [(self.x0[0], self.goal[0]), (self.x0[1], self.goal[1]), (-np.pi, np.pi),
+                             (0.5 * self.velmax_pos[0], self.velmax_pos[0]),
+                             (-self.velmax_neg[1], self.velmax_pos[1]),
+                             (-self.velmax_neg[2], self.velmax_pos[2])]
+        self.goal_bias = [0.5, 0.5, 0, 0, 0, 0]
+
+    def params(self):
+        return np.concatenate((self.invM, self.D_pos, self.D_neg, self.u_max, np.diag(self.kp),
+                               np.diag(self.kd), [self.boat_length / 2]))
+
+
+# --------------------------------------------------------------------------- car
+
+class Car(NativeSystem):
+    """
+    Nonholonomic car (no sway state).
+    params: 0 invM[2] | 2 D[2] | 4 u_lo[2] | 6 u_hi[2] | 8 velmax0 | 9 kp[2] | 11 kd[2]
+    """
+    model = nat.MODEL_CAR
+    nstates, ncontrols = 5, 2
+    wrap_dims = (2,)
+    plan_kwargs = dict(horizon=5, dt=0.1, FPR=0)            # demo_car.py:200-204 (FPR defaulted)
+
+    def __init__(self, obstacle_seed=0, obstacles=None):
+        NativeSystem.__init__(self)
+        m, I = 500, 500
+        self.invM = np.array([1 / m, 1 / I])
+        self.velmax = [1.1, 1]
+        self.u_max = np.array([650, 1800])
+        self.D = np.abs(self.u_max / self.velmax)
+        self.vps = hull_grid(6, 3, 2, 0.5)                  # demo_car.py:77-90
+        self.kp = np.diag([120, 600])
+        self.kd = np.diag([120, 600])
+        self.x0 = np.array([0, 0, np.deg2rad(0), 0, 0])
+        self.goal = [40, 40, np.deg2rad(90), 0, 0]
+        self.goal_buffer = [8, 8, np.inf, np.inf, np.inf]
+        self.error_tol = np.copy(self.goal_buffer) / 2
+        self.obs = np.array([[20, 20, 5], [10, 30, 2], [40, 10, 3]], dtype=np.float64)  # 'some'
+        if obstacles is not None:
+            self.obs = np.asarray(obstacles, dtype=np.float64).reshape(-1, 3)
+        buff = 40
+        self.sample_space = [(self.goal[0] - buff, self.goal[0] + buff),
+                             (self.goal[0] - buff, self.goal[1] + buff),       # sic, demo_car.py:186
+                             (-np.pi, np.pi), (0.9 * self.velmax[0], self.velmax[0]),
+                             (-self.velmax[1], self.velmax[1])]
+        self.goal_bias = [0.5, 0.5, 0, 0, 0]
+
+    def params(self):
+        u_lo = [-self.u_max[0] / 10, -self.u_max[1]]        # demo_car.py:57
+        return np.concatenate((self.invM, self.D, u_lo, self.u_max, [self.velmax[0]],
+                               np.diag(self.kp), np.diag(self.kd)))
+
+
+# --------------------------------------------------------------------------- double pendulum
+
+class DoublePendulum(NativeSystem):
+    """
+    BASELINE.json config 1 ("pendulum"): the reference's demo is a 4-state double pendulum.
+    params: 0 a | 1 b2 | 2 m1 L1^2 | 3 m1 L0 L1 | 4 g(m0+m1)L0 | 5 m1 g L1 | 6 d[2] | 8 b[2] |
+            10 c[2] | 12 umax | 13 umax_plan | 14 K[4]
+    The demo passes horizon=0, which the reference rejects (planner.py:548-553); this build
+    plans it with horizon=0.05 s (50 steps of dt=1 ms).
+    """
+    model = nat.MODEL_PENDULUM
+    nstates, ncontrols = 4, 1
+    wrap_dims = (0, 1)
+    plan_kwargs = dict(horizon=0.05, dt=0.001, FPR=0.5)
+
+    def __init__(self, obstacle_seed=0):
+        NativeSystem.__init__(self)
+        self.L = [1, 0.5]
+        self.m = [5, 5]
+        self.g = 9.81
+        self.d = [0.4, 0.4]
+        self.b = [0.01, 0.01]
+        self.c = [0.1, 0.1]
+        self.umax = np.inf
+        self.umax_plan = 0.75 * self.umax
+        self.K = np.array([[10, 200, 0, 0]], dtype=np.float64)
+        self.x0 = np.array([-np.pi / 2, 0, 0, 0])
+        self.goal = [np.pi / 2, 0, 0, 0]
+        self.goal_buffer = [np.deg2rad(1), np.deg2rad(1), 0.001, 0.001]
+        self.error_tol = [np.deg2rad(10), np.deg2rad(10), 0.1, 0.1]
+        self.sample_space = [(0, 1.1 * np.pi), (-np.pi / 2, np.pi / 2), (-np.pi / 2, np.pi), (-np.pi, np.pi)]
+        self.goal_bias = [0.5, 0.5, 0.5, 0.5]
+
+    def params(self):
+        m, L, g = self.m, self.L, self.g
+        a = (m[0] + m[1]) * L[0]**2 + m[1] * L[1]**2        # demo_pendulum.py:62 constant part
+        b2 = 2 * m[1] * L[0] * L[1]
+        return np.concatenate(([a, b2, m[1] * L[1]**2, m[1] * L[0] * L[1],
+                                g * (m[0] + m[1]) * L[0], m[1] * g * L[1]],
+                               self.d, self.b, self.c, [self.umax, self.umax_plan], self.K.ravel()))
+
+
+# --------------------------------------------------------------------------- synthetic config 5
+
+class DoubleIntegrator(NativeSystem):
+    """
+    BASELINE.json config 5 (not in the reference): q, qdot in R^6, u in R^6, explicit Euler
+    q+ = q + dt qdot, qdot+ = qdot + dt u.  The cost-to-go S and gain K = (R+B'SB)^-1 B'SA solve the
+    discrete Riccati equation for Q = R = I (build-added operator; golden = SciPy, see lqrrt_amd.dare).
+    Obstacles: axis-aligned boxes [lo3, hi3] on q[0:3].
+    params: 0 dt | 1 K[6][12]
+    """
+    model = nat.MODEL_DOUBLE_INTEGRATOR
+    nstates, ncontrols = 12, 6
+    wrap_dims = ()
+
+    def __init__(self, n_boxes=1000, seed=0, dt=0.1, horizon=2.0, extent=100.0):
+        NativeSystem.__init__(self)
+        from .dare import dare_doubling
+        dof = 6
+        n, m = 12, 6
+        self.plan_kwargs = dict(horizon=horizon, dt=dt, FPR=0.5)
+        self.dt_model = dt
+        self.A = np.eye(n)
+        self.A[:dof, dof:] = dt * np.eye(dof)
+        self.Bm = np.vstack((np.zeros((dof, dof)), dt * np.eye(dof)))
+        self.S, self.K = dare_doubling(self.A, self.Bm, np.eye(n), np.eye(m))
+        rs = np.random.RandomState(seed)
+        centres = rs.uniform(0, extent, (n_boxes, 3))
+        half = rs.uniform(0.1, 0.5, (n_boxes, 3))
+        self.obs = np.hstack((centres - half, centres + half))
+        self.obs_stride = 6
+        self.x0 = np.zeros(n)
+        self.goal = np.concatenate((np.full(3, 0.9 * extent), np.zeros(n - 3)))
+        gb = np.full(n, np.inf)
+        gb[:3] = 0.08 * extent
+        self.goal_buffer = gb
+        self.error_tol = gb / 8
+        vmax = 2.0
+        self.sample_space = [(0, extent)] * 3 + [(-1, 1)] * (dof - 3) + [(-vmax, vmax)] * dof
+        self.goal_bias = [0.1] * 3 + [0] * (n - 3)
+
+    def params(self):
+        return np.concatenate(([self.dt_model], self.K.ravel()))
+
+
+SYSTEMS = {
+    "boat_advanced": BoatAdvanced,
+    "boat_intermediate": BoatIntermediate,
+    "boat_novice": BoatNovice,
+    "car": Car,
+    "pendulum": DoublePendulum,
+    "double_integrator": DoubleIntegrator,
+}

@@ -1,0 +1,123 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol that
+include/lqrrt_hip.h declares, and refuses to compute without a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import lqrrt_amd
+from lqrrt_amd import _native as nat
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "lqrrt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lqrrt_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    lib = nat.lib()
+    names = _declared()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(lib, name), "liblqrrt_hip.so does not export %s" % name
+        assert name in nat.SIGNATURES, "%s has no ctypes signature" % name
+    for name in nat.SIGNATURES:
+        assert name in names, "%s bound but not declared in the header" % name
+    assert lib.lqrrt_abi_version() == 1
+
+
+def test_struct_sizes_match_header():
+    # sizes implied by include/lqrrt_hip.h (natural alignment)
+    import ctypes as C
+    assert C.sizeof(nat.SystemDesc) == 16 + 8 * 96 + 16 + 16
+    assert C.sizeof(nat.Resolution) == 16 + 8 + 4 * 8 * 12
+    assert C.sizeof(nat.SamplerDesc) == 3 * 8 * 12 + 8
+    assert C.sizeof(nat.ExtendStats) == 8 * 8 + 8
+
+
+def test_plain_callables_are_rejected():
+    boat = lqrrt_amd.systems.BoatAdvanced(0)
+    with pytest.raises(ValueError):
+        lqrrt_amd.Constraints(6, 3, boat.goal_buffer, lambda x, u: True)
+    cons = lqrrt_amd.Constraints(6, 3, boat.goal_buffer, boat.is_feasible)
+    with pytest.raises(ValueError):
+        lqrrt_amd.Planner(lambda x, u, dt: x, boat.lqr, cons, horizon=2, dt=0.1)
+    with pytest.raises(ValueError):
+        lqrrt_amd.Planner(boat.dynamics, boat.lqr, cons, horizon=2, dt=0.1)      # np.subtract erf on an angular system
+    car = lqrrt_amd.systems.Car()
+    with pytest.raises(ValueError):
+        lqrrt_amd.Planner(boat.dynamics, car.lqr, cons, horizon=2, dt=0.1, erf=boat.erf)
+
+
+def test_reference_error_conventions():
+    boat = lqrrt_amd.systems.BoatAdvanced(0)
+    with pytest.raises(ValueError):
+        lqrrt_amd.Constraints(6, 3, [1, 2, 3], boat.is_feasible)                  # constraints.py:49
+    cons = lqrrt_amd.Constraints(6, 3, boat.goal_buffer, boat.is_feasible)
+    kw = dict(error_tol=boat.error_tol, erf=boat.erf, printing=False)
+    with pytest.raises(ValueError):
+        lqrrt_amd.Planner(boat.dynamics, boat.lqr, cons, horizon=0, dt=0.1, **kw)  # planner.py:553
+    with pytest.raises(ValueError):
+        lqrrt_amd.Planner(boat.dynamics, boat.lqr, cons, horizon=2, dt=0.1, min_time=3, max_time=1, **kw)  # :504
+    with pytest.raises(ValueError):
+        lqrrt_amd.Planner(boat.dynamics, boat.lqr, cons, horizon=2, dt=0.1, goal0=[1, 2], **kw)            # :480
+    p = lqrrt_amd.Planner(boat.dynamics, boat.lqr, cons, horizon=0.3, dt=0.1, **kw)
+    assert p.horizon_iters == int(0.3 / 0.1) == 2                                  # planner.py:549 float floor
+    assert p.update_plan(boat.x0, boat.sample_space) is False                      # no goal -> False, :157-161
+    np.testing.assert_array_equal(p.get_state(0.3), boat.x0)
+
+
+def test_no_gpu_means_no_compute():
+    if nat.device_count() > 0:
+        pytest.skip("a GPU is present")
+    boat = lqrrt_amd.systems.BoatAdvanced(0)
+    cons = lqrrt_amd.Constraints(6, 3, boat.goal_buffer, boat.is_feasible)
+    p = lqrrt_amd.Planner(boat.dynamics, boat.lqr, cons, error_tol=boat.error_tol, erf=boat.erf,
+                          goal0=boat.goal, printing=False, **boat.plan_kwargs)
+    with pytest.raises(nat.NativeError):
+        p.update_plan(boat.x0, boat.sample_space, goal_bias=boat.goal_bias)
+    with pytest.raises(nat.NativeError):
+        boat.dynamics(boat.x0, np.zeros(3), 0.1)
+
+
+def test_system_tables_match_reference_fixtures(golden_dir):
+    for name, cls in lqrrt_amd.systems.SYSTEMS.items():
+        path = os.path.join(golden_dir, "ops_%s.npz" % name)
+        if not os.path.exists(path):
+            continue
+        g = np.load(path)
+        s = cls(0)
+        if "vps" in g.files:
+            np.testing.assert_array_equal(s.vps, g["vps"])
+        if "obs" in g.files and name != "pendulum":
+            np.testing.assert_array_equal(np.asarray(s.obs).reshape(-1, 3), g["obs"])
+        for key in ("B", "invB", "D_pos", "D_neg", "D", "invM", "u_max"):
+            if "tbl_" + key in g.files:
+                np.testing.assert_array_equal(np.asarray(getattr(s, key), dtype=np.float64), g["tbl_" + key])
+        np.testing.assert_array_equal(np.asarray(s.goal, dtype=np.float64), g["tbl_goal"])
+        np.testing.assert_array_equal(np.asarray(s.error_tol, dtype=np.float64), g["tbl_error_tol"])
+        np.testing.assert_array_equal(np.asarray(s.sample_space, dtype=np.float64), g["tbl_sample_space"])
+
+
+def test_dare_matches_scipy():
+    import scipy.linalg
+    from lqrrt_amd.dare import dare_doubling
+    rng = np.random.RandomState(3)
+    for n, m in ((2, 1), (4, 2), (12, 6)):
+        if n == 12:
+            dt = 0.1
+            A = np.eye(n); A[:6, 6:] = dt * np.eye(6)
+            B = np.vstack((np.zeros((6, 6)), dt * np.eye(6)))
+        else:
+            A = np.eye(n) + 0.1 * rng.randn(n, n)
+            B = rng.randn(n, m)
+        Q, R = np.eye(n), np.eye(m)
+        S, K = dare_doubling(A, B, Q, R)
+        S_ref = scipy.linalg.solve_discrete_are(A, B, Q, R)
+        K_ref = np.linalg.solve(R + B.T @ S_ref @ B, B.T @ S_ref @ A)
+        np.testing.assert_allclose(S, S_ref, rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(K, K_ref, rtol=1e-10, atol=1e-10)
