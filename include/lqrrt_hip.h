@@ -146,6 +146,12 @@ int lqrrt_engine_get_mt19937(lqrrt_engine* e, uint32_t* key624, int* pos);
 int lqrrt_tree_reset(lqrrt_engine* e, const double* x0_host, void* stream);
 int lqrrt_tree_size(lqrrt_engine* e);
 
+/* Remember / restore the current tree size, ignore set and goal bookkeeping.  Nodes are only
+ * ever appended, so rewinding is O(1); used by bench.py to keep the tree inside the size
+ * window the metric is quoted at. (build-only; the reference rebuilds its tree per call) */
+int lqrrt_tree_mark(lqrrt_engine* e);
+int lqrrt_tree_rewind(lqrrt_engine* e);
+
 /* Host copies of tree features (planner.tree.state / .pID / .lqr / .x_seq / .u_seq). */
 int lqrrt_tree_get_states(lqrrt_engine* e, int first, int count, double* out_host /*[count][n]*/);
 int lqrrt_tree_get_gains(lqrrt_engine* e, int first, int count, double* out_host /*[count][m][n]*/);

@@ -65,6 +65,8 @@ SIGNATURES = {
     "lqrrt_engine_get_mt19937": (_I, [_P, _P, C.POINTER(_I)]),
     "lqrrt_tree_reset": (_I, [_P, _P, _P]),
     "lqrrt_tree_size": (_I, [_P]),
+    "lqrrt_tree_mark": (_I, [_P]),
+    "lqrrt_tree_rewind": (_I, [_P]),
     "lqrrt_tree_get_states": (_I, [_P, _I, _I, _P]),
     "lqrrt_tree_get_gains": (_I, [_P, _I, _I, _P]),
     "lqrrt_tree_get_parents": (_I, [_P, _I, _I, _P]),
@@ -106,6 +108,11 @@ def lib():
             raise RuntimeError(
                 "lqrrt_amd: %s is missing -- build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64,
+        # and a second copy (the one under /opt/rocm that hipcc linked against) would fight it for the
+        # device.  Importing torch first makes the loader resolve our NEEDED libamdhip64.so.7 to the copy
+        # torch already mapped, so kernels, torch tensors and RCCL all share one runtime.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

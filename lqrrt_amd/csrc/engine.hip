@@ -114,6 +114,11 @@ struct lqrrt_engine {
     int best_end = -1;
     int64_t best_steps = -1;
 
+    // mark/rewind (bench: keep the tree inside a size window)
+    int mark_N = 0, mark_best_end = -1;
+    int64_t mark_hits = 0, mark_best_steps = -1;
+    std::vector<unsigned long long> mark_ign;
+
     // wave buffers
     RecLayout L{};
     double* d_rec = nullptr;
@@ -266,13 +271,15 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     int* pia = want_all ? e->d_pidx_all : nullptr;
     EvPair ev;
     if (profile) prof_begin(e, st, &ev);
+#define NN_LAUNCH(DENSE, TRI)                                                                            \
+    DISPATCH(e, hipLaunchKernelGGL((k_nn_scan<S, DENSE, TRI>), grid, dim3(64), 0, st, nv, xs, W, S_use, chunk, \
+                                   e->d_pcost, e->d_pidx, pca, pia))
     if (S_use) {
-        DISPATCH(e, hipLaunchKernelGGL((k_nn_scan<S, true>), grid, dim3(64), 0, st, nv, xs, W, S_use, chunk,
-                                        tri ? 1 : 0, e->d_pcost, e->d_pidx, pca, pia));
+        if (tri) { NN_LAUNCH(true, true); } else { NN_LAUNCH(true, false); }
     } else {
-        DISPATCH(e, hipLaunchKernelGGL((k_nn_scan<S, false>), grid, dim3(64), 0, st, nv, xs, W, S_use, chunk,
-                                        tri ? 1 : 0, e->d_pcost, e->d_pidx, pca, pia));
+        if (tri) { NN_LAUNCH(false, true); } else { NN_LAUNCH(false, false); }
     }
+#undef NN_LAUNCH
     if (profile) prof_end(e, st, &ev, 0, (double)W * (double)nv.count * (8.0 * e->n + 1.0));
     hipLaunchKernelGGL(k_nn_reduce, dim3((W + 255) / 256), dim3(256), 0, st, e->d_pcost, e->d_pidx, pca, pia, W,
                        n_chunks, out_id, out_cost, rec, e->L.R, e->L.off_cost, e->L.off_parent);
@@ -589,9 +596,28 @@ extern "C" int lqrrt_tree_get_ignored(lqrrt_engine* e, int first, int count, uin
     return 0;
 }
 
+extern "C" int lqrrt_tree_mark(lqrrt_engine* e) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    if (e->N < 1) return fail(LQRRT_E_STATE, "no tree: call lqrrt_tree_reset");
+    e->mark_N = e->N; e->mark_ign = e->h_ign; e->mark_hits = e->goal_hits;
+    e->mark_best_end = e->best_end; e->mark_best_steps = e->best_steps;
+    return 0;
+}
+
+extern "C" int lqrrt_tree_rewind(lqrrt_engine* e) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    if (e->mark_N < 1 || e->mark_N > e->N) return fail(LQRRT_E_STATE, "no valid mark");
+    e->N = e->mark_N;
+    e->h_pid.resize(e->N); e->h_elen.resize(e->N);
+    e->h_ign = e->mark_ign; e->ign_dirty = true;
+    e->goal_hits = e->mark_hits; e->best_end = e->mark_best_end; e->best_steps = e->mark_best_steps;
+    e->tot.tree_size = e->N;
+    return 0;
+}
+
 static int flush_ignore(lqrrt_engine* e, hipStream_t st) {
     if (!e->ign_dirty) return 0;
-    HIPCHK(hipMemcpyAsync(e->tv.ignore, e->h_ign.data(), sizeof(unsigned long long) * ((size_t)e->N / 64 + 1),
+    HIPCHK(hipMemcpyAsync(e->tv.ignore, e->h_ign.data(), sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1),
                           hipMemcpyHostToDevice, st));
     e->ign_dirty = false;
     return 0;

@@ -111,11 +111,12 @@ __device__ __forceinline__ double quad_cost(const double* e, const double* Sd) {
 
 // ------------------------------------------------------------------------------------------
 // NN scan.  grid = (ceil(W/64), n_chunks), block = 64.  Lane = sample, uniform loop over the
-// chunk's nodes.  tri != 0: only nodes with index < sample index are eligible (in-wave pass).
+// chunk's nodes.  TRI: only nodes with index < sample index are eligible (in-wave pass; a
+// separate instantiation so that profiles tell it apart from the tree scan).
 // Output partial minima [chunk][W]: masked (respecting `ignore`) and unmasked.
-template <class S, bool DENSE>
+template <class S, bool DENSE, bool TRI>
 __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __restrict__ xs, int W,
-                                                const double* __restrict__ Sd, int chunk, int tri,
+                                                const double* __restrict__ Sd, int chunk,
                                                 double* __restrict__ pcost, int* __restrict__ pidx,
                                                 double* __restrict__ pcost_all, int* __restrict__ pidx_all) {
     const int lane = threadIdx.x;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
     const int i0 = blockIdx.y * chunk;
     int i1 = i0 + chunk;
     if (i1 > nv.count) i1 = nv.count;
-    if (tri) {
+    if constexpr (TRI) {
         const int tmax = blockIdx.x * 64 + 63;
         if (i1 > tmax) i1 = tmax;
     }
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
         erf_cached<S>(xg, gtrig, x, trig, e);
         const double c = quad_cost<S, DENSE>(e, Sd);
         const bool ign = nv.ignore ? ((nv.ignore[i >> 6] >> (i & 63)) & 1ull) != 0 : false;
-        const bool ok = tri ? (i < t) : true;
+        const bool ok = TRI ? (i < t) : true;
         if (ok && c < best_all) { best_all = c; bidx_all = i; }
         if (ok && !ign && c < best) { best = c; bidx = i; }
     }

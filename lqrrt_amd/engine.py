@@ -101,6 +101,12 @@ class Engine(object):
         x0 = nat.as_f64(x0, (self.n,))
         nat.check(nat.lib().lqrrt_tree_reset(self.h, nat.ptr(x0), nat.current_stream()))
 
+    def tree_mark(self):
+        nat.check(nat.lib().lqrrt_tree_mark(self.h))
+
+    def tree_rewind(self):
+        nat.check(nat.lib().lqrrt_tree_rewind(self.h))
+
     @property
     def size(self):
         return nat.check(nat.lib().lqrrt_tree_size(self.h))
