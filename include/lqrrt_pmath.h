@@ -1,0 +1,140 @@
+/*
+ * lqrrt_pmath.h -- portable, bit-reproducible sin / cos / atan2 in IEEE-754 double.
+ *
+ * Why this exists: the reference's problem plugins call np.sin / np.cos / np.arctan2, whose last
+ * bit depends on the host (glibc vs SVML/AVX-512 dispatch inside NumPy), and the boat problem's
+ * "magic rudder" (demos/demo_boat_advanced.py:101-111) amplifies one-ulp differences by up to
+ * ~1e2-1e3 per step once the boat is nearly stopped with saturated thrusters -- see DESIGN.md
+ * "Conditioning".  To be able to prove that the wave-parallel engine reproduces the sequential
+ * algorithm EXACTLY (bit-for-bit trees at any size) the device code and the C oracle both
+ * evaluate elementary functions through this header, which uses only operations that IEEE-754
+ * defines exactly -- + - * / fma floor fabs copysign and comparisons -- in a fixed order.  The
+ * same source therefore gives identical bits on gfx950 (hipcc -ffp-contract=off) and on x86-64
+ * (gcc -ffp-contract=off; fma() is correctly rounded by the C standard, in hardware or not).
+ *
+ * Accuracy (measured against 60-digit mpmath, tests/test_pmath.py): sin, cos <= 1 ulp for
+ * |x| <= 1e5; atan2 <= 2 ulp.  Domain: finite arguments; |x| < 1.6e6 for sin/cos (beyond that
+ * the 33-bit Cody-Waite product n*P1 is no longer exact and libm is used instead).
+ *
+ * Method: sin/cos -- reduction x = n*(pi/2) + r by a two-level Cody-Waite split of pi/2 with an
+ * explicit tail, Taylor kernels in r^2 (reciprocal factorials; truncation < 1e-19 on |r| <= pi/4).
+ * atan2 -- t = min/max in [0,1]; t > tan(pi/8) is folded by atan t = pi/4 + atan((t-1)/(t+1));
+ * atan z = z + z^3 q(z^2) with q a degree-10 Chebyshev-node interpolant (relative error 5e-18,
+ * coefficients generated with mpmath for this file); octant/sign fix-up with hi/lo pi constants.
+ */
+#ifndef LQRRT_PMATH_H
+#define LQRRT_PMATH_H
+
+#include <math.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define LQ_HD __host__ __device__ __forceinline__
+#else
+#define LQ_HD static inline
+#endif
+
+#define LQ_PI_HI     0x1.921fb54442d18p+1
+#define LQ_PI_LO     0x1.1a62633145c07p-53
+#define LQ_PI_2_HI   0x1.921fb54442d18p+0
+#define LQ_PI_2_LO   0x1.1a62633145c07p-54
+#define LQ_PI_4_HI   0x1.921fb54442d18p-1
+#define LQ_PI_4_LO   0x1.1a62633145c07p-55
+#define LQ_2_OVER_PI 0x1.45f306dc9c883p-1
+#define LQ_TAN_PI_8  0x1.a827999fcef32p-2
+/* pi/2 = P1 + P1T (P1: leading 33 bits), P1T = P2 + P2T (P2: next 33 bits) */
+#define LQ_P1        0x1.921fb54400000p+0
+#define LQ_P1T       0x1.0b4611a626331p-34
+#define LQ_P2        0x1.0b4611a600000p-34
+#define LQ_P2T       0x1.3198a2e037073p-69
+
+/* sin and cos of x together */
+LQ_HD void lq_sincos(double x, double* sn, double* cs) {
+    double r, rt;
+    int q = 0;
+    const double ax = fabs(x);
+    if (ax <= LQ_PI_4_HI) {
+        r = x;
+        rt = 0.0;
+    } else if (ax < 1.6e6) {
+        const double fn = floor(x * LQ_2_OVER_PI + 0.5);
+        double r0 = x - fn * LQ_P1;                 /* exact: fn*P1 has <= 53 bits, Sterbenz */
+        double w = fn * LQ_P1T;
+        r = r0 - w;
+        if (fabs(r) < fabs(r0) * 0x1p-16) {         /* x close to a multiple of pi/2: go one level deeper */
+            const double t = r0;
+            w = fn * LQ_P2;
+            r0 = t - w;
+            w = fn * LQ_P2T - ((t - r0) - w);
+            r = r0 - w;
+        }
+        rt = (r0 - r) - w;
+        q = (int)(fn - 4.0 * floor(fn * 0.25));      /* fn mod 4 in {0,1,2,3} */
+    } else {
+        *sn = sin(x);
+        *cs = cos(x);
+        return;
+    }
+    const double z = r * r;
+    /* sin r = r + r z (s3 + z (s5 + ... + z s17)) */
+    double ps = 0x1.952c77030ad4ap-49;                          /* 1/17! */
+    ps = fma(ps, z, -0x1.ae7f3e733b81fp-41);                    /* -1/15! */
+    ps = fma(ps, z, 0x1.6124613a86d09p-33);                     /* 1/13! */
+    ps = fma(ps, z, -0x1.ae64567f544e4p-26);                    /* -1/11! */
+    ps = fma(ps, z, 0x1.71de3a556c734p-19);                     /* 1/9! */
+    ps = fma(ps, z, -0x1.a01a01a01a01ap-13);                    /* -1/7! */
+    ps = fma(ps, z, 0x1.1111111111111p-7);                      /* 1/5! */
+    ps = fma(ps, z, -0x1.5555555555555p-3);                     /* -1/3! */
+    const double hz = 0.5 * z;
+    const double ksin = r + (r * z * ps + rt * (1.0 - hz));
+    /* cos r = 1 - z/2 + z^2 (c4 + z (c6 + ... + z c16)) */
+    double pc = 0x1.ae7f3e733b81fp-45;                          /* 1/16! */
+    pc = fma(pc, z, -0x1.93974a8c07c9dp-37);                    /* -1/14! */
+    pc = fma(pc, z, 0x1.1eed8eff8d898p-29);                     /* 1/12! */
+    pc = fma(pc, z, -0x1.27e4fb7789f5cp-22);                    /* -1/10! */
+    pc = fma(pc, z, 0x1.a01a01a01a01ap-16);                     /* 1/8! */
+    pc = fma(pc, z, -0x1.6c16c16c16c17p-10);                    /* -1/6! */
+    pc = fma(pc, z, 0x1.5555555555555p-5);                      /* 1/4! */
+    const double one_m = 1.0 - hz;
+    const double kcos = one_m + (((1.0 - one_m) - hz) + (z * z * pc - r * rt));
+    double s = ksin, c = kcos;
+    if (q == 1) { s = kcos; c = -ksin; }
+    else if (q == 2) { s = -ksin; c = -kcos; }
+    else if (q == 3) { s = -kcos; c = ksin; }
+    *sn = s;
+    *cs = c;
+}
+
+LQ_HD double lq_sin(double x) { double s, c; lq_sincos(x, &s, &c); return s; }
+LQ_HD double lq_cos(double x) { double s, c; lq_sincos(x, &s, &c); return c; }
+
+/* four-quadrant arctangent, C99 sign conventions for zeros */
+LQ_HD double lq_atan2(double y, double x) {
+    const double ax = fabs(x), ay = fabs(y);
+    const int xneg = copysign(1.0, x) < 0.0;
+    if (ay == 0.0) return xneg ? copysign(LQ_PI_HI, y) : y;
+    if (ax == 0.0) return copysign(LQ_PI_2_HI, y);
+    const int swap = ay > ax;
+    const double mx = swap ? ay : ax, mn = swap ? ax : ay;
+    const double t = mn / mx;
+    const int big = t > LQ_TAN_PI_8;
+    const double z = big ? (t - 1.0) / (t + 1.0) : t;
+    const double w = z * z;
+    double p = -0x1.3a31a1d5ffde0p-6;
+    p = fma(p, w, 0x1.4162b9ab69c5ap-5);
+    p = fma(p, w, -0x1.a0999a234950fp-5);
+    p = fma(p, w, 0x1.dfe6491089bd5p-5);
+    p = fma(p, w, -0x1.10fa77ab514f0p-4);
+    p = fma(p, w, 0x1.3b126305dc4dep-4);
+    p = fma(p, w, -0x1.745d0b28a2eeep-4);
+    p = fma(p, w, 0x1.c71c71853d607p-4);
+    p = fma(p, w, -0x1.24924924361fep-3);
+    p = fma(p, w, 0x1.999999999934cp-3);
+    p = fma(p, w, -0x1.5555555555555p-2);
+    const double corr = z * w * p;                               /* atan z - z */
+    double a = big ? LQ_PI_4_HI + (z + (corr + LQ_PI_4_LO)) : z + corr;
+    if (swap) a = LQ_PI_2_HI - (a - LQ_PI_2_LO);
+    if (xneg) a = LQ_PI_HI - (a - LQ_PI_LO);
+    return copysign(a, y);
+}
+
+#endif /* LQRRT_PMATH_H */

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -876,6 +877,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
         HIPCHK(hipMemcpyAsync(e->h_summary, e->d_summary, sizeof(int) * (2 + 3 * (size_t)W), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         const int n_list = e->h_summary[0], n_defer = e->h_summary[1];
+        if (getenv("LQRRT_TRACE")) fprintf(stderr, "[wave N=%d W=%d] round %d: list=%d defer=%d\n", e->N, W, rounds, n_list, n_defer);
         if (n_list == 0 && n_defer == 0) break;
         if (n_list == 0) return fail(LQRRT_E_STATE, "exact-mode repair made no progress (deferred=%d)", n_defer);
         TRY(launch_steer(e, xs, e->d_list, 0, n_list, e->d_par_done, st));
@@ -932,6 +934,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
         ws.goal_hits = 1;
         if (e->best_end < 0 || steps < e->best_steps) { e->best_end = id; e->best_steps = steps; }  // planner.py:276 (T < self.T)
     }
+    if (getenv("LQRRT_TRACE")) fprintf(stderr, "[wave N=%d W=%d] commit C=%d acc=%d hit=%d rounds=%d\n", base, W, C, acc, (int)hit, rounds);
     // advance the stream
     const int64_t last = e->cursor + C - 1;
     if (C > 0) e->committed_row = e->pool_rows_end[(size_t)(last - e->pool_base)];

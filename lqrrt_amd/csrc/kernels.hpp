@@ -73,8 +73,7 @@ template <class S>
 __device__ __forceinline__ void trig_of(const double* x, double* trig) {
 #pragma unroll
     for (int k = 0; k < S::NW; ++k) {
-        trig[2 * k] = cos(x[S::wd(k)]);
-        trig[2 * k + 1] = sin(x[S::wd(k)]);
+        lq_sincos(x[S::wd(k)], &trig[2 * k + 1], &trig[2 * k]);
     }
 }
 

@@ -3,9 +3,11 @@
 // The reference keeps dynamics / lqr / erf / is_feasible as Python callbacks defined in its
 // demo scripts; a GPU cannot call Python, so each shipped problem is restated here as a set of
 // inlined device functions with the SAME operation order in IEEE double (the file is compiled
-// with -ffp-contract=off, so a*b+c is two roundings exactly as in NumPy).  Remaining
-// differences to NumPy are the last-ulp behaviour of sin/cos/atan2/tanh/sqrt (ocml vs
-// glibc/SVML) and BLAS summation order inside the demos' tiny `.dot` calls.
+// with -ffp-contract=off, so a*b+c is two roundings exactly as in NumPy).  sin/cos/atan2 come
+// from include/lqrrt_pmath.h (bit-reproducible on CPU and GPU, <= 2 ulp), so the C oracle and
+// this code agree bit-for-bit; remaining differences to NumPy are the last ulp of those
+// functions (NumPy itself switches between glibc and SVML by CPU) and BLAS summation order
+// inside the demos' tiny `.dot` calls.
 //
 // Every system S provides
 //   S::N, S::M            state / effort sizes
@@ -19,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include "../../include/lqrrt_pmath.h"
 
 namespace lq {
 
@@ -43,7 +46,7 @@ __device__ __forceinline__ double clipd(double v, double lo, double hi) {
 
 // The demos' angle error: atan2(sg*c - cg*s, cg*c + sg*s)  (e.g. demo_boat_advanced.py:159-164)
 __device__ __forceinline__ double wrap_err(double cg, double sg, double c, double s) {
-    return atan2(sg * c - cg * s, cg * c + sg * s);
+    return lq_atan2(sg * c - cg * s, cg * c + sg * s);
 }
 
 // np.sum over the last axis of a C-contiguous (N,n) array: plain left-to-right loop for n < 8,
@@ -131,8 +134,9 @@ struct BoatCommon {
     __device__ static double rudder_term(double gainv, const double* x, double c, double s) {
         const double vw0 = c * x[3] + (-s) * x[4];
         const double vw1 = s * x[3] + c * x[4];
-        const double ang = atan2(vw1, vw0);
-        const double cg = cos(ang), sg = sin(ang);
+        const double ang = lq_atan2(vw1, vw0);
+        double cg, sg;
+        lq_sincos(ang, &sg, &cg);
         return gainv * wrap_err(cg, sg, c, s);
     }
 
@@ -287,7 +291,7 @@ struct Pendulum {
     __device__ static void step(const double* P, const double* q, const double* trig, double* u, double dt, double* qn) {
         // manipulator equation, demo_pendulum.py:54-100
         const double c1 = trig[2], s1 = trig[3], c0 = trig[0];
-        const double c01 = cos(q[0] + q[1]);
+        const double c01 = lq_cos(q[0] + q[1]);
         const double M00 = P[0] + P[1] * c1;
         const double M01 = P[2] + P[3] * c1;
         const double M11 = P[2];

@@ -1,0 +1,187 @@
+"""
+ORACLE (test infrastructure) -- ctypes wrapper of oracle/lqrrt_oracle.c, the plain-C sequential
+restatement of the reference's extend path.  Used by tests/, smoke() and bench.py's cpu_baseline
+leg only.  Takes the same plain-data problem description as the HIP engine (model id, parameter
+block, hull/obstacle tables) so both sides are fed identical inputs.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liblqrrt_oracle.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            subprocess.check_call(["make", "-s", "-C", _HERE])
+        L = C.CDLL(_LIB)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        for name in ("orc_iterations", "orc_candidates", "orc_hits", "orc_best_steps"):
+            getattr(L, name).restype = C.c_longlong
+        L.orc_extend.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p]
+        L.orc_enable_trace.argtypes = [C.c_void_p, C.c_longlong]
+        L.orc_get_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
+        L.orc_set_resolution.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int] + [C.c_void_p] * 4
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class COracle(object):
+    """Sequential planner for one problem (system = an object with model/params()/vps/obs/obs_stride)."""
+
+    def __init__(self, system, capacity):
+        self.n, self.m = system.nstates, system.ncontrols
+        params = _f(system.params())
+        vps = _f(system.vps)
+        obs = _f(system.obs).reshape(-1, system.obs_stride)
+        self.system = system
+        self.h = C.c_void_p(lib().orc_create(system.model, _p(params), params.size, _p(vps), vps.shape[1],
+                                             _p(obs), obs.shape[0], system.obs_stride, int(capacity)))
+        if not self.h:
+            raise ValueError("unknown model")
+        self.H = 1
+        self.S = None if system.S is None else _f(system.S)
+
+    def __del__(self):
+        try:
+            lib().orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def configure(self, dt, FPR, horizon_iters, error_tol, goal, goal_buffer, sample_space, goal_bias, tries=10):
+        tol = _f(np.broadcast_to(np.abs(np.asarray(error_tol, dtype=np.float64)), (self.n,)))
+        g = _f(goal)
+        b = np.abs(_f(goal_buffer))
+        lo, hi = _f(g - b), _f(g + b)
+        lib().orc_set_resolution(self.h, float(dt), float(FPR), int(horizon_iters), _p(tol), _p(g), _p(lo), _p(hi))
+        self.H = int(horizon_iters)
+        space = _f(sample_space)
+        centers, spans, bias = _f(np.mean(space, axis=1)), _f(np.diff(space).flatten()), _f(goal_bias)
+        lib().orc_set_sampler(self.h, _p(centers), _p(spans), _p(bias), int(tries))
+
+    def seed(self, seed):
+        st = np.random.RandomState(seed).get_state()
+        key = np.ascontiguousarray(st[1], dtype=np.uint32)
+        lib().orc_set_mt19937(self.h, _p(key), int(st[2]))
+
+    def reset(self, x0):
+        x0 = _f(x0)
+        lib().orc_reset(self.h, _p(x0))
+
+    def enable_trace(self, cap):
+        lib().orc_enable_trace(self.h, int(cap))
+
+    def extend(self, max_iters=-1, max_nodes=-1, pruning=True, stop_on_goal=False):
+        return lib().orc_extend(self.h, int(max_iters), int(max_nodes), 1 if pruning else 0, 1 if stop_on_goal else 0,
+                                _p(self.S) if self.S is not None else None)
+
+    @property
+    def size(self):
+        return lib().orc_size(self.h)
+
+    @property
+    def iterations(self):
+        return lib().orc_iterations(self.h)
+
+    @property
+    def candidates(self):
+        return lib().orc_candidates(self.h)
+
+    @property
+    def hits(self):
+        return lib().orc_hits(self.h)
+
+    def best(self):
+        return lib().orc_best_end(self.h), lib().orc_best_steps(self.h)
+
+    def states(self):
+        out = np.empty((self.size, self.n))
+        lib().orc_get_states(self.h, _p(out))
+        return out
+
+    def gains(self):
+        out = np.empty((self.size, self.m, self.n))
+        lib().orc_get_gains(self.h, _p(out))
+        return out
+
+    def parents(self):
+        out = np.empty(self.size, dtype=np.int32)
+        lib().orc_get_parents(self.h, _p(out))
+        return out
+
+    def edge_lengths(self):
+        out = np.empty(self.size, dtype=np.int32)
+        lib().orc_get_edge_lengths(self.h, _p(out))
+        return out
+
+    def ignored(self):
+        out = np.empty(self.size, dtype=np.uint8)
+        lib().orc_get_ignored(self.h, _p(out))
+        return out.astype(bool)
+
+    def edge(self, ID):
+        x = np.empty((self.H, self.n))
+        u = np.empty((self.H, self.m))
+        ln = lib().orc_get_edge(self.h, int(ID), _p(x), _p(u))
+        return x[:ln].copy(), u[:ln].copy()
+
+    def trace(self):
+        k = self.iterations
+        near = np.empty(k, dtype=np.int32)
+        ln = np.empty(k, dtype=np.int32)
+        lib().orc_get_trace(self.h, _p(near), _p(ln), k)
+        return near, ln
+
+    def nearest(self, x, S=None, pruning=False):
+        x = _f(x)
+        S = None if S is None else _f(S)
+        return lib().orc_nearest(self.h, _p(x), _p(S) if S is not None else None, 1 if pruning else 0)
+
+    # single-call operators
+    def dynamics(self, x, u):
+        x, u = _f(x), _f(u)
+        out = np.empty(self.n)
+        lib().orc_dynamics(self.h, _p(x), _p(u), _p(out))
+        return out
+
+    def feasible(self, x, u):
+        x, u = _f(x), _f(u)
+        return bool(lib().orc_feasible(self.h, _p(x), _p(u)))
+
+    def gain(self, x, u):
+        x, u = _f(x), _f(u)
+        out = np.empty((self.m, self.n))
+        lib().orc_gain(self.h, _p(x), _p(u), _p(out))
+        return out
+
+    def erf(self, xg, x):
+        xg, x = _f(xg), _f(x)
+        out = np.empty(self.n)
+        lib().orc_erf(self.h, _p(xg), _p(x), _p(out))
+        return out
+
+
+def make(system, max_nodes, seed=1, tries=10):
+    """COracle configured with the demo's PLAN kwargs, seeded and reset at x0."""
+    o = COracle(system, capacity=int(max_nodes) + 8)
+    kw = system.plan_kwargs
+    o.configure(kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]), system.error_tol, system.goal, system.goal_buffer,
+                system.sample_space, system.goal_bias, tries)
+    o.seed(seed)
+    o.reset(system.x0)
+    return o

@@ -1,0 +1,499 @@
+/*
+ * ORACLE (test infrastructure, NOT product code) -- plain-C, single-threaded restatement of the
+ * reference lqRRT extend path for the shipped demo problems.
+ *
+ *   * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *   * The product (lqrrt_amd/) never links or calls it; there is no CPU fallback.
+ *
+ * It follows the reference statement by statement (citations relative to jnez71/lqRRT):
+ *   sampler            planner.py:176-211      cost-to-go + nearest   planner.py:239-247,340-350
+ *   steer              planner.py:354-438      add node / goal test   planner.py:253-283, tree.py:77-96
+ *   problem plugins    demos/demo_boat_advanced.py:78-225, demo_boat_intermediate.py:48-210,
+ *                      demo_boat_novice.py:45-164, demo_car.py:46-180, demo_pendulum.py:54-157
+ *
+ * Strictly sequential (one sample at a time, exactly like the reference's while-loop); it shares
+ * NOTHING with the HIP engine except include/lqrrt_pmath.h, the portable sin/cos/atan2, so that
+ * engine-vs-oracle comparisons can be bit-exact at any tree size (tests/test_hip_vs_coracle.py).
+ * Pinning against the reference itself: tests/test_coracle_golden.py replays tests/golden/.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off -> oracle/_build/liblqrrt_oracle.so)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/lqrrt_pmath.h"
+
+#define MAXN 12
+#define MAXM 6
+
+enum { BOAT_ADV = 1, BOAT_INT = 2, BOAT_NOV = 3, CAR = 4, PEND = 5, DINT = 6 };
+
+typedef struct {
+    int model, n, m, nw, wd[2];
+    double P[96];
+    int V, O, stride;
+    double *vps, *obs;
+    double dt, FPR, tol[MAXN], goal[MAXN], glo[MAXN], ghi[MAXN];
+    int H;
+    double centers[MAXN], spans[MAXN], bias[MAXN];
+    int tries;
+    /* MT19937 */
+    uint32_t key[624];
+    int pos;
+    /* tree */
+    int cap, N;
+    double *state, *trig, *K, *xedge, *uedge;
+    int *pid, *elen;
+    unsigned char* ign;
+    /* counters */
+    long long iterations, candidates, hits;
+    int best_end;
+    long long best_steps;
+    int *trace_near, *trace_len;
+    long long trace_cap;
+} orc;
+
+/* ------------------------------------------------------------------ MT19937 (numpy legacy) */
+static void mt_gen(orc* o) {
+    uint32_t* k = o->key;
+    int i;
+    uint32_t y;
+    for (i = 0; i < 227; ++i) { y = (k[i] & 0x80000000u) | (k[i + 1] & 0x7fffffffu); k[i] = k[i + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+    for (; i < 623; ++i) { y = (k[i] & 0x80000000u) | (k[i + 1] & 0x7fffffffu); k[i] = k[i - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); }
+    y = (k[623] & 0x80000000u) | (k[0] & 0x7fffffffu);
+    k[623] = k[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    o->pos = 0;
+}
+static uint32_t mt32(orc* o) {
+    if (o->pos >= 624) mt_gen(o);
+    uint32_t y = o->key[o->pos++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+static double mt_double(orc* o) {
+    uint32_t a = mt32(o) >> 5, b = mt32(o) >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+/* ------------------------------------------------------------------ helpers */
+static double clipd(double v, double lo, double hi) { double t = v < lo ? lo : v; return t > hi ? hi : t; }
+static double wrap_err(double cg, double sg, double c, double s) { return lq_atan2(sg * c - cg * s, cg * c + sg * s); }
+
+static void trig_of(const orc* o, const double* x, double* tr) {
+    for (int k = 0; k < o->nw; ++k) lq_sincos(x[o->wd[k]], &tr[2 * k + 1], &tr[2 * k]);
+}
+
+/* np.sum over a row: left-to-right for n<8, numpy's 8-way pairwise block otherwise */
+static double row_sum(const double* a, int n) {
+    if (n < 8) { double r = a[0]; for (int i = 1; i < n; ++i) r += a[i]; return r; }
+    double r[8];
+    for (int i = 0; i < 8; ++i) r[i] = a[i];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+/* hull vs circles (demo_boat_advanced.py:216-224; car adds the vertex 2p, demo_car.py:175) */
+static int hull_hits(const orc* o, double px, double py, double c, double s, int extra2p) {
+    const double ms = -s;
+    for (int ob = 0; ob < o->O; ++ob) {
+        const double ox = o->obs[ob * o->stride], oy = o->obs[ob * o->stride + 1], r = o->obs[ob * o->stride + 2];
+        for (int v = 0; v < o->V; ++v) {
+            const double bx = o->vps[v], by = o->vps[o->V + v];
+            const double vx = px + (c * bx + ms * by), vy = py + (s * bx + c * by);
+            const double dx = vx - ox, dy = vy - oy;
+            if (sqrt(dx * dx + dy * dy) <= r) return 1;
+        }
+        if (extra2p) {
+            const double dx = (px + px) - ox, dy = (py + py) - oy;
+            if (sqrt(dx * dx + dy * dy) <= r) return 1;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ plugins */
+static void gain(const orc* o, const double* x, const double* tr, const double* u, double* K) {
+    (void)x; (void)u;
+    const double* P = o->P;
+    const double c = tr[0], s = tr[1];
+    const double *kp = 0, *kd = 0;
+    switch (o->model) {
+        case BOAT_ADV: kp = P + 40; kd = P + 43; break;
+        case BOAT_INT: kp = P + 15; kd = P + 18; break;
+        case BOAT_NOV: kp = P + 12; kd = P + 15; break;
+        case CAR:
+            K[0] = P[9] * c; K[1] = P[9] * s; K[2] = P[9] * 0.0; K[3] = P[11]; K[4] = 0.0;
+            K[5] = P[10] * 0.0; K[6] = P[10] * 0.0; K[7] = P[10] * 1.0; K[8] = 0.0; K[9] = P[12];
+            return;
+        case PEND: K[0] = P[14]; K[1] = P[15]; K[2] = P[16]; K[3] = P[17]; return;
+        case DINT: for (int j = 0; j < 72; ++j) K[j] = P[1 + j]; return;
+    }
+    K[0] = kp[0] * c;    K[1] = kp[0] * s;    K[2] = kp[0] * 0.0;  K[3] = kd[0];  K[4] = 0.0;   K[5] = 0.0;
+    K[6] = kp[1] * (-s); K[7] = kp[1] * c;    K[8] = kp[1] * 0.0;  K[9] = 0.0;    K[10] = kd[1]; K[11] = 0.0;
+    K[12] = kp[2] * 0.0; K[13] = kp[2] * 0.0; K[14] = kp[2] * 1.0; K[15] = 0.0;   K[16] = 0.0;  K[17] = kd[2];
+}
+
+static double rudder_term(double g, const double* x, double c, double s) {
+    const double vw0 = c * x[3] + (-s) * x[4], vw1 = s * x[3] + c * x[4];
+    const double ang = lq_atan2(vw1, vw0);
+    double cg, sg;
+    lq_sincos(ang, &sg, &cg);
+    return g * wrap_err(cg, sg, c, s);
+}
+
+static void boat_euler(const double* invM, const double* Dp, const double* Dn, const double* x, double c, double s,
+                       const double* u, double dt, double* xn) {
+    double xd[6];
+    xd[0] = c * x[3] + (-s) * x[4];
+    xd[1] = s * x[3] + c * x[4];
+    xd[2] = x[5];
+    for (int i = 0; i < 3; ++i) {
+        const double v = x[3 + i];
+        const double D = (v >= 0.0) ? Dp[i] : Dn[i];
+        xd[3 + i] = invM[i] * (u[i] - D * v);
+    }
+    for (int i = 0; i < 6; ++i) xn[i] = x[i] + xd[i] * dt;
+}
+
+static void carlike(const double* x, double vp, double vn, double* xn) {
+    if (x[3] > 0.0) xn[5] = clipd(fabs(xn[3] / vp), 0.0, 1.0) * xn[5];
+    else if (x[3] < 0.0) xn[5] = clipd(fabs(xn[3] / vn), 0.0, 1.0) * xn[5];
+    if (xn[3] < 0.0) xn[3] = 0.0;
+}
+
+/* dynamics(x,u,dt); u is a scratch copy */
+static void step(const orc* o, const double* x, const double* tr, double* u, double dt, double* xn) {
+    const double* P = o->P;
+    const double c = tr[0], s = tr[1];
+    switch (o->model) {
+        case BOAT_ADV: {
+            u[2] = u[2] + rudder_term(P[37], x, c, s);
+            double t[4], us[3];
+            for (int j = 0; j < 4; ++j) {
+                double a = P[21 + 3 * j] * u[0];
+                a += P[21 + 3 * j + 1] * u[1];
+                a += P[21 + 3 * j + 2] * u[2];
+                t[j] = clipd(a, -P[33 + j], P[33 + j]);
+            }
+            for (int i = 0; i < 3; ++i) {
+                double a = P[9 + 4 * i] * t[0];
+                a += P[9 + 4 * i + 1] * t[1];
+                a += P[9 + 4 * i + 2] * t[2];
+                a += P[9 + 4 * i + 3] * t[3];
+                us[i] = a;
+            }
+            boat_euler(P, P + 3, P + 6, x, c, s, us, dt, xn);
+            carlike(x, P[38], P[39], xn);
+        } break;
+        case BOAT_INT:
+            u[2] = u[2] + rudder_term(P[12], x, c, s);
+            for (int i = 0; i < 3; ++i) if (fabs(u[i]) > P[9 + i]) u[i] = P[9 + i] * (u[i] > 0.0 ? 1.0 : -1.0);
+            boat_euler(P, P + 3, P + 6, x, c, s, u, dt, xn);
+            carlike(x, P[13], P[14], xn);
+            break;
+        case BOAT_NOV:
+            for (int i = 0; i < 3; ++i) if (fabs(u[i]) > P[9 + i]) u[i] = P[9 + i] * (u[i] > 0.0 ? 1.0 : -1.0);
+            boat_euler(P, P + 3, P + 6, x, c, s, u, dt, xn);
+            break;
+        case CAR: {
+            const double vwx = c * x[3], vwy = s * x[3];
+            const double u0 = clipd(u[0], P[4], P[6]), u1 = clipd(u[1], P[5], P[7]);
+            double xd[5] = {vwx, vwy, x[4], P[0] * (u0 - P[2] * x[3]), P[1] * (u1 - P[3] * x[4])};
+            for (int i = 0; i < 5; ++i) xn[i] = x[i] + xd[i] * dt;
+            if (xn[3] < 0.0) xn[3] = 0.0;
+            xn[4] = clipd(fabs(xn[3] / P[8]), 0.0, 1.0) * xn[4];
+        } break;
+        case PEND: {
+            const double c1 = tr[2], s1 = tr[3], c0 = tr[0];
+            const double c01 = lq_cos(x[0] + x[1]);
+            const double M00 = P[0] + P[1] * c1, M01 = P[2] + P[3] * c1, M11 = P[2];
+            const double V0 = (-P[3]) * ((2.0 * x[2]) * x[3] + x[3] * x[3]) * s1;
+            const double V1 = (P[3] * (x[2] * x[2])) * s1;
+            const double G0 = P[4] * c0 + P[5] * c01, G1 = P[5] * c01;
+            const double D0 = P[6] * x[2], D1 = P[7] * x[3];
+            const double F0 = P[8] * tanh(P[10] * x[2]), F1 = P[9] * tanh(P[11] * x[3]);
+            const double tau = clipd(u[0], -P[12], P[12]);
+            const double r0 = (((tau - V0) - G0) - D0) - F0, r1 = (((0.0 - V1) - G1) - D1) - F1;
+            const double det = M00 * M11 - M01 * M01;
+            const double a0 = (M11 * r0 - M01 * r1) / det, a1 = (M00 * r1 - M01 * r0) / det;
+            xn[0] = x[0] + x[2] * dt; xn[1] = x[1] + x[3] * dt;
+            xn[2] = x[2] + a0 * dt;   xn[3] = x[3] + a1 * dt;
+        } break;
+        case DINT: {
+            const double h = P[0];
+            for (int i = 0; i < 6; ++i) { xn[i] = x[i] + h * x[6 + i]; xn[6 + i] = x[6 + i] + h * u[i]; }
+        } break;
+    }
+}
+
+static int feasible(const orc* o, const double* x, const double* u, const double* tr) {
+    const double* P = o->P;
+    switch (o->model) {
+        case BOAT_ADV:
+            for (int i = 0; i < 3; ++i) if (x[3 + i] > P[46 + i] || x[3 + i] < P[49 + i]) return 0;
+            return !hull_hits(o, x[0], x[1], tr[0], tr[1], 0);
+        case BOAT_INT: return !hull_hits(o, x[0], x[1], tr[0], tr[1], 0);
+        case BOAT_NOV:
+            for (int ob = 0; ob < o->O; ++ob) {
+                const double dx = x[0] - o->obs[ob * o->stride], dy = x[1] - o->obs[ob * o->stride + 1];
+                if (sqrt(dx * dx + dy * dy) <= P[18] + o->obs[ob * o->stride + 2]) return 0;
+            }
+            return 1;
+        case CAR: return !hull_hits(o, x[0], x[1], tr[0], tr[1], 1);
+        case PEND: return !(fabs(u[0]) > P[13]);
+        case DINT:
+            for (int ob = 0; ob < o->O; ++ob) {
+                const double* b = o->obs + (size_t)ob * o->stride;
+                if (x[0] >= b[0] && x[0] <= b[3] && x[1] >= b[1] && x[1] <= b[4] && x[2] >= b[2] && x[2] <= b[5]) return 0;
+            }
+            return 1;
+    }
+    return 1;
+}
+
+static void erf_cached(const orc* o, const double* xg, const double* gt, const double* x, const double* tr, double* e) {
+    for (int d = 0; d < o->n; ++d) e[d] = xg[d] - x[d];
+    for (int k = 0; k < o->nw; ++k) e[o->wd[k]] = wrap_err(gt[2 * k], gt[2 * k + 1], tr[2 * k], tr[2 * k + 1]);
+}
+
+/* ------------------------------------------------------------------ API */
+orc* orc_create(int model, const double* params, int n_params, const double* vps, int V, const double* obs, int O,
+                int stride, int capacity) {
+    orc* o = (orc*)calloc(1, sizeof(orc));
+    o->model = model;
+    switch (model) {
+        case BOAT_ADV: case BOAT_INT: case BOAT_NOV: o->n = 6; o->m = 3; o->nw = 1; o->wd[0] = 2; break;
+        case CAR: o->n = 5; o->m = 2; o->nw = 1; o->wd[0] = 2; break;
+        case PEND: o->n = 4; o->m = 1; o->nw = 2; o->wd[0] = 0; o->wd[1] = 1; break;
+        case DINT: o->n = 12; o->m = 6; o->nw = 0; break;
+        default: free(o); return 0;
+    }
+    memcpy(o->P, params, sizeof(double) * n_params);
+    o->V = V; o->O = O; o->stride = stride > 0 ? stride : 3;
+    o->vps = (double*)malloc(sizeof(double) * (2 * V + 1));
+    o->obs = (double*)malloc(sizeof(double) * ((size_t)O * o->stride + 1));
+    if (V) memcpy(o->vps, vps, sizeof(double) * 2 * V);
+    if (O) memcpy(o->obs, obs, sizeof(double) * (size_t)O * o->stride);
+    o->cap = capacity;
+    o->H = 1;
+    o->pos = 624;
+    return o;
+}
+
+static void free_tree(orc* o) {
+    free(o->state); free(o->trig); free(o->K); free(o->xedge); free(o->uedge); free(o->pid); free(o->elen); free(o->ign);
+    o->state = o->trig = o->K = o->xedge = o->uedge = 0; o->pid = o->elen = 0; o->ign = 0;
+}
+
+void orc_destroy(orc* o) {
+    if (!o) return;
+    free_tree(o);
+    free(o->vps); free(o->obs); free(o->trace_near); free(o->trace_len);
+    free(o);
+}
+
+void orc_set_resolution(orc* o, double dt, double FPR, int H, const double* tol, const double* goal,
+                        const double* goal_lo, const double* goal_hi) {
+    o->dt = dt; o->FPR = FPR; o->H = H;
+    for (int d = 0; d < o->n; ++d) { o->tol[d] = tol[d]; o->goal[d] = goal[d]; o->glo[d] = goal_lo[d]; o->ghi[d] = goal_hi[d]; }
+}
+
+void orc_set_sampler(orc* o, const double* centers, const double* spans, const double* bias, int tries) {
+    for (int d = 0; d < o->n; ++d) { o->centers[d] = centers[d]; o->spans[d] = spans[d]; o->bias[d] = bias[d]; }
+    o->tries = tries;
+}
+
+void orc_set_mt19937(orc* o, const uint32_t* key, int pos) { memcpy(o->key, key, sizeof(uint32_t) * 624); o->pos = pos; }
+void orc_get_mt19937(orc* o, uint32_t* key, int* pos) { memcpy(key, o->key, sizeof(uint32_t) * 624); *pos = o->pos; }
+
+void orc_reset(orc* o, const double* x0) {
+    free_tree(o);
+    const int n = o->n, m = o->m, cap = o->cap, H = o->H;
+    o->state = (double*)malloc(sizeof(double) * (size_t)cap * n);
+    o->trig = (double*)malloc(sizeof(double) * (size_t)cap * 4);
+    o->K = (double*)malloc(sizeof(double) * (size_t)cap * m * n);
+    o->xedge = (double*)malloc(sizeof(double) * (size_t)cap * H * n);
+    o->uedge = (double*)malloc(sizeof(double) * (size_t)cap * H * m);
+    o->pid = (int*)malloc(sizeof(int) * cap);
+    o->elen = (int*)malloc(sizeof(int) * cap);
+    o->ign = (unsigned char*)calloc(cap, 1);
+    double u0[MAXM] = {0};
+    memcpy(o->state, x0, sizeof(double) * n);
+    trig_of(o, x0, o->trig);
+    gain(o, x0, o->trig, u0, o->K);
+    o->pid[0] = -1; o->elen[0] = 1;
+    memcpy(o->xedge, x0, sizeof(double) * n);
+    memset(o->uedge, 0, sizeof(double) * m);
+    o->N = 1;
+    o->iterations = o->candidates = o->hits = 0;
+    o->best_end = -1; o->best_steps = -1;
+}
+
+void orc_enable_trace(orc* o, long long cap) {
+    free(o->trace_near); free(o->trace_len);
+    o->trace_near = (int*)malloc(sizeof(int) * cap);
+    o->trace_len = (int*)malloc(sizeof(int) * cap);
+    o->trace_cap = cap;
+}
+
+/* default sampler, planner.py:201-211 */
+static void sample(orc* o, double* x) {
+    const int n = o->n;
+    double u0[MAXM] = {0}, tr[4];
+    for (int t = 0; t < o->tries; ++t) {
+        for (int d = 0; d < n; ++d) x[d] = o->centers[d] + o->spans[d] * (mt_double(o) - 0.5);
+        const double gate = mt_double(o);
+        for (int d = 0; d < n; ++d) if (o->bias[d] > gate) x[d] = o->goal[d];
+        o->candidates++;
+        trig_of(o, x, tr);
+        if (feasible(o, x, u0, tr)) return;
+    }
+}
+
+/* nearest by cost-to-go about the sample, planner.py:239-247 + 340-350 (identity or dense S) */
+static int nearest(const orc* o, const double* xs, const double* Sd, int pruning) {
+    const int n = o->n;
+    double gt[4], e[MAXN], prod[MAXN];
+    trig_of(o, xs, gt);
+    double best = INFINITY, best_all = INFINITY;
+    int bi = -1, bai = -1;
+    for (int i = 0; i < o->N; ++i) {
+        erf_cached(o, xs, gt, o->state + (size_t)i * n, o->trig + (size_t)i * 4, e);
+        if (!Sd) for (int k = 0; k < n; ++k) prod[k] = e[k] * e[k];
+        else for (int k = 0; k < n; ++k) {
+            double t = e[0] * Sd[k];
+            for (int j = 1; j < n; ++j) t += e[j] * Sd[j * n + k];
+            prod[k] = t * e[k];
+        }
+        const double c = row_sum(prod, n);
+        if (c < best_all) { best_all = c; bai = i; }
+        if (!(pruning && o->ign[i]) && c < best) { best = c; bi = i; }
+    }
+    return bi >= 0 ? bi : bai;
+}
+
+/* planner.py:354-438; returns the number of recorded steps, xs/us hold them */
+static int steer(const orc* o, int ID, const double* xt, double* xs, double* us) {
+    const int n = o->n, m = o->m;
+    double x[MAXN], K[MAXM * MAXN], tr[4], tt[4];
+    memcpy(x, o->state + (size_t)ID * n, sizeof(double) * n);
+    memcpy(tr, o->trig + (size_t)ID * 4, sizeof(double) * 4);
+    memcpy(K, o->K + (size_t)ID * m * n, sizeof(double) * m * n);
+    trig_of(o, xt, tt);
+    int cnt = 0, steps = 0;
+    for (;;) {
+        double e[MAXN], u[MAXM], uc[MAXM], xn[MAXN], trn[4];
+        erf_cached(o, xt, tt, x, tr, e);
+        for (int i = 0; i < m; ++i) {
+            double a = K[i * n] * e[0];
+            for (int j = 1; j < n; ++j) a += K[i * n + j] * e[j];
+            u[i] = a; uc[i] = a;
+        }
+        step(o, x, tr, uc, o->dt, xn);
+        trig_of(o, xn, trn);
+        if (!feasible(o, xn, u, trn)) { cnt = (int)(o->FPR * (double)cnt); break; }
+        ++steps;
+        int conv = 1;
+        for (int d = 0; d < n; ++d) conv = conv && (fabs(e[d]) <= o->tol[d]);
+        if (steps > o->H || conv) break;
+        memcpy(xs + (size_t)cnt * n, xn, sizeof(double) * n);
+        memcpy(us + (size_t)cnt * m, u, sizeof(double) * m);
+        ++cnt;
+        memcpy(x, xn, sizeof(double) * n);
+        memcpy(tr, trn, sizeof(double) * 4);
+        gain(o, x, tr, u, K);
+    }
+    return cnt;
+}
+
+/*
+ * The loop of planner.py:233-290.  Stops when `max_iters` more iterations ran (<0: unlimited),
+ * when tree.size > max_nodes (planner.py:311), or -- stop_on_goal -- right after an iteration
+ * that produced a goal hit (planner.py:293 with min_time already elapsed).
+ * Returns the stop reason: 1 iterations, 2 nodes, 4 goal.
+ */
+int orc_extend(orc* o, long long max_iters, long long max_nodes, int pruning, int stop_on_goal, const double* Sd) {
+    const int n = o->n, m = o->m, H = o->H;
+    double xs[MAXN];
+    double* ex = (double*)malloc(sizeof(double) * (size_t)(H + 1) * n);
+    double* eu = (double*)malloc(sizeof(double) * (size_t)(H + 1) * m);
+    long long done = 0;
+    int reason = 1;
+    for (;;) {
+        if (max_iters >= 0 && done >= max_iters) { reason = 1; break; }
+        if (max_nodes >= 0 && o->N > max_nodes) { reason = 2; break; }
+        if (o->N + 1 >= o->cap) { reason = 2; break; }
+        sample(o, xs);
+        const int near = nearest(o, xs, Sd, pruning);
+        const int len = steer(o, near, xs, ex, eu);
+        if (o->trace_near && o->iterations < o->trace_cap) { o->trace_near[o->iterations] = near; o->trace_len[o->iterations] = len; }
+        o->iterations++;
+        ++done;
+        if (len > 0) {
+            const int id = o->N;
+            const double* xe = ex + (size_t)(len - 1) * n;
+            memcpy(o->state + (size_t)id * n, xe, sizeof(double) * n);
+            trig_of(o, xe, o->trig + (size_t)id * 4);
+            gain(o, xe, o->trig + (size_t)id * 4, eu + (size_t)(len - 1) * m, o->K + (size_t)id * m * n);
+            o->pid[id] = near; o->elen[id] = len;
+            memcpy(o->xedge + (size_t)id * H * n, ex, sizeof(double) * len * n);
+            memcpy(o->uedge + (size_t)id * H * m, eu, sizeof(double) * len * m);
+            o->N++;
+            int in = 1;
+            for (int d = 0; d < n; ++d) in = in && (o->glo[d] < xe[d]) && (xe[d] < o->ghi[d]);
+            if (in) {
+                long long steps = 0;
+                for (int v = id; v != -1; v = o->pid[v]) { steps += o->elen[v]; if (pruning) o->ign[v] = 1; }
+                o->hits++;
+                if (o->best_end < 0 || steps < o->best_steps) { o->best_end = id; o->best_steps = steps; }
+                if (stop_on_goal) { reason = 4; break; }
+            }
+        }
+    }
+    free(ex); free(eu);
+    return reason;
+}
+
+/* guide search of planner.py:311-318: argmin over ALL nodes with a dense S */
+int orc_nearest(orc* o, const double* x, const double* Sd, int pruning) { return nearest(o, x, Sd, pruning); }
+
+int orc_size(const orc* o) { return o->N; }
+long long orc_iterations(const orc* o) { return o->iterations; }
+long long orc_candidates(const orc* o) { return o->candidates; }
+long long orc_hits(const orc* o) { return o->hits; }
+int orc_best_end(const orc* o) { return o->best_end; }
+long long orc_best_steps(const orc* o) { return o->best_steps; }
+void orc_get_states(const orc* o, double* out) { memcpy(out, o->state, sizeof(double) * (size_t)o->N * o->n); }
+void orc_get_gains(const orc* o, double* out) { memcpy(out, o->K, sizeof(double) * (size_t)o->N * o->m * o->n); }
+void orc_get_parents(const orc* o, int* out) { memcpy(out, o->pid, sizeof(int) * o->N); }
+void orc_get_edge_lengths(const orc* o, int* out) { memcpy(out, o->elen, sizeof(int) * o->N); }
+void orc_get_ignored(const orc* o, unsigned char* out) { memcpy(out, o->ign, o->N); }
+int orc_get_edge(const orc* o, int id, double* x, double* u) {
+    const int len = o->elen[id];
+    memcpy(x, o->xedge + (size_t)id * o->H * o->n, sizeof(double) * len * o->n);
+    memcpy(u, o->uedge + (size_t)id * o->H * o->m, sizeof(double) * len * o->m);
+    return len;
+}
+void orc_get_trace(const orc* o, int* near, int* len, long long count) {
+    memcpy(near, o->trace_near, sizeof(int) * count);
+    memcpy(len, o->trace_len, sizeof(int) * count);
+}
+/* single-call operators for tests */
+void orc_dynamics(const orc* o, const double* x, const double* u, double* xn) {
+    double tr[4], uc[MAXM];
+    memcpy(uc, u, sizeof(double) * o->m);
+    trig_of(o, x, tr);
+    step(o, x, tr, uc, o->dt, xn);
+}
+int orc_feasible(const orc* o, const double* x, const double* u) { double tr[4]; trig_of(o, x, tr); return feasible(o, x, u, tr); }
+void orc_gain(const orc* o, const double* x, const double* u, double* K) { double tr[4]; trig_of(o, x, tr); gain(o, x, tr, u, K); }
+void orc_erf(const orc* o, const double* xg, const double* x, double* e) {
+    double gt[4], tr[4];
+    trig_of(o, xg, gt); trig_of(o, x, tr);
+    erf_cached(o, xg, gt, x, tr, e);
+}

@@ -1,0 +1,91 @@
+"""
+GPU: the wave-parallel HIP engine against the sequential C oracle, BIT FOR BIT.
+
+Both sides evaluate the same IEEE operations in the same order (elementary functions from
+include/lqrrt_pmath.h), so the bar here is equality, not a tolerance: parent ids, edge lengths,
+ignore sets, iteration and sampler-row counts, node states, gains and edges must be identical for
+any wave size and at the benchmark's full size.  This is the proof that exact mode == the
+reference's sequential semantics, independent of the ulp-level chaos of the boat dynamics.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_run(name, max_nodes, wave, seed=1, pruning=True, stop_on_goal=False, **sys_kw):
+    import lqrrt_amd
+    from lqrrt_amd.engine import Engine
+    s = lqrrt_amd.systems.SYSTEMS[name](0, **sys_kw) if not sys_kw else lqrrt_amd.systems.SYSTEMS[name](**sys_kw)
+    eng = Engine(s, capacity=max_nodes + wave + 8, max_wave=wave)
+    kw = s.plan_kwargs
+    eng.set_resolution(kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer))
+    space = np.array(s.sample_space, dtype=np.float64)
+    eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), np.array(s.goal_bias, dtype=np.float64), 10)
+    st = np.random.RandomState(seed).get_state()
+    eng.set_mt19937(st[1], st[2])
+    eng.tree_reset(s.x0)
+    stats = eng.extend(wave, node_limit=max_nodes, pruning=pruning, stop_on_goal=stop_on_goal)
+    return s, eng, stats
+
+
+def _compare(eng, stats, o):
+    assert eng.size == o.size
+    assert stats.attempts == o.iterations
+    assert stats.candidates == o.candidates
+    np.testing.assert_array_equal(eng.parents(), o.parents())
+    np.testing.assert_array_equal(eng.edge_lengths(), o.edge_lengths())
+    np.testing.assert_array_equal(eng.ignored(), o.ignored())
+    np.testing.assert_array_equal(eng.states(), o.states())          # bit-exact
+    np.testing.assert_array_equal(eng.gains(), o.gains())
+    for ID in (0, 1, eng.size // 3, eng.size // 2, eng.size - 1):
+        ex, eu = eng.edge(ID)
+        ox, ou = o.edge(ID)
+        np.testing.assert_array_equal(ex, ox)
+        np.testing.assert_array_equal(eu, ou)
+    end, steps, hits = eng.plan_best()
+    assert hits == o.hits
+    assert (end, steps) == o.best()
+
+
+CASES = [("boat_advanced", 300, 16), ("boat_advanced", 300, 1024), ("boat_advanced", 3000, 1024),
+         ("boat_intermediate", 600, 256), ("boat_novice", 600, 512), ("car", 1500, 1024), ("pendulum", 300, 128)]
+
+
+@pytest.mark.parametrize("name,nodes,wave", CASES)
+def test_bit_exact_vs_sequential_oracle(name, nodes, wave):
+    import coracle
+    s, eng, stats = _engine_run(name, nodes, wave)
+    o = coracle.make(s, nodes + wave + 8, seed=1)
+    assert o.extend(max_nodes=nodes) == 2
+    if name == "pendulum":
+        # tanh comes from each side's libm (not in lqrrt_pmath.h): compare at 1e-12 instead
+        np.testing.assert_array_equal(eng.parents(), o.parents())
+        np.testing.assert_allclose(eng.states(), o.states(), rtol=0, atol=1e-12)
+        return
+    _compare(eng, stats, o)
+
+
+def test_bit_exact_headline_config_10k():
+    """BASELINE.json's metric configuration: demo_boat_advanced grown to 10k nodes (goal reached,
+    ignore set active), W = 1024."""
+    import coracle
+    s, eng, stats = _engine_run("boat_advanced", 10000, 1024)
+    o = coracle.make(s, 10000 + 1024 + 8, seed=1)
+    assert o.extend(max_nodes=10000) == 2
+    assert o.hits > 0
+    _compare(eng, stats, o)
+
+
+def test_bit_exact_other_seeds_and_modes():
+    import coracle
+    for seed, pruning in ((5, True), (6, False)):
+        s, eng, stats = _engine_run("car", 800, 256, seed=seed, pruning=pruning)
+        o = coracle.make(s, 800 + 256 + 8, seed=seed)
+        o.extend(max_nodes=800, pruning=pruning)
+        _compare(eng, stats, o)
+    # stop at the first goal hit (planner.py:293 with min_time = 0)
+    s, eng, stats = _engine_run("boat_novice", 5000, 512, seed=2, stop_on_goal=True)
+    o = coracle.make(s, 5000 + 512 + 8, seed=2)
+    assert o.extend(max_nodes=5000, stop_on_goal=True) == 4
+    _compare(eng, stats, o)
