@@ -628,6 +628,7 @@ static int flush_ignore(lqrrt_engine* e, hipStream_t st) {
 // batched operators
 
 extern "C" int lqrrt_feasible_batch(lqrrt_engine* e, const double* x, const double* u, int B, uint8_t* ok, void* stream) {
+    if (e && B == 0) return 0;
     if (!e || !x || !ok || B < 0) return fail(LQRRT_E_ARG, "bad argument");
     if (!B) return 0;
     TRY(use_device(e));
@@ -637,6 +638,7 @@ extern "C" int lqrrt_feasible_batch(lqrrt_engine* e, const double* x, const doub
 }
 
 extern "C" int lqrrt_dynamics_batch(lqrrt_engine* e, const double* x, const double* u, int B, double* xn, void* stream) {
+    if (e && B == 0) return 0;
     if (!e || !x || !u || !xn || B < 0) return fail(LQRRT_E_ARG, "bad argument");
     if (!e->has_res) return fail(LQRRT_E_STATE, "set_resolution first (dt)");
     if (!B) return 0;
@@ -647,6 +649,7 @@ extern "C" int lqrrt_dynamics_batch(lqrrt_engine* e, const double* x, const doub
 }
 
 extern "C" int lqrrt_gain_batch(lqrrt_engine* e, const double* x, const double* u, int B, double* K, void* stream) {
+    if (e && B == 0) return 0;
     if (!e || !x || !K || B < 0) return fail(LQRRT_E_ARG, "bad argument");
     if (!B) return 0;
     TRY(use_device(e));
@@ -656,6 +659,7 @@ extern "C" int lqrrt_gain_batch(lqrrt_engine* e, const double* x, const double* 
 }
 
 extern "C" int lqrrt_erf_batch(lqrrt_engine* e, const double* xg, const double* x, int B, double* eo, void* stream) {
+    if (e && B == 0) return 0;
     if (!e || !xg || !x || !eo || B < 0) return fail(LQRRT_E_ARG, "bad argument");
     if (!B) return 0;
     TRY(use_device(e));
