@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -103,6 +104,7 @@ struct lqrrt_engine {
     double goal[MAXN];
     double* d_vps = nullptr;
     double* d_obs = nullptr;
+    double* d_oc = nullptr;       // derived circle table [O][4]
     double* d_S = nullptr;        // dense system S (n x n) or null = identity
 
     // tree
@@ -128,7 +130,7 @@ struct lqrrt_engine {
     int *d_par_done = nullptr, *d_par_want = nullptr, *d_list = nullptr, *d_rank = nullptr;
     unsigned char *d_changed = nullptr, *d_stale = nullptr, *d_need = nullptr;
     unsigned long long* d_wmask = nullptr;
-    int* d_summary = nullptr;     // [2 + 3*maxW]
+    int* d_summary = nullptr;     // [4 + 3*maxW]: ctrl (listed, deferred, horizon, -) + len/flags/parent
     int* h_summary = nullptr;     // pinned
     int* h_rank = nullptr;        // pinned
     static constexpr int MAXCH = 256;
@@ -175,6 +177,19 @@ struct lqrrt_engine {
         default: return fail(LQRRT_E_ARG, "unknown model %d", (e)->model);                        \
     }
 
+// Largest T with fl(sqrt(T)) <= r: `d2 <= T` is then exactly `sqrt(d2) <= r` (sqrt is monotone and
+// correctly rounded), which removes the square root from the collision sweep without changing a bit.
+static double exact_sq_threshold(double r) {
+    if (!(r >= 0.0)) return -1.0;
+    if (std::isinf(r)) return r;
+    double T = r * r;
+    while (std::sqrt(std::nextafter(T, INFINITY)) <= r) T = std::nextafter(T, INFINITY);
+    while (T > 0.0 && std::sqrt(T) > r) T = std::nextafter(T, -INFINITY);
+    return T;
+}
+
+static size_t geo_lds_bytes(const lqrrt_engine* e);
+
 static bool model_dims(int model, int* n, int* m, int* nw) {
     switch (model) {
         case LQRRT_MODEL_BOAT_ADVANCED:
@@ -185,6 +200,10 @@ static bool model_dims(int model, int* n, int* m, int* nw) {
         case LQRRT_MODEL_DOUBLE_INTEGRATOR: *n = 12; *m = 6; *nw = 0; return true;
     }
     return false;
+}
+
+static size_t geo_lds_bytes(const lqrrt_engine* e) {
+    return e->geo.oc ? sizeof(double) * ((size_t)2 * e->geo.V + (size_t)4 * e->geo.O) : 0;
 }
 
 static int use_device(lqrrt_engine* e) {
@@ -205,6 +224,7 @@ static NodeView tree_view(const lqrrt_engine* e, bool use_ignore) {
     v.x = e->tv.state; v.trig = e->tv.trig;
     v.sn = 1; v.sd = e->cap; v.tn = 1; v.td = e->cap;
     v.ignore = use_ignore ? e->tv.ignore : nullptr;
+    v.len = nullptr;
     v.count = e->N; v.pad = 0;
     return v;
 }
@@ -213,7 +233,8 @@ static NodeView record_view(const lqrrt_engine* e, int W) {
     NodeView v;
     v.x = e->d_rec + e->L.off_xend; v.trig = e->d_rec + e->L.off_trig;
     v.sn = e->L.R; v.sd = 1; v.tn = e->L.R; v.td = 1;
-    v.ignore = e->d_wmask;
+    v.ignore = nullptr;
+    v.len = e->d_rec + e->L.off_len;
     v.count = W; v.pad = 0;
     return v;
 }
@@ -262,10 +283,12 @@ static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
 // NN over a node table for W samples at xs (device, [W][n]); writes id/cost and/or records.
 static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int W, const double* Sd,
                      bool tri, bool want_all, int* out_id, double* out_cost, double* rec, hipStream_t st,
-                     bool profile) {
+                     bool profile, int* n_chunks_out = nullptr) {
     if (W <= 0) return 0;
     int chunk, n_chunks;
-    pick_chunks(nv.count, W, &chunk, &n_chunks);
+    if (tri) { chunk = 64; n_chunks = (nv.count + 63) / 64; }   // in-wave pass: the reduction is fused into k_decide
+    else pick_chunks(nv.count, W, &chunk, &n_chunks);
+    if (n_chunks_out) *n_chunks_out = n_chunks;
     dim3 grid((W + 63) / 64, n_chunks);
     const double* S_use = Sd ? Sd : e->d_S;
     double* pca = want_all ? e->d_pcost_all : nullptr;
@@ -282,6 +305,7 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     }
 #undef NN_LAUNCH
     if (profile) prof_end(e, st, &ev, 0, (double)W * (double)nv.count * (8.0 * e->n + 1.0));
+    if (tri) { HIPCHK(hipGetLastError()); return 0; }
     hipLaunchKernelGGL(k_nn_reduce, dim3((W + 255) / 256), dim3(256), 0, st, e->d_pcost, e->d_pidx, pca, pia, W,
                        n_chunks, out_id, out_cost, rec, e->L.R, e->L.off_cost, e->L.off_parent);
     HIPCHK(hipGetLastError());
@@ -291,7 +315,7 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
 static int launch_steer(lqrrt_engine* e, const double* xs, const int* list, int lo, int count,
                         const int* par, hipStream_t st) {
     if (count <= 0) return 0;
-    const size_t lds = (size_t)e->H * (e->n + e->m) * sizeof(double);
+    const size_t lds = (size_t)e->H * (e->n + e->m) * sizeof(double) + geo_lds_bytes(e);
     EvPair ev;
     prof_begin(e, st, &ev);
     DISPATCH(e, hipLaunchKernelGGL((k_steer<S>), dim3(count), dim3(64), lds, st, e->P, e->geo, e->res, e->tv,
@@ -314,7 +338,7 @@ extern "C" int lqrrt_device_count(void) {
 }
 
 static void free_all(lqrrt_engine* e) {
-    void* ptrs[] = {e->d_vps, e->d_obs, e->d_S, e->tv.state, e->tv.trig, e->tv.K, e->tv.pID, e->tv.elen,
+    void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_S, e->tv.state, e->tv.trig, e->tv.K, e->tv.pID, e->tv.elen,
                     e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_pcost_all, e->d_wcost,
                     e->d_pidx, e->d_pidx_all, e->d_wid, e->d_par_done, e->d_par_want, e->d_list, e->d_rank,
                     e->d_changed, e->d_stale, e->d_need, e->d_wmask, e->d_summary, e->d_pool, e->d_cand, e->d_flags};
@@ -377,7 +401,24 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     }
     rc = up(&e->d_vps, sys->vps, (size_t)2 * sys->n_vertices);
     if (!rc) rc = up(&e->d_obs, sys->obs, (size_t)sys->n_obstacles * e->geo.stride);
-    e->geo.vps = e->d_vps; e->geo.obs = e->d_obs;
+    e->geo.vps = e->d_vps; e->geo.obs = e->d_obs; e->geo.oc = nullptr;
+    if (!rc && e->geo.stride == 3) {
+        // exact square-root-free collision thresholds + conservative reach radii (see systems.hpp Geo)
+        double hull_r = 0.0;
+        for (int v = 0; v < sys->n_vertices; ++v)
+            hull_r = std::max(hull_r, std::sqrt(sys->vps[v] * sys->vps[v] + sys->vps[sys->n_vertices + v] * sys->vps[sys->n_vertices + v]));
+        const double inflate = (sys->model == LQRRT_MODEL_BOAT_NOVICE) ? sys->params[18] : 0.0;
+        std::vector<double> oc((size_t)4 * sys->n_obstacles + 4);
+        for (int o = 0; o < sys->n_obstacles; ++o) {
+            const double r = (sys->model == LQRRT_MODEL_BOAT_NOVICE) ? inflate + sys->obs[3 * o + 2] : sys->obs[3 * o + 2];
+            oc[4 * o] = sys->obs[3 * o]; oc[4 * o + 1] = sys->obs[3 * o + 1];
+            oc[4 * o + 2] = exact_sq_threshold(r);
+            const double reach = (r + hull_r) * (1.0 + 1e-9) + 1e-9;
+            oc[4 * o + 3] = (r >= 0.0) ? reach * reach : -1.0;
+        }
+        rc = up(&e->d_oc, oc.data(), (size_t)4 * sys->n_obstacles);
+        e->geo.oc = e->d_oc;
+    }
     e->tv.cap = e->cap;
     if (!rc) rc = dalloc(&e->tv.state, (size_t)n * e->cap);
     if (!rc) rc = dalloc(&e->tv.trig, (size_t)(2 * nw + 1) * e->cap);
@@ -400,8 +441,8 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     if (!rc) rc = dalloc(&e->d_stale, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_need, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_wmask, (size_t)e->maxW / 64 + 1);
-    if (!rc) rc = dalloc(&e->d_summary, (size_t)2 + 3 * e->maxW);
-    if (!rc && hipHostMalloc((void**)&e->h_summary, sizeof(int) * (2 + 3 * (size_t)e->maxW)) != hipSuccess)
+    if (!rc) rc = dalloc(&e->d_summary, (size_t)4 + 3 * e->maxW);
+    if (!rc && hipHostMalloc((void**)&e->h_summary, sizeof(int) * (4 + 3 * (size_t)e->maxW)) != hipSuccess)
         rc = fail(LQRRT_E_HIP, "hipHostMalloc failed");
     if (!rc && hipHostMalloc((void**)&e->h_rank, sizeof(int) * (size_t)e->maxW) != hipSuccess)
         rc = fail(LQRRT_E_HIP, "hipHostMalloc failed");
@@ -632,7 +673,7 @@ extern "C" int lqrrt_feasible_batch(lqrrt_engine* e, const double* x, const doub
     if (!e || !x || !ok || B < 0) return fail(LQRRT_E_ARG, "bad argument");
     if (!B) return 0;
     TRY(use_device(e));
-    DISPATCH(e, hipLaunchKernelGGL((k_feasible_batch<S>), dim3(B), dim3(64), 0, (hipStream_t)stream, e->P, e->geo, x, u, B, ok));
+    DISPATCH(e, hipLaunchKernelGGL((k_feasible_batch<S>), dim3(B), dim3(64), geo_lds_bytes(e), (hipStream_t)stream, e->P, e->geo, x, u, B, ok));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -760,7 +801,7 @@ static int ensure_samples(lqrrt_engine* e, int64_t need_end, hipStream_t st) {
                 if (e->smp.goal_bias[d] > gate) c[d] = e->goal[d];
         }
         HIPCHK(hipMemcpyAsync(e->d_cand, cand.data(), sizeof(double) * CH * n, hipMemcpyHostToDevice, st));
-        DISPATCH(e, hipLaunchKernelGGL((k_feasible_batch<S>), dim3(CH), dim3(64), 0, st, e->P, e->geo, e->d_cand, nullptr, CH, e->d_flags));
+        DISPATCH(e, hipLaunchKernelGGL((k_feasible_batch<S>), dim3(CH), dim3(64), geo_lds_bytes(e), st, e->P, e->geo, e->d_cand, nullptr, CH, e->d_flags));
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(flags.data(), e->d_flags, CH, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -868,20 +909,21 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     const int guard = 4 * W + 8;
     int rounds = 0;
     while (true) {
+        int n_chunks = 1;
         if (W > 1) {
-            hipLaunchKernelGGL(k_mask_from_records, dim3((W + 255) / 256), dim3(256), 0, st, e->d_rec, e->L, W, e->d_wmask);
-            TRY(launch_nn(e, record_view(e, W), xs, W, nullptr, true, false, e->d_wid, e->d_wcost, nullptr, st, false));
+            TRY(launch_nn(e, record_view(e, W), xs, W, nullptr, true, false, nullptr, nullptr, nullptr, st, false, &n_chunks));
         } else {
-            HIPCHK(hipMemsetAsync(e->d_wid, 0xff, sizeof(int), st));
+            HIPCHK(hipMemsetAsync(e->d_pidx, 0xff, sizeof(int), st));        // no in-wave candidate
+            HIPCHK(hipMemsetAsync(e->d_pcost, 0x7f, sizeof(double), st));    // large finite cost
         }
-        hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, st, e->d_rec, e->L, W, e->d_wid, e->d_wcost, e->d_par_done,
-                           e->d_par_want, e->d_changed, e->d_stale, e->d_need, e->d_list, e->d_summary);
-        hipLaunchKernelGGL(k_summary, dim3((W + 255) / 256), dim3(256), 0, st, e->d_rec, e->L, W, e->d_par_done, e->d_summary + 2);
+        hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, st, e->d_rec, e->L, W, e->d_pcost, e->d_pidx, n_chunks,
+                           e->d_par_done, e->d_par_want, e->d_changed, e->d_stale, e->d_need, e->d_list, e->d_summary,
+                           e->d_summary + 4);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(e->h_summary, e->d_summary, sizeof(int) * (2 + 3 * (size_t)W), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(e->h_summary, e->d_summary, sizeof(int) * (4 + 3 * (size_t)W), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         const int n_list = e->h_summary[0], n_defer = e->h_summary[1];
-        if (getenv("LQRRT_TRACE")) fprintf(stderr, "[wave N=%d W=%d] round %d: list=%d defer=%d\n", e->N, W, rounds, n_list, n_defer);
+        if (getenv("LQRRT_TRACE")) fprintf(stderr, "[wave N=%d W=%d] round %d: list=%d defer=%d horizon=%d\n", e->N, W, rounds, n_list, n_defer, e->h_summary[2]);
         if (n_list == 0 && n_defer == 0) break;
         if (n_list == 0) return fail(LQRRT_E_STATE, "exact-mode repair made no progress (deferred=%d)", n_defer);
         TRY(launch_steer(e, xs, e->d_list, 0, n_list, e->d_par_done, st));
@@ -891,9 +933,9 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     }
 
     // commit prefix: stop after the first goal hit, the node limit, or max_commit attempts
-    const int* len = e->h_summary + 2;
-    const int* flg = e->h_summary + 2 + W;
-    const int* par = e->h_summary + 2 + 2 * W;
+    const int* len = e->h_summary + 4;
+    const int* flg = e->h_summary + 4 + W;
+    const int* par = e->h_summary + 4 + 2 * W;
     int C = 0, acc = 0;
     bool hit = false;
     const int64_t room = node_limit + 1 - (int64_t)e->N;   // nodes that may still be added (size > max_nodes stops)

@@ -6,7 +6,7 @@
 //   k_steer                  <- Planner._steer(force_arrive=False)        planner.py:354-438
 //   k_feasible_batch         <- Constraints.is_feasible                   constraints.py:53-61
 //   k_tree_root / k_append   <- Tree.__init__ / Tree.add_node             tree.py:50-96
-//   k_mask_from_records, k_decide, k_rank  (build-only: exact-mode wave validation)
+//   k_decide                 (build-only: exact-mode wave validation, see engine.hip)
 //
 // Execution model choices (MI355X):
 //   * NN scan: one lane = one sample, the node loop index is wave-uniform so node data comes
@@ -37,6 +37,7 @@ struct NodeView {
     const double* trig;     // trig entry j of node i at trig[i*tn + j*td]
     long long sn, sd, tn, td;
     const unsigned long long* ignore;   // bit i set -> node i not eligible (may be null)
+    const double* len;      // in-wave pass: node i eligible iff len[i*sn] > 0 (record field), else null
     int count, pad;
 };
 
@@ -143,7 +144,9 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
         for (int j = 0; j < 2 * S::NW; ++j) trig[j] = nv.trig[(long long)i * nv.tn + j * nv.td];
         erf_cached<S>(xg, gtrig, x, trig, e);
         const double c = quad_cost<S, DENSE>(e, Sd);
-        const bool ign = nv.ignore ? ((nv.ignore[i >> 6] >> (i & 63)) & 1ull) != 0 : false;
+        bool ign;
+        if constexpr (TRI) ign = !(nv.len[(long long)i * nv.sn] > 0.0);
+        else ign = nv.ignore ? ((nv.ignore[i >> 6] >> (i & 63)) & 1ull) != 0 : false;
         const bool ok = TRI ? (i < t) : true;
         if (ok && c < best_all) { best_all = c; bidx_all = i; }
         if (ok && !ign && c < best) { best = c; bidx = i; }
@@ -207,15 +210,18 @@ template <class S>
 __global__ __launch_bounds__(64) void k_feasible_batch(Params P, Geo g, const double* __restrict__ x,
                                                        const double* __restrict__ u, int B,
                                                        unsigned char* __restrict__ ok) {
+    extern __shared__ double geo_lds[];
     const int b = blockIdx.x;                 // one wavefront per item
     if (b >= B) return;
+    const GeoL gl = stage_geo(g, geo_lds, threadIdx.x, 64);
+    __syncthreads();
     double xs[S::N], us[S::M], trig[2 * S::NW + 1];
 #pragma unroll
     for (int d = 0; d < S::N; ++d) xs[d] = x[(size_t)b * S::N + d];
 #pragma unroll
     for (int j = 0; j < S::M; ++j) us[j] = u ? u[(size_t)b * S::M + j] : 0.0;
     trig_of<S>(xs, trig);
-    const bool f = S::feasible(P.p, g, xs, us, trig, threadIdx.x);
+    const bool f = S::feasible(P.p, g, gl, xs, us, trig, threadIdx.x);
     if (threadIdx.x == 0) ok[b] = f ? 1 : 0;
 }
 
@@ -280,6 +286,8 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
     double* hx = hist;
     double* hu = hist + (size_t)r.H * S::N;
     const int lane = threadIdx.x;
+    const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
+    __syncthreads();
     const int t = list ? list[blockIdx.x] : lo + (int)blockIdx.x;
     const int pref = par[t];
     double* my = rec + (size_t)t * L.R;
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         }
         S::step(P.p, x, trig, uc, r.dt, xn);                     // planner.py:390 (dynamics gets copies)
         trig_of<S>(xn, trn);
-        if (!S::feasible(P.p, g, xn, u, trn, lane)) {            // planner.py:393-396
+        if (!S::feasible(P.p, g, gl, xn, u, trn, lane)) {        // planner.py:393-396
             cnt = (int)(r.FPR * (double)cnt);
             break;
         }
@@ -403,37 +411,48 @@ __global__ void k_tree_root(Params P, TreeView tv, const double* __restrict__ x0
     for (int j = 0; j < S::M; ++j) tv.uedge[j] = 0.0;
 }
 
-// bit s of mask = 1 when sample s produced no node (len == 0) -> not a candidate parent.
-__global__ void k_mask_from_records(const double* __restrict__ rec, RecLayout L, int W,
-                                    unsigned long long* __restrict__ mask) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool dead = (t < W) ? (rec[(size_t)t * L.R + L.off_len] <= 0.0) : true;
-    const unsigned long long b = __ballot(dead);
-    if ((threadIdx.x & 63) == 0 && (t >> 6) < ((W + 63) >> 6)) mask[t >> 6] = b;
-}
-
-// Exact-mode decision step (single workgroup, strided over the wave).  For every sample:
-//   want = in-wave winner s (if its cost beats the snapshot cost strictly) else snapshot parent;
-//   redo when want differs from the parent the record was computed with, when that in-wave
-//   parent was itself recomputed last round, or when a redo was deferred.
-// A redo whose in-wave parent is also redone this round is deferred (its start state is
-// about to change).  Outputs: list of samples to re-steer now, counts[0]=listed, counts[1]=deferred.
+// Exact-mode decision step (single workgroup, strided over the wave); fuses the reduction of the
+// in-wave scan partials, the decision and the host summary.
+//   horizon L  = first sample whose CURRENT record is an accepted goal hit (or W-1): samples after
+//                L cannot be committed by this wave (the wave is cut at the first goal hit because
+//                the ignore set changes there, planner.py:270), so they are left alone;
+//   want       = in-wave winner s (strictly cheaper than the snapshot parent) else snapshot parent;
+//   redo when want differs from the parent the record was computed with, when that in-wave parent
+//   was itself recomputed last round, or when a redo was deferred.  A redo whose in-wave parent is
+//   also redone this round is deferred (its start state is about to change).
+// ctrl[0]=listed, ctrl[1]=deferred, ctrl[2]=L; summary[0..3W) = len, flags, parent per sample.
 __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ rec, RecLayout L, int W,
-                                                 const int* __restrict__ win_id, const double* __restrict__ win_cost,
+                                                 const double* __restrict__ pcost, const int* __restrict__ pidx, int n_chunks,
                                                  int* __restrict__ par_done, int* __restrict__ par_want,
                                                  unsigned char* __restrict__ changed, unsigned char* __restrict__ stale,
                                                  unsigned char* __restrict__ need, int* __restrict__ list,
-                                                 int* __restrict__ counts) {
-    __shared__ int n_list, n_defer;
-    if (threadIdx.x == 0) { n_list = 0; n_defer = 0; }
+                                                 int* __restrict__ ctrl, int* __restrict__ summary) {
+    __shared__ int n_list, n_defer, horizon;
+    if (threadIdx.x == 0) { n_list = 0; n_defer = 0; horizon = W - 1; }
     __syncthreads();
     for (int t = threadIdx.x; t < W; t += blockDim.x) {
-        const double csnap = rec[(size_t)t * L.R + L.off_cost];
-        const int psnap = (int)rec[(size_t)t * L.R + L.off_parent];
-        const int s = win_id[t];
-        const int want = (s >= 0 && win_cost[t] < csnap) ? ~s : psnap;
-        bool nd = (want != par_done[t]) || (stale[t] != 0);
-        if (want < 0 && changed[~want]) nd = true;
+        const int len = (int)rec[(size_t)t * L.R + L.off_len];
+        const int flg = (int)rec[(size_t)t * L.R + L.off_flags];
+        if (len > 0 && (flg & 1)) atomicMin(&horizon, t);
+    }
+    __syncthreads();
+    const int hz = horizon;
+    for (int t = threadIdx.x; t < W; t += blockDim.x) {
+        bool nd = false;
+        int want = par_done[t];
+        if (t <= hz) {
+            double wc = INFINITY;
+            int s = -1;
+            for (int c = 0; c < n_chunks; ++c) {            // ascending chunks + strict '<' = lowest id on ties
+                const double v = pcost[(size_t)c * W + t];
+                if (v < wc) { wc = v; s = pidx[(size_t)c * W + t]; }
+            }
+            const double csnap = rec[(size_t)t * L.R + L.off_cost];
+            const int psnap = (int)rec[(size_t)t * L.R + L.off_parent];
+            want = (s >= 0 && wc < csnap) ? ~s : psnap;
+            nd = (want != par_done[t]) || (stale[t] != 0);
+            if (want < 0 && changed[~want]) nd = true;
+        }
         par_want[t] = want;
         need[t] = nd ? 1 : 0;
     }
@@ -453,19 +472,12 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ rec,
             }
         }
         changed[t] = ch;
+        summary[t] = (int)rec[(size_t)t * L.R + L.off_len];
+        summary[W + t] = (int)rec[(size_t)t * L.R + L.off_flags];
     }
     __syncthreads();
-    if (threadIdx.x == 0) { counts[0] = n_list; counts[1] = n_defer; }
-}
-
-// Summary for the host after convergence: len, flags and parent of every sample (int32 x3 x W).
-__global__ void k_summary(const double* __restrict__ rec, RecLayout L, int W, const int* __restrict__ par_done,
-                          int* __restrict__ out) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= W) return;
-    out[t] = (int)rec[(size_t)t * L.R + L.off_len];
-    out[W + t] = (int)rec[(size_t)t * L.R + L.off_flags];
-    out[2 * W + t] = par_done[t];
+    for (int t = threadIdx.x; t < W; t += blockDim.x) summary[2 * W + t] = par_done[t];
+    if (threadIdx.x == 0) { ctrl[0] = n_list; ctrl[1] = n_defer; ctrl[2] = hz; }
 }
 
 // Append the first C samples' accepted records to the tree (tree.py:77-96).  rank[t] = number of

@@ -14,7 +14,7 @@
 //   S::NW, S::wd(k)       number and index of angular (wrapped) states
 //   S::gain(P,x,trig,u,K)         lqr(x,u)[1]                       (K row-major M x N)
 //   S::step(P,x,trig,u,dt,xn)     dynamics(x,u,dt); u is the caller's scratch copy
-//   S::feasible(P,G,x,u,trig,lane) Constraints.is_feasible, cooperative over one wavefront,
+//   S::feasible(P,G,GL,x,u,trig,lane) Constraints.is_feasible, cooperative over one wavefront,
 //                                  returns a wave-uniform bool
 // where trig[2k],trig[2k+1] = cos,sin of x[wd(k)] (computed once per state and shared by
 // erf / dynamics / lqr / feasibility, which all need it).
@@ -31,12 +31,37 @@ constexpr int MAXP = 96;
 
 struct Params { double p[MAXP]; };
 
-// Collision geometry tables in HBM (uniform, read through the scalar/L1 path).
+// Collision geometry.  `vps`/`obs` are the raw tables in HBM; `oc` holds, per circular obstacle,
+// [x, y, thr, cull2]: thr is the largest double with fl(sqrt(thr)) <= r, so that `d2 <= thr` is
+// bit-for-bit the reference's `norm(v - c) <= r` without a square root (r < 0 placeholders get
+// thr = -1: never hit); cull2 = ((r + hull radius)(1+1e-9)+1e-9)^2 is a conservative reach test
+// on the vehicle centre.  Kernels stage vps and oc into LDS once (GeoL) and sweep from there.
 struct Geo {
     const double* vps;   // [2][V] body-frame hull points
-    const double* obs;   // [O][stride]
+    const double* obs;   // [O][stride] raw obstacles (circles [x,y,r] or boxes [lo3,hi3])
+    const double* oc;    // [O][4] derived circle table (null for box obstacles)
     int V, O, stride, pad;
 };
+
+struct GeoL {            // LDS-resident copy used inside a workgroup
+    const double* vps;   // [2][V]
+    const double* oc;    // [O][4]
+    int V, O;
+};
+
+__device__ __forceinline__ size_t geo_lds_doubles(const Geo& g) { return g.oc ? (size_t)2 * g.V + (size_t)4 * g.O : 0; }
+
+// Cooperative copy HBM -> LDS by the calling workgroup (caller synchronises afterwards).
+__device__ __forceinline__ GeoL stage_geo(const Geo& g, double* lds, int tid, int nthreads) {
+    GeoL L;
+    L.V = g.V; L.O = g.O;
+    L.vps = lds; L.oc = lds + 2 * g.V;
+    if (g.oc) {
+        for (int i = tid; i < 2 * g.V; i += nthreads) lds[i] = g.vps[i];
+        for (int i = tid; i < 4 * g.O; i += nthreads) lds[2 * g.V + i] = g.oc[i];
+    }
+    return L;
+}
 
 __device__ __forceinline__ double clipd(double v, double lo, double hi) {
     // np.clip = minimum(maximum(v, lo), hi)
@@ -73,42 +98,36 @@ __device__ __forceinline__ double numpy_row_sum(const double* a) {
 
 // Hull-vs-circles sweep shared by the planar vehicles (demo_boat_advanced.py:216-224):
 // verts = p + R(h) vps ; collision iff any ||vert - c|| <= r.  `extra2p` adds the car's
-// accidental vertex at 2p (demo_car.py:175).  One wavefront cooperates: lanes span the
-// obstacles when there are many of them, otherwise the hull points.
-__device__ __forceinline__ bool hull_hits(const Geo& g, double px, double py, double c, double s,
+// accidental vertex at 2p (demo_car.py:175).  One wavefront cooperates: lanes first cull the
+// obstacles by reach of the vehicle centre (one obstacle per lane), then, for each obstacle
+// that is within reach (wave-uniform loop over the ballot), the lanes split the hull points.
+__device__ __forceinline__ bool hull_hits(const GeoL& g, double px, double py, double c, double s,
                                           bool extra2p, int lane) {
     bool hit = false;
     const double ms = -s;
-    if (g.O >= 32) {
-        for (int o = lane; o < g.O; o += 64) {
-            const double ox = g.obs[o * g.stride + 0], oy = g.obs[o * g.stride + 1], r = g.obs[o * g.stride + 2];
-            for (int v = 0; v < g.V; ++v) {
+    for (int o0 = 0; o0 < g.O; o0 += 64) {
+        const int o = o0 + lane;
+        bool near = false;
+        if (o < g.O) {
+            const double ox = g.oc[4 * o], oy = g.oc[4 * o + 1];
+            const double dx = px - ox, dy = py - oy;
+            near = (dx * dx + dy * dy) <= g.oc[4 * o + 3];
+            if (extra2p) {
+                const double ex = (px + px) - ox, ey = (py + py) - oy;
+                hit |= (ex * ex + ey * ey) <= g.oc[4 * o + 2];
+            }
+        }
+        unsigned long long m = __ballot(near);
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const double ox = g.oc[4 * (o0 + j)], oy = g.oc[4 * (o0 + j) + 1], thr = g.oc[4 * (o0 + j) + 2];
+            for (int v = lane; v < g.V; v += 64) {
                 const double bx = g.vps[v], by = g.vps[g.V + v];
                 const double vx = px + (c * bx + ms * by);
                 const double vy = py + (s * bx + c * by);
                 const double dx = vx - ox, dy = vy - oy;
-                hit |= (sqrt(dx * dx + dy * dy) <= r);
-            }
-            if (extra2p) {
-                const double dx = (px + px) - ox, dy = (py + py) - oy;
-                hit |= (sqrt(dx * dx + dy * dy) <= r);
-            }
-        }
-    } else {
-        const int nv = g.V + (extra2p ? 1 : 0);
-        for (int v = lane; v < nv; v += 64) {
-            double vx, vy;
-            if (v < g.V) {
-                const double bx = g.vps[v], by = g.vps[g.V + v];
-                vx = px + (c * bx + ms * by);
-                vy = py + (s * bx + c * by);
-            } else {
-                vx = px + px;
-                vy = py + py;
-            }
-            for (int o = 0; o < g.O; ++o) {
-                const double dx = vx - g.obs[o * g.stride + 0], dy = vy - g.obs[o * g.stride + 1];
-                hit |= (sqrt(dx * dx + dy * dy) <= g.obs[o * g.stride + 2]);
+                hit |= (dx * dx + dy * dy) <= thr;
             }
         }
     }
@@ -196,12 +215,12 @@ struct BoatAdvanced : BoatCommon {
         euler(P + 0, P + 3, P + 6, x, c, s, us, dt, xn);
         carlike(x, P[38], P[39], xn);
     }
-    __device__ static bool feasible(const double* P, const Geo& g, const double* x, const double*, const double* trig, int lane) {
+    __device__ static bool feasible(const double* P, const Geo&, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
         // planning speed box first (demo_boat_advanced.py:211-213)
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             if (x[3 + i] > P[46 + i] || x[3 + i] < P[49 + i]) return false;
-        return !hull_hits(g, x[0], x[1], trig[0], trig[1], false, lane);
+        return !hull_hits(gl, x[0], x[1], trig[0], trig[1], false, lane);
     }
 };
 
@@ -220,8 +239,8 @@ struct BoatIntermediate : BoatCommon {
         euler(P + 0, P + 3, P + 6, x, c, s, u, dt, xn);
         carlike(x, P[13], P[14], xn);
     }
-    __device__ static bool feasible(const double*, const Geo& g, const double* x, const double*, const double* trig, int lane) {
-        return !hull_hits(g, x[0], x[1], trig[0], trig[1], false, lane);
+    __device__ static bool feasible(const double*, const Geo&, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
+        return !hull_hits(gl, x[0], x[1], trig[0], trig[1], false, lane);
     }
 };
 
@@ -236,12 +255,13 @@ struct BoatNovice : BoatCommon {
             if (fabs(u[i]) > P[9 + i]) u[i] = P[9 + i] * (u[i] > 0.0 ? 1.0 : -1.0);
         euler(P + 0, P + 3, P + 6, x, trig[0], trig[1], u, dt, xn);
     }
-    __device__ static bool feasible(const double* P, const Geo& g, const double* x, const double*, const double*, int lane) {
-        // centre point vs circles inflated by half the boat length (demo_boat_novice.py:160-164)
+    __device__ static bool feasible(const double*, const Geo&, const GeoL& gl, const double* x, const double*, const double*, int lane) {
+        // centre point vs circles inflated by half the boat length (demo_boat_novice.py:160-164);
+        // the inflated radius boat_length/2 + r is folded into the exact threshold on the host
         bool hit = false;
-        for (int o = lane; o < g.O; o += 64) {
-            const double dx = x[0] - g.obs[o * g.stride + 0], dy = x[1] - g.obs[o * g.stride + 1];
-            hit |= (sqrt(dx * dx + dy * dy) <= P[18] + g.obs[o * g.stride + 2]);
+        for (int o = lane; o < gl.O; o += 64) {
+            const double dx = x[0] - gl.oc[4 * o], dy = x[1] - gl.oc[4 * o + 1];
+            hit |= (dx * dx + dy * dy) <= gl.oc[4 * o + 2];
         }
         return __any(hit) == 0;
     }
@@ -272,8 +292,8 @@ struct Car {
         if (xn[3] < 0.0) xn[3] = 0.0;                                   // demo_car.py:66-67
         xn[4] = clipd(fabs(xn[3] / P[8]), 0.0, 1.0) * xn[4];            // demo_car.py:70
     }
-    __device__ static bool feasible(const double*, const Geo& g, const double* x, const double*, const double* trig, int lane) {
-        return !hull_hits(g, x[0], x[1], trig[0], trig[1], true, lane);
+    __device__ static bool feasible(const double*, const Geo&, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
+        return !hull_hits(gl, x[0], x[1], trig[0], trig[1], true, lane);
     }
 };
 
@@ -312,7 +332,7 @@ struct Pendulum {
         qn[2] = q[2] + a0 * dt;
         qn[3] = q[3] + a1 * dt;
     }
-    __device__ static bool feasible(const double* P, const Geo&, const double*, const double* u, const double*, int) {
+    __device__ static bool feasible(const double* P, const Geo&, const GeoL&, const double*, const double* u, const double*, int) {
         return !(fabs(u[0]) > P[13]);                                   // demo_pendulum.py:154-157
     }
 };
@@ -337,7 +357,7 @@ struct DoubleIntegratorT {
             xn[D + i] = x[D + i] + h * u[i];
         }
     }
-    __device__ static bool feasible(const double*, const Geo& g, const double* x, const double*, const double*, int lane) {
+    __device__ static bool feasible(const double*, const Geo& g, const GeoL&, const double* x, const double*, const double*, int lane) {
         bool hit = false;
         for (int o = lane; o < g.O; o += 64) {
             const double* b = g.obs + (size_t)o * g.stride;
