@@ -133,7 +133,7 @@ struct lqrrt_engine {
     int* d_summary = nullptr;     // [4 + 3*maxW]: ctrl (listed, deferred, horizon, -) + len/flags/parent
     int* h_summary = nullptr;     // pinned
     int* h_rank = nullptr;        // pinned
-    static constexpr int MAXCH = 256;
+    static constexpr int MAXCH = 1024;
 
     // sample stream
     MT mt_gen, mt_base;
@@ -152,6 +152,9 @@ struct lqrrt_engine {
     double* d_cand = nullptr;
     unsigned char* d_flags = nullptr;
     int cand_cap = 0;
+
+    // adaptive wave size (exactness does not depend on W, only speed does)
+    double ctl_w = 0.0;
 
     // counters
     lqrrt_extend_stats tot{};
@@ -272,7 +275,7 @@ static void prof_flush(lqrrt_engine* e) {
 
 static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
     const int groups = (W + 63) / 64;
-    int want = 4096 / (groups > 0 ? groups : 1);
+    int want = 8192 / (groups > 0 ? groups : 1);
     want = std::max(1, std::min(want, (int)lqrrt_engine::MAXCH));
     int c = (count + want - 1) / want;
     c = std::max(c, 8);
@@ -286,7 +289,7 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
                      bool profile, int* n_chunks_out = nullptr) {
     if (W <= 0) return 0;
     int chunk, n_chunks;
-    if (tri) { chunk = 64; n_chunks = (nv.count + 63) / 64; }   // in-wave pass: the reduction is fused into k_decide
+    if (tri) { chunk = 16; n_chunks = (nv.count + 15) / 16; }   // in-wave pass: the reduction is fused into k_decide
     else pick_chunks(nv.count, W, &chunk, &n_chunks);
     if (n_chunks_out) *n_chunks_out = n_chunks;
     dim3 grid((W + 63) / 64, n_chunks);
@@ -306,7 +309,7 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
 #undef NN_LAUNCH
     if (profile) prof_end(e, st, &ev, 0, (double)W * (double)nv.count * (8.0 * e->n + 1.0));
     if (tri) { HIPCHK(hipGetLastError()); return 0; }
-    hipLaunchKernelGGL(k_nn_reduce, dim3((W + 255) / 256), dim3(256), 0, st, e->d_pcost, e->d_pidx, pca, pia, W,
+    hipLaunchKernelGGL(k_nn_reduce, dim3(W), dim3(64), 0, st, e->d_pcost, e->d_pidx, pca, pia, W,
                        n_chunks, out_id, out_cost, rec, e->L.R, e->L.off_cost, e->L.off_parent);
     HIPCHK(hipGetLastError());
     return 0;
@@ -572,6 +575,7 @@ extern "C" int lqrrt_tree_reset(lqrrt_engine* e, const double* x0_host, void* st
     e->goal_hits = 0; e->best_end = -1; e->best_steps = -1;
     memset(&e->tot, 0, sizeof e->tot);
     e->tot.tree_size = 1;
+    e->ctl_w = 0.0;
     return 0;
 }
 
@@ -916,7 +920,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
             HIPCHK(hipMemsetAsync(e->d_pidx, 0xff, sizeof(int), st));        // no in-wave candidate
             HIPCHK(hipMemsetAsync(e->d_pcost, 0x7f, sizeof(double), st));    // large finite cost
         }
-        hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, st, e->d_rec, e->L, W, e->d_pcost, e->d_pidx, n_chunks,
+        hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, st, e->d_rec, e->L, W, e->d_pcost, e->d_pidx, n_chunks, 16,
                            e->d_par_done, e->d_par_want, e->d_changed, e->d_stale, e->d_need, e->d_list, e->d_summary,
                            e->d_summary + 4);
         HIPCHK(hipGetLastError());
@@ -1000,8 +1004,24 @@ static int pick_wave(const lqrrt_engine* e, int wave_cap) {
     W = std::max(W, 8);
     W = std::min(W, wave_cap);
     W = std::min(W, e->maxW);
+    // feedback from recent waves (goal hits cut a wave short; long dependency chains cost repair rounds)
+    if (e->ctl_w >= 8.0 && (double)W > e->ctl_w) W = (int)e->ctl_w;
     if (W >= 64) W = (W / 64) * 64;
     return W;
+}
+
+static void tune_wave(lqrrt_engine* e, int W, const lqrrt_extend_stats& ws, int wave_cap) {
+    double w = e->ctl_w >= 8.0 ? e->ctl_w : (double)W;
+    if (ws.goal_hits && ws.attempts < W) {
+        // cut by a goal hit after ws.attempts samples: the rest of the speculation was discarded
+        const double target = std::max(64.0, 2.0 * (double)ws.attempts);
+        w = 0.5 * w + 0.5 * target;
+    } else if (ws.fix_rounds > 6) {
+        w = std::max(64.0, 0.5 * w);
+    } else if (ws.fix_rounds <= 3) {
+        w = std::min((double)wave_cap, 1.5 * w + 32.0);
+    }
+    e->ctl_w = w;
 }
 
 extern "C" int lqrrt_engine_extend(lqrrt_engine* e, int wave, int64_t max_attempts, int64_t node_limit, int until_size,
@@ -1027,6 +1047,7 @@ extern "C" int lqrrt_engine_extend(lqrrt_engine* e, int wave, int64_t max_attemp
         TRY(lqrrt_wave_speculate(e, W, 0, W, stream));
         lqrrt_extend_stats ws;
         TRY(lqrrt_wave_commit(e, W, cap_attempts, lim, pruning, &ws, stream));
+        tune_wave(e, W, ws, wave);
         acc.attempts += ws.attempts; acc.accepted += ws.accepted; acc.waves += 1;
         acc.fix_rounds += ws.fix_rounds; acc.resteers += ws.resteers; acc.goal_hits += ws.goal_hits;
         if (stop_on_goal && ws.goal_hits) { acc.stop_reason = LQRRT_STOP_GOAL; break; }

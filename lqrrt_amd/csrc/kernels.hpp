@@ -9,9 +9,10 @@
 //   k_decide                 (build-only: exact-mode wave validation, see engine.hip)
 //
 // Execution model choices (MI355X):
-//   * NN scan: one lane = one sample, the node loop index is wave-uniform so node data comes
-//     through the scalar path (s_load -> SGPR operands); no cross-lane traffic at all, each
-//     lane keeps its own running (min, argmin).  The grid is (sample groups) x (node chunks)
+//   * NN scan: one lane = one sample; each workgroup stages its chunk of nodes into LDS with
+//     coalesced loads (the tree is SoA, node index fastest) and then every lane walks the same
+//     node sequence through LDS broadcasts; no cross-lane traffic at all, each lane keeps its
+//     own running (min, argmin).  The grid is (sample groups) x (node chunks)
 //     so that >> 1024 wavefronts cover the 256 CUs x 4 SIMDs even though one wave of samples
 //     is only 16 wavefronts wide.  The node table is tiny (480 KB at 10k x 6) and lives in L2;
 //     the kernel is bound by fp64 VALU (the per-pair atan2), see DESIGN.md.
@@ -119,6 +120,11 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
                                                 const double* __restrict__ Sd, int chunk,
                                                 double* __restrict__ pcost, int* __restrict__ pidx,
                                                 double* __restrict__ pcost_all, int* __restrict__ pidx_all) {
+    // one node = N state doubles + 2*NW trig doubles + 1 eligibility flag, padded to an even count so
+    // that every node starts 16-byte aligned in LDS (ds_read_b128 broadcasts)
+    constexpr int NV = S::N + 2 * S::NW;
+    constexpr int NVP = (NV + 2) & ~1;
+    __shared__ __attribute__((aligned(16))) double tile[64 * NVP];
     const int lane = threadIdx.x;
     const int t = blockIdx.x * 64 + lane;
     const int ts = t < W ? t : W - 1;
@@ -136,20 +142,38 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
 
     double best = INFINITY, best_all = INFINITY;
     int bidx = -1, bidx_all = -1;
-    for (int i = i0; i < i1; ++i) {
-        double x[S::N], trig[2 * S::NW + 1], e[S::N];
+    for (int base = i0; base < i1; base += 64) {
+        const int cnt = (i1 - base) < 64 ? (i1 - base) : 64;
+        __syncthreads();
+        if (lane < cnt) {                      // lane j stages node base+j (coalesced on the SoA tree)
+            const int i = base + lane;
+            double* nd = tile + lane * NVP;
 #pragma unroll
-        for (int d = 0; d < S::N; ++d) x[d] = nv.x[(long long)i * nv.sn + d * nv.sd];
+            for (int d = 0; d < S::N; ++d) nd[d] = nv.x[(long long)i * nv.sn + d * nv.sd];
 #pragma unroll
-        for (int j = 0; j < 2 * S::NW; ++j) trig[j] = nv.trig[(long long)i * nv.tn + j * nv.td];
-        erf_cached<S>(xg, gtrig, x, trig, e);
-        const double c = quad_cost<S, DENSE>(e, Sd);
-        bool ign;
-        if constexpr (TRI) ign = !(nv.len[(long long)i * nv.sn] > 0.0);
-        else ign = nv.ignore ? ((nv.ignore[i >> 6] >> (i & 63)) & 1ull) != 0 : false;
-        const bool ok = TRI ? (i < t) : true;
-        if (ok && c < best_all) { best_all = c; bidx_all = i; }
-        if (ok && !ign && c < best) { best = c; bidx = i; }
+            for (int j = 0; j < 2 * S::NW; ++j) nd[S::N + j] = nv.trig[(long long)i * nv.tn + j * nv.td];
+            bool ign;
+            if constexpr (TRI) ign = !(nv.len[(long long)i * nv.sn] > 0.0);
+            else ign = nv.ignore ? ((nv.ignore[i >> 6] >> (i & 63)) & 1ull) != 0 : false;
+            nd[NV] = ign ? 1.0 : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int j = 0; j < cnt; ++j) {        // every lane reads the same node: LDS broadcast
+            const double* nd = tile + j * NVP;
+            double x[S::N], trig[2 * S::NW + 1], e[S::N];
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) x[d] = nd[d];
+#pragma unroll
+            for (int k = 0; k < 2 * S::NW; ++k) trig[k] = nd[S::N + k];
+            erf_cached<S>(xg, gtrig, x, trig, e);
+            const double c = quad_cost<S, DENSE>(e, Sd);
+            const int i = base + j;
+            const bool ign = nd[NV] != 0.0;
+            const bool ok = TRI ? (i < t) : true;
+            if (ok && c < best_all) { best_all = c; bidx_all = i; }
+            if (ok && !ign && c < best) { best = c; bidx = i; }
+        }
     }
     if (t < W) {
         const size_t o = (size_t)blockIdx.y * W + t;
@@ -158,32 +182,51 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
     }
 }
 
-// Lexicographic (cost, id) minimum over the chunk partials; ascending chunk order + strict '<'
-// keeps the lowest node id among exactly equal costs (stable-argsort order, planner.py:240).
-// When every node is ignored the overall best is returned (planner.py:241,245 fallback).
-__global__ void k_nn_reduce(const double* __restrict__ pcost, const int* __restrict__ pidx,
-                            const double* __restrict__ pcost_all, const int* __restrict__ pidx_all,
-                            int W, int n_chunks, int* __restrict__ out_id, double* __restrict__ out_cost,
-                            double* __restrict__ rec, int R, int off_cost, int off_parent) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// Lexicographic (cost, id) minimum over the chunk partials: one wavefront per sample, lanes span
+// the chunks, then a butterfly over the 64 lanes.  Ordering by (cost, node id) keeps the lowest
+// node id among exactly equal costs (stable-argsort order, planner.py:240; chunks are ascending in
+// id, so comparing ids is the same as comparing chunk order).  When every node is ignored the
+// overall best is returned (planner.py:241,245 fallback).
+__device__ __forceinline__ void lexmin_wave(double& c, int& i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oc = __shfl_xor(c, off);
+        const int oi = __shfl_xor(i, off);
+        const bool take = (oi >= 0) && (i < 0 || oc < c || (oc == c && oi < i));
+        if (take) { c = oc; i = oi; }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_nn_reduce(const double* __restrict__ pcost, const int* __restrict__ pidx,
+                                                  const double* __restrict__ pcost_all, const int* __restrict__ pidx_all,
+                                                  int W, int n_chunks, int* __restrict__ out_id, double* __restrict__ out_cost,
+                                                  double* __restrict__ rec, int R, int off_cost, int off_parent) {
+    const int t = blockIdx.x;
     if (t >= W) return;
+    const int lane = threadIdx.x;
     double b = INFINITY, ba = INFINITY;
     int bi = -1, bai = -1;
-    for (int c = 0; c < n_chunks; ++c) {
+    for (int c = lane; c < n_chunks; c += 64) {              // ascending per lane, strict '<'
         const size_t o = (size_t)c * W + t;
         const double v = pcost[o];
-        if (v < b) { b = v; bi = pidx[o]; }
+        const int vi = pidx[o];
+        if (vi >= 0 && (bi < 0 || v < b)) { b = v; bi = vi; }
         if (pcost_all) {
             const double va = pcost_all[o];
-            if (va < ba) { ba = va; bai = pidx_all[o]; }
+            const int vai = pidx_all[o];
+            if (vai >= 0 && (bai < 0 || va < ba)) { ba = va; bai = vai; }
         }
     }
+    lexmin_wave(b, bi);
+    if (pcost_all) lexmin_wave(ba, bai);
     if (bi < 0 && pcost_all) { b = ba; bi = bai; }
-    if (out_id) out_id[t] = bi;
-    if (out_cost) out_cost[t] = b;
-    if (rec) {
-        rec[(size_t)t * R + off_cost] = b;
-        rec[(size_t)t * R + off_parent] = (double)bi;
+    if (lane == 0) {
+        if (out_id) out_id[t] = bi;
+        if (out_cost) out_cost[t] = b;
+        if (rec) {
+            rec[(size_t)t * R + off_cost] = b;
+            rec[(size_t)t * R + off_parent] = (double)bi;
+        }
     }
 }
 
@@ -422,7 +465,7 @@ __global__ void k_tree_root(Params P, TreeView tv, const double* __restrict__ x0
 //   also redone this round is deferred (its start state is about to change).
 // ctrl[0]=listed, ctrl[1]=deferred, ctrl[2]=L; summary[0..3W) = len, flags, parent per sample.
 __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ rec, RecLayout L, int W,
-                                                 const double* __restrict__ pcost, const int* __restrict__ pidx, int n_chunks,
+                                                 const double* __restrict__ pcost, const int* __restrict__ pidx, int n_chunks, int chunk,
                                                  int* __restrict__ par_done, int* __restrict__ par_want,
                                                  unsigned char* __restrict__ changed, unsigned char* __restrict__ stale,
                                                  unsigned char* __restrict__ need, int* __restrict__ list,
@@ -443,7 +486,9 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ rec,
         if (t <= hz) {
             double wc = INFINITY;
             int s = -1;
-            for (int c = 0; c < n_chunks; ++c) {            // ascending chunks + strict '<' = lowest id on ties
+            const int nc = min(n_chunks, t / chunk + 1);     // chunks that hold samples < t
+#pragma unroll 4
+            for (int c = 0; c < nc; ++c) {                   // ascending chunks + strict '<' = lowest id on ties
                 const double v = pcost[(size_t)c * W + t];
                 if (v < wc) { wc = v; s = pidx[(size_t)c * W + t]; }
             }
