@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""
+Turns the rocprofv3 CSVs of one round (kernel-trace --stats pass, FETCH_SIZE pass, WRITE_SIZE pass)
+into the committed summaries under profiles/:
+  profiles/rNN_kernel_stats.csv      -- rocprofv3 --kernel-trace --stats summary (verbatim)
+  profiles/rNN_nn_traffic.json       -- per-launch HBM traffic of the NN scan from the PMC passes
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x
+(MI355X_MICROARCH.md, HBM section), so fetch bytes = 2 * FETCH_SIZE * 1024.
+"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def per_kernel(path, name_part):
+    rows = [r for r in csv.DictReader(open(path)) if name_part in r["Kernel_Name"]]
+    vals = [float(r["Counter_Value"]) for r in rows]
+    durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+    return len(rows), sum(vals), sum(durs)
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out")
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    shutil.copy(os.path.join(src, "prof_r1", "bench_kernel_stats.csv"), os.path.join(out, "%s_kernel_stats.csv" % rnd))
+    kern = "k_nn_scan<lq::BoatAdvanced, false, false>"
+    n_f, fetch_kib, dur_f = per_kernel(os.path.join(src, "prof_r1_fetch", "bench_counter_collection.csv"), kern)
+    n_w, write_kib, dur_w = per_kernel(os.path.join(src, "prof_r1_write", "bench_counter_collection.csv"), kern)
+    summary = {
+        "kernel": kern, "command": "python bench.py --steps 20 --warmup 3 --no-cpu (whole process: tree growth + warm-up + timed steps)",
+        "launches": n_f,
+        "FETCH_SIZE_KiB_per_launch": fetch_kib / n_f, "WRITE_SIZE_KiB_per_launch": write_kib / n_w,
+        "fetch_correction": 2.0,
+        "hbm_bytes_per_launch": (2.0 * fetch_kib / n_f + write_kib / n_w) * 1024.0,
+        "avg_launch_ns_fetch_pass": dur_f / n_f, "avg_launch_ns_write_pass": dur_w / n_w,
+    }
+    with open(os.path.join(out, "%s_nn_traffic.json" % rnd), "w") as f:
+        json.dump(summary, f, indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
