@@ -210,6 +210,11 @@ int lqrrt_record_layout(lqrrt_engine* e, int32_t* layout11);
 /* Device address of the engine's wave record buffer [max_wave][record doubles]. */
 int lqrrt_wave_records(lqrrt_engine* e, void** dev_ptr);
 
+/* Wave size the engine would pick now (<= wave_cap): ~N/6 while the tree is small, then steered by
+ * feedback from the last commits (waves cut short by goal hits, repair rounds).  Any W gives the
+ * same tree; this only tunes speed.  All ranks of a sharded run get the same answer. */
+int lqrrt_wave_suggest(lqrrt_engine* e, int wave_cap);
+
 /* Phase A of a wave (shardable): prepares samples [k0, k0+W) of the sample stream if needed,
  * then runs the speculative nearest-neighbour + steer for the slice [lo,hi) of the wave
  * against the current tree and writes records lo..hi-1.  Other ranks fill the rest

@@ -82,6 +82,7 @@ SIGNATURES = {
     "lqrrt_steer_batch": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "lqrrt_record_layout": (_I, [_P, _P]),
     "lqrrt_wave_records": (_I, [_P, C.POINTER(_P)]),
+    "lqrrt_wave_suggest": (_I, [_P, _I]),
     "lqrrt_wave_speculate": (_I, [_P, _I, _I, _I, _P]),
     "lqrrt_wave_commit": (_I, [_P, _I, _I64, _I64, _I, C.POINTER(ExtendStats), _P]),
     "lqrrt_engine_extend": (_I, [_P, _I, _I64, _I64, _I, _I, _I, C.POINTER(ExtendStats), _P]),

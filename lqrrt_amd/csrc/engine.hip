@@ -894,6 +894,38 @@ __global__ void k_par_from_records(const double* __restrict__ rec, RecLayout L, 
     if (t < W) par_done[t] = (int)rec[(size_t)t * L.R + L.off_parent];
 }
 
+static int pick_wave(const lqrrt_engine* e, int wave_cap) {
+    // conflicts (true parent born inside the wave) scale ~ W/N: keep W a fraction of the tree
+    int W = e->N / 6;
+    W = std::max(W, 8);
+    W = std::min(W, wave_cap);
+    W = std::min(W, e->maxW);
+    // feedback from recent waves (goal hits cut a wave short; long dependency chains cost repair rounds)
+    if (e->ctl_w >= 8.0 && (double)W > e->ctl_w) W = (int)e->ctl_w;
+    if (W >= 64) W = (W / 64) * 64;
+    return W;
+}
+
+static void tune_wave(lqrrt_engine* e, int W, const lqrrt_extend_stats& ws, int wave_cap) {
+    double w = e->ctl_w >= 8.0 ? e->ctl_w : (double)W;
+    if (ws.goal_hits && ws.attempts < W) {
+        // cut by a goal hit after ws.attempts samples: the rest of the speculation was discarded
+        const double target = std::max(64.0, 2.0 * (double)ws.attempts);
+        w = 0.5 * w + 0.5 * target;
+    } else if (ws.fix_rounds > 6) {
+        w = std::max(64.0, 0.5 * w);
+    } else if (ws.fix_rounds <= 3) {
+        w = std::min((double)wave_cap, 1.5 * w + 32.0);
+    }
+    e->ctl_w = w;
+}
+
+extern "C" int lqrrt_wave_suggest(lqrrt_engine* e, int wave_cap) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    if (wave_cap < 1) return fail(LQRRT_E_ARG, "wave_cap must be >= 1");
+    return pick_wave(e, wave_cap);
+}
+
 extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_limit, int pruning,
                                  lqrrt_extend_stats* out, void* stream) {
     if (!e) return fail(LQRRT_E_ARG, "null engine");
@@ -994,34 +1026,9 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     e->tot.attempts += C; e->tot.accepted += acc; e->tot.waves += 1; e->tot.fix_rounds += ws.fix_rounds;
     e->tot.resteers += ws.resteers; e->tot.goal_hits += ws.goal_hits; e->tot.tree_size = e->N;
     e->tot.candidates = e->committed_row;
+    tune_wave(e, W, ws, e->maxW);
     if (out) *out = ws;
     return 0;
-}
-
-static int pick_wave(const lqrrt_engine* e, int wave_cap) {
-    // conflicts (true parent born inside the wave) scale ~ W/N: keep W a fraction of the tree
-    int W = e->N / 6;
-    W = std::max(W, 8);
-    W = std::min(W, wave_cap);
-    W = std::min(W, e->maxW);
-    // feedback from recent waves (goal hits cut a wave short; long dependency chains cost repair rounds)
-    if (e->ctl_w >= 8.0 && (double)W > e->ctl_w) W = (int)e->ctl_w;
-    if (W >= 64) W = (W / 64) * 64;
-    return W;
-}
-
-static void tune_wave(lqrrt_engine* e, int W, const lqrrt_extend_stats& ws, int wave_cap) {
-    double w = e->ctl_w >= 8.0 ? e->ctl_w : (double)W;
-    if (ws.goal_hits && ws.attempts < W) {
-        // cut by a goal hit after ws.attempts samples: the rest of the speculation was discarded
-        const double target = std::max(64.0, 2.0 * (double)ws.attempts);
-        w = 0.5 * w + 0.5 * target;
-    } else if (ws.fix_rounds > 6) {
-        w = std::max(64.0, 0.5 * w);
-    } else if (ws.fix_rounds <= 3) {
-        w = std::min((double)wave_cap, 1.5 * w + 32.0);
-    }
-    e->ctl_w = w;
 }
 
 extern "C" int lqrrt_engine_extend(lqrrt_engine* e, int wave, int64_t max_attempts, int64_t node_limit, int until_size,
@@ -1047,7 +1054,6 @@ extern "C" int lqrrt_engine_extend(lqrrt_engine* e, int wave, int64_t max_attemp
         TRY(lqrrt_wave_speculate(e, W, 0, W, stream));
         lqrrt_extend_stats ws;
         TRY(lqrrt_wave_commit(e, W, cap_attempts, lim, pruning, &ws, stream));
-        tune_wave(e, W, ws, wave);
         acc.attempts += ws.attempts; acc.accepted += ws.accepted; acc.waves += 1;
         acc.fix_rounds += ws.fix_rounds; acc.resteers += ws.resteers; acc.goal_hits += ws.goal_hits;
         if (stop_on_goal && ws.goal_hits) { acc.stop_reason = LQRRT_STOP_GOAL; break; }

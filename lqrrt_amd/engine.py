@@ -237,6 +237,9 @@ class Engine(object):
         nat.check(nat.lib().lqrrt_wave_records(self.h, C.byref(p)))
         return p.value
 
+    def wave_suggest(self, wave_cap):
+        return nat.check(nat.lib().lqrrt_wave_suggest(self.h, int(wave_cap)))
+
     def wave_speculate(self, W, lo, hi):
         nat.check(nat.lib().lqrrt_wave_speculate(self.h, W, lo, hi, nat.current_stream()))
 

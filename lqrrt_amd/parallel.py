@@ -34,7 +34,8 @@ def records_tensor(engine):
 
 
 def pick_wave(tree_size, wave_cap):
-    """Same policy as pick_wave() in csrc/engine.hip: W ~ N/6 keeps in-wave conflicts rare."""
+    """Open-loop part of the engine's wave-size policy (W ~ N/6 keeps in-wave conflicts rare); the
+    engine's lqrrt_wave_suggest adds feedback from the last commits and is used when available."""
     W = max(tree_size // 6, 8)
     W = min(W, wave_cap)
     if W >= 64:
@@ -57,7 +58,8 @@ class ShardedWave(object):
 
     def wave(self, want, max_commit, node_limit=-1, pruning=True):
         """One wave of up to `want` samples; returns the commit's ExtendStats."""
-        W = min(pick_wave(self.e.size, self.max_wave), want)
+        suggest = getattr(self.e, "wave_suggest", None)
+        W = min(suggest(self.max_wave) if suggest else pick_wave(self.e.size, self.max_wave), want)
         per, lo, hi = shard_bounds(W, self.rank, self.world)
         while per * self.world > self.max_wave:        # gather buffer must hold world * per rows
             W -= 1

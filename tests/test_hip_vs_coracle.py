@@ -16,7 +16,10 @@ pytestmark = pytest.mark.gpu
 def _engine_run(name, max_nodes, wave, seed=1, pruning=True, stop_on_goal=False, **sys_kw):
     import lqrrt_amd
     from lqrrt_amd.engine import Engine
-    s = lqrrt_amd.systems.SYSTEMS[name](0, **sys_kw) if not sys_kw else lqrrt_amd.systems.SYSTEMS[name](**sys_kw)
+    if sys_kw:
+        s = lqrrt_amd.systems.SYSTEMS[name](n_boxes=sys_kw["n_boxes"], seed=sys_kw["seed_boxes"])
+    else:
+        s = lqrrt_amd.systems.SYSTEMS[name](0)
     eng = Engine(s, capacity=max_nodes + wave + 8, max_wave=wave)
     kw = s.plan_kwargs
     eng.set_resolution(kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer))
@@ -63,6 +66,16 @@ def test_bit_exact_vs_sequential_oracle(name, nodes, wave):
         np.testing.assert_array_equal(eng.parents(), o.parents())
         np.testing.assert_allclose(eng.states(), o.states(), rtol=0, atol=1e-12)
         return
+    _compare(eng, stats, o)
+
+
+def test_bit_exact_double_integrator_dense_S():
+    """BASELINE.json config 5 at test size: 12-state double integrator, dense DARE cost-to-go matrix,
+    box obstacles; exercises the DENSE cost path and numpy's >= 8-term summation order."""
+    import coracle
+    s, eng, stats = _engine_run("double_integrator", 2500, 512, n_boxes=3000, seed_boxes=0)
+    o = coracle.make(s, 2500 + 512 + 8, seed=1)
+    assert o.extend(max_nodes=2500) == 2
     _compare(eng, stats, o)
 
 
