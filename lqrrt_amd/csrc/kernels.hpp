@@ -71,6 +71,19 @@ __host__ __device__ inline RecLayout make_layout(int n, int m, int nw, int H) {
     return L;
 }
 
+// Stores a wave-uniform register array: lane j writes element j (and j+64, ... for longer arrays).
+// The select chain keeps the array in registers (no dynamic indexing -> no scratch).
+template <int CNT>
+__device__ __forceinline__ void store_uniform(double* dst, const double* a, int lane) {
+#pragma unroll
+    for (int base = 0; base < CNT; base += 64) {
+        double v = a[base];
+#pragma unroll
+        for (int j = base + 1; j < (base + 64 < CNT ? base + 64 : CNT); ++j) v = (lane == j - base) ? a[j] : v;
+        if (base + lane < CNT) dst[base + lane] = v;
+    }
+}
+
 template <class S>
 __device__ __forceinline__ void trig_of(const double* x, double* trig) {
 #pragma unroll
@@ -219,12 +232,15 @@ __global__ __launch_bounds__(64) void k_nn_reduce(const double* __restrict__ pco
     }
     lexmin_wave(b, bi);
     if (pcost_all) lexmin_wave(ba, bai);
-    if (bi < 0 && pcost_all) { b = ba; bi = bai; }
+    const bool fallback = bi < 0 && pcost_all;               // every snapshot node is ignored
+    if (fallback) { b = ba; bi = bai; }
     if (lane == 0) {
         if (out_id) out_id[t] = bi;
         if (out_cost) out_cost[t] = b;
         if (rec) {
-            rec[(size_t)t * R + off_cost] = b;
+            // A fallback parent only stands if nothing else exists: any (never ignored) node born earlier
+            // in the same wave must beat it regardless of cost, so the record carries +inf as its cost.
+            rec[(size_t)t * R + off_cost] = fallback ? INFINITY : b;
             rec[(size_t)t * R + off_parent] = (double)bi;
         }
     }
@@ -379,16 +395,8 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= r.tol[d]);
         if (steps > r.H || conv) break;                          // planner.py:428
         // record (planner.py:432-433): lane d keeps component d
-        {
-            double v = xn[0];
-#pragma unroll
-            for (int d = 1; d < S::N; ++d) v = (lane == d) ? xn[d] : v;
-            if (lane < S::N) hx[cnt * S::N + lane] = v;
-            double w = u[0];
-#pragma unroll
-            for (int j = 1; j < S::M; ++j) w = (lane == j) ? u[j] : w;
-            if (lane < S::M) hu[cnt * S::M + lane] = w;
-        }
+        store_uniform<S::N>(hx + cnt * S::N, xn, lane);
+        store_uniform<S::M>(hu + cnt * S::M, u, lane);
         ++cnt;
 #pragma unroll
         for (int d = 0; d < S::N; ++d) x[d] = xn[d];
@@ -413,22 +421,9 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         flags = in ? 1 : 0;
         for (int q = lane; q < cnt * S::N; q += 64) my[L.off_xseq + q] = hx[q];
         for (int q = lane; q < cnt * S::M; q += 64) my[L.off_useq + q] = hu[q];
-        {
-            double v = x[0];
-#pragma unroll
-            for (int d = 1; d < S::N; ++d) v = (lane == d) ? x[d] : v;
-            if (lane < S::N) my[L.off_xend + lane] = v;
-            if constexpr (S::NW > 0) {
-                double w = trig[0];
-#pragma unroll
-                for (int j = 1; j < 2 * S::NW; ++j) w = (lane == j) ? trig[j] : w;
-                if (lane < 2 * S::NW) my[L.off_trig + lane] = w;
-            }
-            double kk = K[0];
-#pragma unroll
-            for (int j = 1; j < S::M * S::N; ++j) kk = (lane == j) ? K[j] : kk;
-            if (lane < S::M * S::N) my[L.off_K + lane] = kk;
-        }
+        store_uniform<S::N>(my + L.off_xend, x, lane);
+        if constexpr (S::NW > 0) store_uniform<2 * S::NW>(my + L.off_trig, trig, lane);
+        store_uniform<S::M * S::N>(my + L.off_K, K, lane);
     }
     if (lane == 0) {
         my[L.off_len] = (double)cnt;
@@ -541,7 +536,7 @@ __global__ __launch_bounds__(64) void k_append(TreeView tv, const double* __rest
     const int lane = threadIdx.x;
     if (lane < S::N) tv.state[(size_t)lane * tv.cap + id] = my[L.off_xend + lane];
     if (lane < 2 * S::NW) tv.trig[(size_t)lane * tv.cap + id] = my[L.off_trig + lane];
-    if (lane < S::M * S::N) tv.K[(size_t)id * S::M * S::N + lane] = my[L.off_K + lane];
+    for (int q = lane; q < S::M * S::N; q += 64) tv.K[(size_t)id * S::M * S::N + q] = my[L.off_K + q];
     if (lane == 0) {
         const int p = par_done[t];
         tv.pID[id] = p >= 0 ? p : base + rank[~p];
