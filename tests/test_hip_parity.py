@@ -252,3 +252,61 @@ def test_empty_and_edge_cases():
     pc.update_plan(c.x0, c.sample_space, goal_bias=c.goal_bias, xrand_gen=10, pruning=False)
     assert not pc._engine.ignored().any()
     assert pc.plan_reached_goal
+
+
+def test_full_size_invariants_boat_advanced_10k():
+    """Size-independent properties of the reference's data structures, checked at BASELINE.json's
+    full size (demo_boat_advanced grown to 10k nodes on the GPU)."""
+    s = _system("boat_advanced")
+    p = _planner(s, 10000, wave_size=1024)
+    np.random.seed(1)
+    assert p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10) is False
+    eng = p._engine
+    N, H = eng.size, p.horizon_iters
+    assert N == 10001                                              # planner.py:311: stop once size > max_nodes
+    pid, elen, st = eng.parents(), eng.edge_lengths(), eng.states()
+    assert pid[0] == -1 and np.all(pid[1:] >= 0) and np.all(pid[1:] < np.arange(1, N))   # parents are older nodes
+    assert elen[0] == 1 and np.all(elen[1:] >= 1) and np.all(elen[1:] <= H)              # <= H recorded steps
+    assert p.stats["accepted"] == N - 1 and p.stats["attempts"] >= N - 1
+    # every node state is the last state of its edge; every recorded state is feasible; K = lqr(state)
+    ids = np.r_[1:60, N // 2:N // 2 + 60, N - 60:N]
+    xs_all, ulast = [], []
+    for ID in ids:
+        x, u = eng.edge(int(ID))
+        assert len(x) == elen[ID]
+        np.testing.assert_array_equal(x[-1], st[ID])
+        xs_all.append(x)
+        ulast.append(u[-1])
+    xs_all = np.vstack(xs_all)
+    assert eng.feasible_batch(xs_all).all()                        # infeasible steps are never recorded, planner.py:393-396
+    np.testing.assert_array_equal(eng.gain_batch(st[ids], np.array(ulast)), eng.gains()[ids])
+    # nearest-neighbour kernel == arg-min of the full cost vector, with and without the ignore set
+    rng = np.random.RandomState(4)
+    space = np.array(s.sample_space, dtype=np.float64)
+    q = space[:, 0] + (space[:, 1] - space[:, 0]) * rng.random_sample((96, s.nstates))
+    ids_all, cost_all = eng.nn_argmin(q, use_ignore=False)
+    ids_ign, _ = eng.nn_argmin(q, use_ignore=True)
+    ign = eng.ignored()
+    assert ign.any() and not ign.all()
+    for k in range(0, 96, 8):
+        c = eng.costs_to_go(q[k])
+        assert int(ids_all[k]) == int(np.argmin(c)) and cost_all[k] == c.min()
+        live = np.where(ign, np.inf, c)
+        assert int(ids_ign[k]) == int(np.argmin(live))
+    # ignore set = union of root paths of the goal hits (planner.py:270); climb/trajectory round trip
+    lo = np.array(s.goal) - np.array(s.goal_buffer)
+    hi = np.array(s.goal) + np.array(s.goal_buffer)
+    in_goal = np.all((st > lo) & (st < hi), axis=1)
+    want = np.zeros(N, dtype=bool)
+    for ID in np.flatnonzero(in_goal):
+        v = int(ID)
+        while v != -1 and not want[v]:
+            want[v] = True
+            v = int(pid[v])
+    np.testing.assert_array_equal(ign, want)
+    end, steps, hits = eng.plan_best()
+    assert hits == int(in_goal.sum()) and in_goal[end]
+    chain = p.tree.climb(end)
+    assert chain[0] == 0 and chain[-1] == end and steps == int(elen[chain].sum())
+    px, pu = p.tree.trajectory(chain)
+    assert len(px) == steps == len(pu)
