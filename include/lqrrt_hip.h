@@ -180,6 +180,17 @@ int lqrrt_gain_batch(lqrrt_engine* e, const double* x_dev, const double* u_dev, 
 int lqrrt_erf_batch(lqrrt_engine* e, const double* xg_dev, const double* x_dev, int B,
                     double* e_dev, void* stream);
 
+/* The general lqr(x,u) of the API contract (planner.py:39-42: "S solves the local Riccati equation",
+ * K the feedback gain), which no demo of the reference implements: per item, A = df/dx and B = df/du
+ * by central differences (step eps) of the compiled-in dynamics about (x,u), then the discrete
+ * algebraic Riccati equation for weights Q (n x n), R (m x m) by structure-preserving doubling, and
+ * K = (R + B'SB)^-1 B'SA.  One problem per wavefront.  Outputs S [B][n][n], K [B][m][n]; optional
+ * A [B][n][n], B [B][n][m], iterations [B] (NULL to skip).  Golden: scipy.linalg.solve_discrete_are. */
+int lqrrt_lqr_dare_batch(lqrrt_engine* e, const double* x_dev, const double* u_dev, int B,
+                         const double* Q_dev, const double* R_dev, double eps,
+                         double* S_dev, double* K_dev, double* A_dev, double* B_dev, int32_t* iters_dev,
+                         void* stream);
+
 /* Planner._costs_to_go + nearest selection (planner.py:239-247, 340-350) for W samples
  * against the current tree: id[W] = lowest-cost non-ignored node (lowest id on ties; the
  * overall best when every node is ignored), cost[W] its cost.  S_dev: NULL = the system's

@@ -77,6 +77,7 @@ SIGNATURES = {
     "lqrrt_dynamics_batch": (_I, [_P, _P, _P, _I, _P, _P]),
     "lqrrt_gain_batch": (_I, [_P, _P, _P, _I, _P, _P]),
     "lqrrt_erf_batch": (_I, [_P, _P, _P, _I, _P, _P]),
+    "lqrrt_lqr_dare_batch": (_I, [_P, _P, _P, _I, _P, _P, _D, _P, _P, _P, _P, _P, _P]),
     "lqrrt_nn_argmin": (_I, [_P, _P, _I, _P, _I, _P, _P, _P]),
     "lqrrt_costs_to_go": (_I, [_P, _P, _P, _P, _P]),
     "lqrrt_steer_batch": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),

@@ -8,6 +8,7 @@
 // point returns LQRRT_E_NODEVICE.
 #include "../../include/lqrrt_hip.h"
 #include "kernels.hpp"
+#include "dare.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -709,6 +710,20 @@ extern "C" int lqrrt_erf_batch(lqrrt_engine* e, const double* xg, const double* 
     if (!B) return 0;
     TRY(use_device(e));
     DISPATCH(e, hipLaunchKernelGGL((k_erf_batch<S>), dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, xg, x, B, eo));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lqrrt_lqr_dare_batch(lqrrt_engine* e, const double* x, const double* u, int B, const double* Q_dev,
+                                    const double* R_dev, double eps, double* S_dev, double* K_dev, double* A_dev,
+                                    double* B_dev, int32_t* iters_dev, void* stream) {
+    if (!e || !x || !Q_dev || !R_dev || !S_dev || !K_dev || B < 0) return fail(LQRRT_E_ARG, "bad argument");
+    if (!e->has_res) return fail(LQRRT_E_STATE, "set_resolution first (dt)");
+    if (!(eps > 0)) return fail(LQRRT_E_ARG, "eps must be positive");
+    if (!B) return 0;
+    TRY(use_device(e));
+    DISPATCH(e, hipLaunchKernelGGL((k_lqr_dare<S>), dim3(B), dim3(64), 0, (hipStream_t)stream, e->P, x, u, B, Q_dev, R_dev,
+                                   e->res.dt, eps, 64, 1e-14, S_dev, K_dev, A_dev, B_dev, iters_dev));
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -190,6 +190,23 @@ class Engine(object):
         nat.check(nat.lib().lqrrt_erf_batch(self.h, dg.data_ptr(), dx.data_ptr(), B, e.data_ptr(), nat.current_stream()))
         return e.cpu().numpy()
 
+    def lqr_dare_batch(self, x, u, Q, R, eps=1e-6):
+        """(S, K, A, B, iterations) of the finite-difference-linearised DARE at every (x[i], u[i])."""
+        torch = _torch()
+        Bn = len(x)
+        dev = "cuda:%d" % self.device
+        dx, du = self._dev(x, (Bn, self.n)), self._dev(u, (Bn, self.m))
+        dQ, dR = self._dev(Q, (self.n, self.n)), self._dev(R, (self.m, self.m))
+        S = torch.empty((Bn, self.n, self.n), dtype=torch.float64, device=dev)
+        K = torch.empty((Bn, self.m, self.n), dtype=torch.float64, device=dev)
+        A = torch.empty((Bn, self.n, self.n), dtype=torch.float64, device=dev)
+        Bm = torch.empty((Bn, self.n, self.m), dtype=torch.float64, device=dev)
+        it = torch.empty(Bn, dtype=torch.int32, device=dev)
+        nat.check(nat.lib().lqrrt_lqr_dare_batch(self.h, dx.data_ptr(), du.data_ptr(), Bn, dQ.data_ptr(), dR.data_ptr(),
+                                                 float(eps), S.data_ptr(), K.data_ptr(), A.data_ptr(), Bm.data_ptr(),
+                                                 it.data_ptr(), nat.current_stream()))
+        return S.cpu().numpy(), K.cpu().numpy(), A.cpu().numpy(), Bm.cpu().numpy(), it.cpu().numpy()
+
     def nn_argmin(self, xs, S=None, use_ignore=True):
         torch = _torch()
         W = len(xs)
