@@ -211,7 +211,22 @@ int lqrrt_steer_batch(lqrrt_engine* e, const int32_t* parent_dev, const double* 
                       int32_t* len_dev, double* xseq_dev, double* useq_dev, double* xend_dev,
                       double* Kend_dev, void* stream);
 
+/* Planner._steer(ID, xtar, force_arrive=True) (planner.py:354-410, used by finish_on_goal :294-303):
+ * one rollout from tree node `parent` until np.allclose(x, xtar, rtol, atol) (that step is not
+ * recorded), an infeasible step (FPR truncation) or max_steps -- a deterministic stand-in for the
+ * reference's wall-clock timeout (:402-406).  len_dev[0] = recorded steps; xseq [max_steps][n],
+ * useq [max_steps][m]. */
+int lqrrt_steer_force(lqrrt_engine* e, int parent, const double* xtar_dev, int max_steps, double rtol, double atol,
+                      int32_t* len_dev, double* xseq_dev, double* useq_dev, void* stream);
+
 /* ---------------------------------------------------------------- wave engine -------- */
+
+/* Explicit sample stream: the caller supplies the samples (a user xrand_gen function,
+ * planner.py:213-216) instead of the default sampler; xs_host [count][n] are queued after what is
+ * already queued.  lqrrt_engine_set_sampler switches back to the default sampler. */
+int lqrrt_engine_push_samples(lqrrt_engine* e, const double* xs_host, int count);
+int lqrrt_engine_queued_samples(lqrrt_engine* e);
+
 
 /* Doubles per wave record and field offsets (for the RCCL all-gather of records):
  * layout[0]=record doubles, [1]=off_cost, [2]=off_parent, [3]=off_len, [4]=off_flags,

@@ -81,6 +81,9 @@ SIGNATURES = {
     "lqrrt_nn_argmin": (_I, [_P, _P, _I, _P, _I, _P, _P, _P]),
     "lqrrt_costs_to_go": (_I, [_P, _P, _P, _P, _P]),
     "lqrrt_steer_batch": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "lqrrt_steer_force": (_I, [_P, _I, _P, _I, _D, _D, _P, _P, _P, _P]),
+    "lqrrt_engine_push_samples": (_I, [_P, _P, _I]),
+    "lqrrt_engine_queued_samples": (_I, [_P]),
     "lqrrt_record_layout": (_I, [_P, _P]),
     "lqrrt_wave_records": (_I, [_P, C.POINTER(_P)]),
     "lqrrt_wave_suggest": (_I, [_P, _I]),

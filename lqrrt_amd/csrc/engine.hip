@@ -145,6 +145,7 @@ struct lqrrt_engine {
     int64_t pool_base = 0;        // sample index of pool[0]
     std::vector<double> pool;     // [count][n] prepared samples
     std::vector<int64_t> pool_rows_end;  // candidate rows consumed through each pooled sample
+    bool explicit_samples = false; // samples pushed by the host (callable xrand_gen) instead of the sampler
     int tries_carry = 0;          // tries already spent on the sample under construction
     std::vector<double> carry_row;
     double* d_pool = nullptr;     // device mirror of the samples [cursor_at_upload ..)
@@ -520,6 +521,7 @@ extern "C" int lqrrt_engine_set_sampler(lqrrt_engine* e, const lqrrt_sampler_des
     if (s->tries_limit < 1) return fail(LQRRT_E_ARG, "tries_limit must be >= 1");
     e->smp = *s;
     e->has_sampler = true;
+    e->explicit_samples = false;
     // same invalidation as a goal change
     e->pool.clear(); e->pool_rows_end.clear();
     e->pool_base = e->cursor;
@@ -784,11 +786,42 @@ extern "C" int lqrrt_steer_batch(lqrrt_engine* e, const int32_t* parent, const d
     return 0;
 }
 
+extern "C" int lqrrt_steer_force(lqrrt_engine* e, int parent, const double* xtar_dev, int max_steps, double rtol, double atol,
+                                 int32_t* len_dev, double* xseq_dev, double* useq_dev, void* stream) {
+    if (!e || !xtar_dev || !len_dev || !xseq_dev || !useq_dev || max_steps < 1) return fail(LQRRT_E_ARG, "bad argument");
+    if (!e->has_res) return fail(LQRRT_E_STATE, "set_resolution first");
+    TRY(range_ok(e, parent, 1));
+    TRY(use_device(e));
+    DISPATCH(e, hipLaunchKernelGGL((k_steer_force<S>), dim3(1), dim3(64), geo_lds_bytes(e), (hipStream_t)stream, e->P, e->geo,
+                                   e->res, e->tv, parent, xtar_dev, max_steps, rtol, atol, len_dev, xseq_dev, useq_dev));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // --------------------------------------------------------------------------------------------
 // sample stream (default sampler closure, planner.py:176-211)
 
 static int ensure_samples(lqrrt_engine* e, int64_t need_end, hipStream_t st) {
     // makes samples [cursor, need_end) available on the device at d_pool (index - d_pool_base)
+    if (e->explicit_samples) {
+        if (need_end > e->pool_base + (int64_t)e->pool_rows_end.size())
+            return fail(LQRRT_E_STATE, "not enough pushed samples: push more or lower max_attempts");
+        if (!(e->d_pool_count > 0 && e->cursor >= e->d_pool_base && need_end <= e->d_pool_base + e->d_pool_count)) {
+            const int n = e->n;
+            const int64_t off = e->cursor - e->pool_base;
+            const int64_t cnt = (int64_t)e->pool_rows_end.size() - off;
+            if (cnt > e->d_pool_cap) {
+                if (e->d_pool) (void)hipFree(e->d_pool);
+                e->d_pool_cap = cnt + cnt / 2;
+                TRY(dalloc(&e->d_pool, (size_t)e->d_pool_cap * n));
+            }
+            HIPCHK(hipMemcpyAsync(e->d_pool, e->pool.data() + off * n, sizeof(double) * cnt * n, hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+            e->d_pool_base = e->cursor;
+            e->d_pool_count = cnt;
+        }
+        return 0;
+    }
     if (!e->has_sampler) return fail(LQRRT_E_STATE, "set_sampler first");
     if (!e->has_goal) return fail(LQRRT_E_STATE, "no goal set");
     const int n = e->n;
@@ -847,6 +880,31 @@ static int ensure_samples(lqrrt_engine* e, int64_t need_end, hipStream_t st) {
     e->d_pool_base = e->cursor;
     e->d_pool_count = cnt;
     return 0;
+}
+
+extern "C" int lqrrt_engine_push_samples(lqrrt_engine* e, const double* xs_host, int count) {
+    // explicit sample stream (a user xrand_gen function, planner.py:213-216): appended after what is queued
+    if (!e || (count > 0 && !xs_host) || count < 0) return fail(LQRRT_E_ARG, "bad argument");
+    if (!e->explicit_samples) {
+        e->pool.clear(); e->pool_rows_end.clear();
+        e->pool_base = e->cursor; e->d_pool_count = 0; e->tries_carry = 0;
+        e->explicit_samples = true;
+    }
+    if (e->cursor > e->pool_base) {                 // drop what was consumed
+        const int64_t drop = std::min<int64_t>(e->cursor - e->pool_base, (int64_t)e->pool_rows_end.size());
+        e->pool.erase(e->pool.begin(), e->pool.begin() + drop * e->n);
+        e->pool_rows_end.erase(e->pool_rows_end.begin(), e->pool_rows_end.begin() + drop);
+        e->pool_base += drop;
+    }
+    e->pool.insert(e->pool.end(), xs_host, xs_host + (size_t)count * e->n);
+    for (int i = 0; i < count; ++i) e->pool_rows_end.push_back(e->committed_row);
+    e->d_pool_count = 0;                            // force a re-upload
+    return 0;
+}
+
+extern "C" int lqrrt_engine_queued_samples(lqrrt_engine* e) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    return (int)(e->pool_base + (int64_t)e->pool_rows_end.size() - e->cursor);
 }
 
 static const double* wave_samples(const lqrrt_engine* e) {
@@ -1061,6 +1119,11 @@ extern "C" int lqrrt_engine_extend(lqrrt_engine* e, int wave, int64_t max_attemp
         int W = pick_wave(e, wave);
         int64_t cap_attempts = max_attempts >= 0 ? max_attempts - acc.attempts : (int64_t)W;
         if ((int64_t)W > cap_attempts) W = (int)cap_attempts;
+        if (e->explicit_samples) {
+            const int64_t queued = e->pool_base + (int64_t)e->pool_rows_end.size() - e->cursor;
+            if (queued <= 0) { acc.stop_reason = LQRRT_STOP_ATTEMPTS; break; }
+            if ((int64_t)W > queued) W = (int)queued;
+        }
         int64_t lim = node_limit;
         if (until_size > 0) {
             const int64_t l2 = (int64_t)until_size - 1;   // stop once size >= until_size  <=> size > until_size-1

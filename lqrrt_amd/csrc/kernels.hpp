@@ -432,6 +432,58 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
 }
 
 // ------------------------------------------------------------------------------------------
+// Planner._steer(ID, xtar, force_arrive=True) (planner.py:354-410): no horizon and no error_tol; the
+// rollout stops when the new state is np.allclose to the target (rtol, atol; that step is NOT
+// recorded, :409-410 break before :432), when a step is infeasible (FPR truncation, :393-396), or
+// after max_steps -- a deterministic stand-in for the reference's wall-clock timeout (:402-406).
+// One wavefront; recorded steps go straight to xseq [max_steps][n], useq [max_steps][m]; out[0] = len.
+template <class S>
+__global__ __launch_bounds__(64) void k_steer_force(Params P, Geo g, Res r, TreeView tv, int parent,
+                                                    const double* __restrict__ xtar, int max_steps, double rtol, double atol,
+                                                    int* __restrict__ out_len, double* __restrict__ xseq, double* __restrict__ useq) {
+    extern __shared__ double geo_lds[];
+    const int lane = threadIdx.x;
+    const GeoL gl = stage_geo(g, geo_lds, lane, 64);
+    __syncthreads();
+    double x[S::N], K[S::M * S::N], trig[2 * S::NW + 1], xt[S::N], ttrig[2 * S::NW + 1];
+#pragma unroll
+    for (int d = 0; d < S::N; ++d) { xt[d] = xtar[d]; x[d] = tv.state[(size_t)d * tv.cap + parent]; }
+    trig_of<S>(xt, ttrig);
+#pragma unroll
+    for (int j = 0; j < 2 * S::NW; ++j) trig[j] = tv.trig[(size_t)j * tv.cap + parent];
+#pragma unroll
+    for (int j = 0; j < S::M * S::N; ++j) K[j] = tv.K[(size_t)parent * S::M * S::N + j];
+    int cnt = 0;
+    while (cnt < max_steps) {
+        double e[S::N], u[S::M], uc[S::M], xn[S::N], trn[2 * S::NW + 1];
+        erf_cached<S>(xt, ttrig, x, trig, e);
+#pragma unroll
+        for (int i = 0; i < S::M; ++i) {
+            double a = K[i * S::N] * e[0];
+#pragma unroll
+            for (int j = 1; j < S::N; ++j) a += K[i * S::N + j] * e[j];
+            u[i] = a; uc[i] = a;
+        }
+        S::step(P.p, x, trig, uc, r.dt, xn);
+        trig_of<S>(xn, trn);
+        if (!S::feasible(P.p, g, gl, xn, u, trn, lane)) { cnt = (int)(r.FPR * (double)cnt); break; }
+        bool close = true;                                       // np.allclose(x, xtar, rtol, atol)
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) close = close && (fabs(xn[d] - xt[d]) <= atol + rtol * fabs(xt[d]));
+        if (close) break;
+        store_uniform<S::N>(xseq + (size_t)cnt * S::N, xn, lane);
+        store_uniform<S::M>(useq + (size_t)cnt * S::M, u, lane);
+        ++cnt;
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) x[d] = xn[d];
+#pragma unroll
+        for (int j = 0; j < 2 * S::NW; ++j) trig[j] = trn[j];
+        S::gain(P.p, x, trig, u, K);
+    }
+    if (lane == 0) out_len[0] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------
 // Tree root (tree.py:50-73 via planner.py:172): state, trig, K = lqr(x0, 0)[1], pID -1, edge = [x0],[0].
 template <class S>
 __global__ void k_tree_root(Params P, TreeView tv, const double* __restrict__ x0) {

@@ -243,6 +243,27 @@ class Engine(object):
                                               us.data_ptr(), xe.data_ptr(), Ke.data_ptr(), nat.current_stream()))
         return ln.cpu().numpy(), xs.cpu().numpy(), us.cpu().numpy(), xe.cpu().numpy(), Ke.cpu().numpy()
 
+    def steer_force(self, parent, xtar, max_steps, rtol=1e-4, atol=1e-4):
+        torch = _torch()
+        dev = "cuda:%d" % self.device
+        dx = self._dev(xtar, (self.n,))
+        ln = torch.zeros(1, dtype=torch.int32, device=dev)
+        xs = torch.empty((max_steps, self.n), dtype=torch.float64, device=dev)
+        us = torch.empty((max_steps, self.m), dtype=torch.float64, device=dev)
+        nat.check(nat.lib().lqrrt_steer_force(self.h, int(parent), dx.data_ptr(), int(max_steps), float(rtol), float(atol),
+                                              ln.data_ptr(), xs.data_ptr(), us.data_ptr(), nat.current_stream()))
+        k = int(ln.cpu()[0])
+        return xs[:k].cpu().numpy(), us[:k].cpu().numpy()
+
+    def push_samples(self, xs):
+        xs = nat.as_f64(xs)
+        if xs.ndim != 2 or xs.shape[1] != self.n:
+            raise ValueError("expected samples of shape (count, %d)" % self.n)
+        nat.check(nat.lib().lqrrt_engine_push_samples(self.h, nat.ptr(xs), len(xs)))
+
+    def queued_samples(self):
+        return nat.check(nat.lib().lqrrt_engine_queued_samples(self.h))
+
     # -- wave engine -----------------------------------------------------------------------------
     def record_layout(self):
         lay = np.zeros(11, dtype=np.int32)

@@ -140,9 +140,12 @@ class Planner:
             sampling_centers = np.mean(sample_space, axis=1)
             sampling_spans = np.diff(sample_space).flatten()
         else:
+            # A user sampling function (planner.py:213-216).  It is called once per sample, in order, but a
+            # whole batch ahead of the wave that consumes it, so it sees the tree as of the batch start
+            # rather than of the previous iteration (documented deviation; the default sampler never looks
+            # at the tree, so it is unaffected).
             if not hasattr(xrand_gen, '__call__'):
                 raise ValueError("Expected xrand_gen to be None, an integer >= 1,  or a function.")
-            raise NotImplementedError("a Python xrand_gen function cannot drive the on-device sampler yet")
 
         # Store guide state
         if guide is None:
@@ -155,8 +158,10 @@ class Planner:
         eng.set_resolution(self.dt, self.FPR, self.horizon_iters, self.error_tol, self.goal,
                            self.constraints.goal_buffer)
         eng.tree_reset(x0)
-        eng.set_sampler(sampling_centers, sampling_spans, np.array(goal_bias, dtype=np.float64), tries_limit)
-        eng.seed_from_numpy_global()
+        user_sampler = hasattr(xrand_gen, '__call__')
+        if not user_sampler:
+            eng.set_sampler(sampling_centers, sampling_spans, np.array(goal_bias, dtype=np.float64), tries_limit)
+            eng.seed_from_numpy_global()
         self.tree = Tree(eng)
 
         if self.printing:
@@ -170,7 +175,12 @@ class Planner:
 
         # Planning loop: each native call grows the tree by a few waves and returns at every goal hit
         while True:
-            st = eng.extend(self.wave_size, max_attempts=4 * self.wave_size, node_limit=int(self.max_nodes),
+            budget = 4 * self.wave_size
+            if user_sampler:
+                missing = budget - eng.queued_samples()
+                if missing > 0:
+                    eng.push_samples(np.array([np.array(xrand_gen(self), dtype=np.float64) for _ in range(missing)]))
+            st = eng.extend(self.wave_size, max_attempts=budget, node_limit=int(self.max_nodes),
                             pruning=pruning, stop_on_goal=True)
             total = st if total is None else _add_stats(total, st)
 
@@ -210,7 +220,8 @@ class Planner:
                 self._prepare_interpolators()
                 break
 
-        eng.sync_numpy_global()
+        if not user_sampler:
+            eng.sync_numpy_global()
         self.stats = total.as_dict() if total is not None else None
 
         if self.killed or self.tree.size > self.max_nodes:
@@ -233,9 +244,26 @@ class Planner:
         self.t_seq = np.arange(len(self.x_seq)) * self.dt
 
     def _finish_on_goal(self):
-        """planner.py:294-303 (force-arrive steer into the exact goal) -- not on the device yet."""
-        if self.printing:
-            print("(finish_on_goal: exact goal-convergence steer is not available on the device yet)")
+        """
+        planner.py:294-303: steer from the plan's last node to the exact goal (force_arrive) and, if that
+        produced anything, tack it onto the plan and the tree.  The reference stops this rollout on a
+        wall-clock timeout of clip(min_time/2, 0.1, inf) seconds (:402-406); here the same budget is turned
+        into a step cap at the reference's measured ~0.3 ms per simulated step, which is deterministic.
+        """
+        budget_s = float(np.clip(self.min_time / 2, 0.1, np.inf))
+        max_steps = int(min(max(budget_s / 3e-4, 64), 20000))
+        if getattr(self, "force_arrive_max_steps", None):
+            max_steps = int(self.force_arrive_max_steps)        # explicit override of the timeout stand-in
+        xgoal_seq, ugoal_seq = self._engine.steer_force(self.node_seq[-1], self.goal, max_steps)
+        if len(xgoal_seq) == max_steps and self.printing:
+            print("(exact goal-convergence timed-out)")
+        if len(xgoal_seq) > 0:
+            xs, us = [row for row in xgoal_seq], [row for row in ugoal_seq]
+            self.tree.add_node(self.node_seq[-1], self.goal, None, xs, us)
+            self.node_seq.append(self.tree.size - 1)
+            self.x_seq.extend(xs)
+            self.u_seq.extend(us)
+            self.t_seq = np.arange(len(self.x_seq)) * self.dt
 
     def _in_goal(self, x):
         """Returns True if some state x is in the goal region (planner.py:442-447)."""

@@ -44,6 +44,9 @@ class _LqrSeq(object):
         ID = int(ID)
         if ID < 0:
             ID += len(self)
+        base = self._tree._e.size
+        if ID >= base:
+            return self._tree._extra[ID - base][2]
         return (self._tree._S, self._tree._gains()[ID])
 
 
@@ -61,16 +64,17 @@ class Tree:
         self._S = engine.system.Smatrix()
         self._cache = {}
         self._cache_size = -1
+        self._extra = []          # host-side nodes appended after planning (finish_on_goal, planner.py:299)
         self.x_seq = _EdgeSeq(self, 0)
         self.u_seq = _EdgeSeq(self, 1)
         self.lqr = _LqrSeq(self)
 
     @property
     def size(self):
-        return self._e.size
+        return self._e.size + len(self._extra)
 
     def _fresh(self):
-        n = self.size
+        n = self._e.size
         if n != self._cache_size:
             self._cache = {}
             self._cache_size = n
@@ -81,6 +85,8 @@ class Tree:
         c = self._fresh()
         if "state" not in c:
             c["state"] = self._e.states()
+        if self._extra:
+            return np.vstack([c["state"]] + [np.asarray(x[1], dtype=np.float64) for x in self._extra])
         return c["state"]
 
     @property
@@ -88,6 +94,8 @@ class Tree:
         c = self._fresh()
         if "pID" not in c:
             c["pID"] = self._e.parents().tolist()
+        if self._extra:
+            return c["pID"] + [int(x[0]) for x in self._extra]
         return c["pID"]
 
     def _gains(self):
@@ -98,6 +106,9 @@ class Tree:
 
     def _edge(self, ID):
         c = self._fresh()
+        if ID >= self._e.size and ID - self._e.size < len(self._extra):
+            x = self._extra[ID - self._e.size]
+            return (x[3], x[4])
         key = ("edge", ID)
         if key not in c:
             if ID >= self.size or ID < 0:
@@ -107,7 +118,13 @@ class Tree:
         return c[key]
 
     def add_node(self, pID, state, lqr, x_seq, u_seq):
-        raise NotImplementedError("nodes are appended on the device by the planner's waves")
+        """
+        tree.py:77-96.  During planning nodes are appended on the device by the waves; this host-side
+        append exists for what the reference adds afterwards (the finish_on_goal node, planner.py:299).
+        """
+        if pID >= self.size or pID < 0:
+            raise ValueError("The given parent ID, {}, doesn't exist.".format(pID))
+        self._extra.append((pID, state, lqr, x_seq, u_seq))
 
     def climb(self, ID):
         """

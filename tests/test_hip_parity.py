@@ -310,3 +310,43 @@ def test_full_size_invariants_boat_advanced_10k():
     assert chain[0] == 0 and chain[-1] == end and steps == int(elen[chain].sum())
     px, pu = p.tree.trajectory(chain)
     assert len(px) == steps == len(pu)
+
+
+def test_finish_on_goal_and_user_sampler():
+    """planner.py:294-303 (force-arrive steer into the exact goal) and :213-216 (xrand_gen function)."""
+    from systems_np import SYSTEMS, make_oracle_planner
+    s = _system("boat_novice")
+    p = _planner(s, 4000, wave_size=256, min_time=0, max_time=1)
+    p.force_arrive_max_steps = 20000        # the oracle's fake clock never times out, so do not cap the rollout either
+    np.random.seed(1)
+    assert p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10, finish_on_goal=True) is True
+    rs = SYSTEMS["boat_novice"](0)
+    ref = make_oracle_planner(rs, 4000, min_time=0, max_time=1)
+    np.random.seed(1)
+    assert ref.update_plan(rs.x0, rs.sample_space, goal_bias=rs.goal_bias, xrand_gen=10, finish_on_goal=True) is True
+    assert p.plan_reached_goal and ref.plan_reached_goal
+    assert list(p.node_seq) == list(ref.node_seq)
+    assert p.tree.size == ref.tree.size and list(p.tree.pID) == list(ref.tree.pID)
+    np.testing.assert_array_equal(p.tree.state[-1], np.array(s.goal, dtype=np.float64))   # the added node IS the goal
+    assert len(p.x_seq) == len(ref.x_seq) and p.T == ref.T
+    np.testing.assert_allclose(np.array(p.x_seq), np.array(ref.x_seq), rtol=0, atol=ATOL)
+    np.testing.assert_allclose(np.array(p.u_seq), np.array(ref.u_seq), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(p.get_state(p.t_seq[-1] + 5.0), p.x_seq[-1], rtol=0, atol=1e-12)   # fill_value past the end
+    assert len(p.tree.x_seq[p.tree.size - 1]) == len(ref.tree.x_seq[-1])
+
+    # a user sampling function: replay the default sampler's own samples through xrand_gen
+    c = _system("car")
+    pa = _planner(c, 600, wave_size=128)
+    np.random.seed(2)
+    pa.update_plan(c.x0, c.sample_space, goal_bias=c.goal_bias, xrand_gen=10)
+    rc = SYSTEMS["car"](0)
+    refc = make_oracle_planner(rc, 600, min_time=2, max_time=3)
+    np.random.seed(2)
+    refc.update_plan(rc.x0, rc.sample_space, goal_bias=rc.goal_bias, xrand_gen=10, trace=True)
+    samples = iter(refc.trace["xrand"] + [refc.trace["xrand"][-1]] * 4096)
+    pb = _planner(c, 600, wave_size=128)
+    pb.update_plan(c.x0, c.sample_space, xrand_gen=lambda planner: next(samples))
+    assert list(pb.tree.pID) == list(pa.tree.pID) == list(refc.tree.pID)
+    np.testing.assert_array_equal(pb.tree.state, pa.tree.state)
+    with pytest.raises(ValueError):
+        pb.update_plan(c.x0, c.sample_space, xrand_gen="nope")                              # planner.py:216
