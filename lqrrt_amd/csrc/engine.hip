@@ -128,12 +128,15 @@ struct lqrrt_engine {
     double* d_rec = nullptr;
     double *d_pcost = nullptr, *d_pcost_all = nullptr, *d_wcost = nullptr;
     int *d_pidx = nullptr, *d_pidx_all = nullptr, *d_wid = nullptr;
-    int *d_par_done = nullptr, *d_par_want = nullptr, *d_list = nullptr, *d_rank = nullptr;
+    int *d_par_done = nullptr, *d_par_want = nullptr, *d_list = nullptr;
     unsigned char *d_changed = nullptr, *d_stale = nullptr, *d_need = nullptr;
-    unsigned long long* d_wmask = nullptr;
-    int* d_summary = nullptr;     // [4 + 3*maxW]: ctrl (listed, deferred, horizon, -) + len/flags/parent
-    int* h_summary = nullptr;     // pinned
-    int* h_rank = nullptr;        // pinned
+    int* d_summary = nullptr;     // [4]: device-side copy of the listed count (index 0)
+    int* h_summary = nullptr;     // pinned + mapped [4 + 3*maxW]: ctrl (listed, deferred, horizon, seq) + len/flags/parent
+    int* h_summary_dev = nullptr; // device address of h_summary
+    int* h_rank = nullptr;        // pinned + mapped [maxW]
+    int* h_rank_dev = nullptr;
+    int seq = 0;                  // sequence number of the last k_decide
+    bool wave_complete = false;   // the last speculate covered the whole wave (single-GPU path)
     static constexpr int MAXCH = 1024;
 
     // sample stream
@@ -288,7 +291,7 @@ static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
 // NN over a node table for W samples at xs (device, [W][n]); writes id/cost and/or records.
 static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int W, const double* Sd,
                      bool tri, bool want_all, int* out_id, double* out_cost, double* rec, hipStream_t st,
-                     bool profile, int* n_chunks_out = nullptr) {
+                     bool profile, int* n_chunks_out = nullptr, int wave_lo = -1) {
     if (W <= 0) return 0;
     int chunk, n_chunks;
     if (tri) { chunk = 16; n_chunks = (nv.count + 15) / 16; }   // in-wave pass: the reduction is fused into k_decide
@@ -312,7 +315,9 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     if (profile) prof_end(e, st, &ev, 0, (double)W * (double)nv.count * (8.0 * e->n + 1.0));
     if (tri) { HIPCHK(hipGetLastError()); return 0; }
     hipLaunchKernelGGL(k_nn_reduce, dim3(W), dim3(64), 0, st, e->d_pcost, e->d_pidx, pca, pia, W,
-                       n_chunks, out_id, out_cost, rec, e->L.R, e->L.off_cost, e->L.off_parent);
+                       n_chunks, out_id, out_cost, rec, e->L.R, e->L.off_cost, e->L.off_parent,
+                       wave_lo >= 0 ? e->d_par_done + wave_lo : nullptr, wave_lo >= 0 ? e->d_changed + wave_lo : nullptr,
+                       wave_lo >= 0 ? e->d_stale + wave_lo : nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -345,8 +350,8 @@ extern "C" int lqrrt_device_count(void) {
 static void free_all(lqrrt_engine* e) {
     void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_S, e->tv.state, e->tv.trig, e->tv.K, e->tv.pID, e->tv.elen,
                     e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_pcost_all, e->d_wcost,
-                    e->d_pidx, e->d_pidx_all, e->d_wid, e->d_par_done, e->d_par_want, e->d_list, e->d_rank,
-                    e->d_changed, e->d_stale, e->d_need, e->d_wmask, e->d_summary, e->d_pool, e->d_cand, e->d_flags};
+                    e->d_pidx, e->d_pidx_all, e->d_wid, e->d_par_done, e->d_par_want, e->d_list,
+                    e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_cand, e->d_flags};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_summary) (void)hipHostFree(e->h_summary);
@@ -441,16 +446,19 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     if (!rc) rc = dalloc(&e->d_par_done, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_par_want, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_list, (size_t)e->maxW);
-    if (!rc) rc = dalloc(&e->d_rank, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_changed, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_stale, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_need, (size_t)e->maxW);
-    if (!rc) rc = dalloc(&e->d_wmask, (size_t)e->maxW / 64 + 1);
-    if (!rc) rc = dalloc(&e->d_summary, (size_t)4 + 3 * e->maxW);
-    if (!rc && hipHostMalloc((void**)&e->h_summary, sizeof(int) * (4 + 3 * (size_t)e->maxW)) != hipSuccess)
+    if (!rc) rc = dalloc(&e->d_summary, (size_t)4);
+    const unsigned hflags = hipHostMallocMapped | hipHostMallocCoherent;
+    if (!rc && hipHostMalloc((void**)&e->h_summary, sizeof(int) * (4 + 3 * (size_t)e->maxW), hflags) != hipSuccess)
         rc = fail(LQRRT_E_HIP, "hipHostMalloc failed");
-    if (!rc && hipHostMalloc((void**)&e->h_rank, sizeof(int) * (size_t)e->maxW) != hipSuccess)
+    if (!rc && hipHostMalloc((void**)&e->h_rank, sizeof(int) * (size_t)e->maxW, hflags) != hipSuccess)
         rc = fail(LQRRT_E_HIP, "hipHostMalloc failed");
+    if (!rc && (hipHostGetDevicePointer((void**)&e->h_summary_dev, e->h_summary, 0) != hipSuccess ||
+                hipHostGetDevicePointer((void**)&e->h_rank_dev, e->h_rank, 0) != hipSuccess))
+        rc = fail(LQRRT_E_HIP, "hipHostGetDevicePointer failed");
+    if (!rc) memset(e->h_summary, 0, sizeof(int) * 4);
     if (!rc) rc = alloc_wave(e);
     if (rc) { free_all(e); delete e; return rc; }
     e->h_pid.reserve(e->cap); e->h_elen.reserve(e->cap);
@@ -928,15 +936,6 @@ extern "C" int lqrrt_wave_records(lqrrt_engine* e, void** p) {
     return 0;
 }
 
-__global__ void k_init_wave(const double* __restrict__ rec, RecLayout L, int W, int lo, int hi, int* __restrict__ par_done,
-                            unsigned char* __restrict__ changed, unsigned char* __restrict__ stale) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= W) return;
-    if (t >= lo && t < hi) par_done[t] = (int)rec[(size_t)t * L.R + L.off_parent];
-    changed[t] = 0;
-    stale[t] = 0;
-}
-
 extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void* stream) {
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     if (W < 1 || W > e->maxW || lo < 0 || hi > W || lo > hi) return fail(LQRRT_E_ARG, "bad wave slice");
@@ -949,15 +948,16 @@ extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void
     TRY(flush_ignore(e, st));
     const double* xs = wave_samples(e);
     const int cnt = hi - lo;
+    const bool whole = (lo == 0 && hi == W);
     if (cnt > 0) {
-        // snapshot NN for the slice: records lo..hi-1 get (cost, parent)
+        // snapshot NN for the slice: records lo..hi-1 get (cost, parent); the reduce also initialises the
+        // slice's wave bookkeeping (parent-in-use, changed, stale)
         TRY(launch_nn(e, tree_view(e, true), xs + (size_t)lo * e->n, cnt, nullptr, false, true, nullptr, nullptr,
-                      e->d_rec + (size_t)lo * e->L.R, st, true));
+                      e->d_rec + (size_t)lo * e->L.R, st, true, nullptr, lo));
+        TRY(launch_steer(e, xs, nullptr, lo, cnt, e->d_par_done, st));
     }
-    hipLaunchKernelGGL(k_init_wave, dim3((W + 255) / 256), dim3(256), 0, st, e->d_rec, e->L, W, lo, hi, e->d_par_done,
-                       e->d_changed, e->d_stale);
-    if (cnt > 0) TRY(launch_steer(e, xs, nullptr, lo, cnt, e->d_par_done, st));
     HIPCHK(hipGetLastError());
+    e->wave_complete = whole;
     e->tot.speculated += cnt;
     return 0;
 }
@@ -993,6 +993,22 @@ static void tune_wave(lqrrt_engine* e, int W, const lqrrt_extend_stats& ws, int 
     e->ctl_w = w;
 }
 
+// Waits until k_decide number e->seq has published ctrl/summary into pinned host memory.  Spinning on
+// the sequence word costs ~2 us; a hipMemcpyAsync + hipStreamSynchronize round trip costs ~25 us.
+static int wait_summary(lqrrt_engine* e, hipStream_t st) {
+    volatile int* flag = e->h_summary + 3;
+    for (long spin = 0;; ++spin) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == e->seq) return 0;
+        if ((spin & 0xfffff) == 0xfffff) {                     // every ~1M polls: make sure the stream is still alive
+            hipError_t q = hipStreamQuery(st);
+            if (q != hipSuccess && q != hipErrorNotReady)
+                return fail(LQRRT_E_HIP, "stream failed while waiting for the wave summary: %s", hipGetErrorString(q));
+            if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != e->seq)
+                return fail(LQRRT_E_HIP, "wave summary was not published (sequence %d)", e->seq);
+        }
+    }
+}
+
 extern "C" int lqrrt_wave_suggest(lqrrt_engine* e, int wave_cap) {
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     if (wave_cap < 1) return fail(LQRRT_E_ARG, "wave_cap must be >= 1");
@@ -1010,10 +1026,13 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     memset(&ws, 0, sizeof ws);
     ws.waves = 1;
 
-    // parents of records that came from other ranks (all-gather) are only in the records
-    hipLaunchKernelGGL(k_par_from_records, dim3((W + 255) / 256), dim3(256), 0, st, e->d_rec, e->L, W, e->d_par_done);
-    HIPCHK(hipMemsetAsync(e->d_changed, 0, W, st));
-    HIPCHK(hipMemsetAsync(e->d_stale, 0, W, st));
+    if (!e->wave_complete) {
+        // sharded wave: parents of the records that came from other ranks (all-gather) are only in the records
+        hipLaunchKernelGGL(k_par_from_records, dim3((W + 255) / 256), dim3(256), 0, st, e->d_rec, e->L, W, e->d_par_done);
+        HIPCHK(hipMemsetAsync(e->d_changed, 0, W, st));
+        HIPCHK(hipMemsetAsync(e->d_stale, 0, W, st));
+    }
+    e->wave_complete = false;
 
     const int guard = 4 * W + 8;
     int rounds = 0;
@@ -1026,11 +1045,10 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
             HIPCHK(hipMemsetAsync(e->d_pcost, 0x7f, sizeof(double), st));    // large finite cost
         }
         hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, st, e->d_rec, e->L, W, e->d_pcost, e->d_pidx, n_chunks, 16,
-                           e->d_par_done, e->d_par_want, e->d_changed, e->d_stale, e->d_need, e->d_list, e->d_summary,
-                           e->d_summary + 4);
+                           e->d_par_done, e->d_par_want, e->d_changed, e->d_stale, e->d_need, e->d_list, e->h_summary_dev,
+                           e->h_summary_dev + 4, e->d_summary, ++e->seq);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(e->h_summary, e->d_summary, sizeof(int) * (4 + 3 * (size_t)W), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        TRY(wait_summary(e, st));
         const int n_list = e->h_summary[0], n_defer = e->h_summary[1];
         if (getenv("LQRRT_TRACE")) fprintf(stderr, "[wave N=%d W=%d] round %d: list=%d defer=%d horizon=%d\n", e->N, W, rounds, n_list, n_defer, e->h_summary[2]);
         if (n_list == 0 && n_defer == 0) break;
@@ -1062,8 +1080,8 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     if (e->N + acc > e->cap) return fail(LQRRT_E_CAPACITY, "tree capacity exceeded");
     const int base = e->N;
     if (acc > 0) {
-        HIPCHK(hipMemcpyAsync(e->d_rank, e->h_rank, sizeof(int) * W, hipMemcpyHostToDevice, st));
-        DISPATCH(e, hipLaunchKernelGGL((k_append<S>), dim3(C), dim3(64), 0, st, e->tv, e->d_rec, e->L, C, base, e->d_rank, e->d_par_done));
+        // ranks are read by the kernel straight from pinned host memory (written before the launch)
+        DISPATCH(e, hipLaunchKernelGGL((k_append<S>), dim3(C), dim3(64), 0, st, e->tv, e->d_rec, e->L, C, base, e->h_rank_dev, e->d_par_done));
         HIPCHK(hipGetLastError());
     }
     // host mirrors + goal bookkeeping (planner.py:260-283)

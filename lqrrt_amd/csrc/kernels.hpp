@@ -72,16 +72,16 @@ __host__ __device__ inline RecLayout make_layout(int n, int m, int nw, int H) {
 }
 
 // Stores a wave-uniform register array: lane j writes element j (and j+64, ... for longer arrays).
-// The select chain keeps the array in registers (no dynamic indexing -> no scratch).
-template <int CNT>
+// The select chain has compile-time bounds, so the array stays in registers (no dynamic indexing,
+// no scratch).
+template <int CNT, int BASE = 0>
 __device__ __forceinline__ void store_uniform(double* dst, const double* a, int lane) {
+    constexpr int END = (BASE + 64 < CNT) ? BASE + 64 : CNT;
+    double v = a[BASE];
 #pragma unroll
-    for (int base = 0; base < CNT; base += 64) {
-        double v = a[base];
-#pragma unroll
-        for (int j = base + 1; j < (base + 64 < CNT ? base + 64 : CNT); ++j) v = (lane == j - base) ? a[j] : v;
-        if (base + lane < CNT) dst[base + lane] = v;
-    }
+    for (int j = BASE + 1; j < END; ++j) v = (lane == j - BASE) ? a[j] : v;
+    if (BASE + lane < CNT) dst[BASE + lane] = v;
+    if constexpr (END < CNT) store_uniform<CNT, END>(dst, a, lane);
 }
 
 template <class S>
@@ -213,7 +213,9 @@ __device__ __forceinline__ void lexmin_wave(double& c, int& i) {
 __global__ __launch_bounds__(64) void k_nn_reduce(const double* __restrict__ pcost, const int* __restrict__ pidx,
                                                   const double* __restrict__ pcost_all, const int* __restrict__ pidx_all,
                                                   int W, int n_chunks, int* __restrict__ out_id, double* __restrict__ out_cost,
-                                                  double* __restrict__ rec, int R, int off_cost, int off_parent) {
+                                                  double* __restrict__ rec, int R, int off_cost, int off_parent,
+                                                  int* __restrict__ par_done, unsigned char* __restrict__ changed,
+                                                  unsigned char* __restrict__ stale) {
     const int t = blockIdx.x;
     if (t >= W) return;
     const int lane = threadIdx.x;
@@ -243,6 +245,7 @@ __global__ __launch_bounds__(64) void k_nn_reduce(const double* __restrict__ pco
             rec[(size_t)t * R + off_cost] = fallback ? INFINITY : b;
             rec[(size_t)t * R + off_parent] = (double)bi;
         }
+        if (par_done) { par_done[t] = bi; changed[t] = 0; stale[t] = 0; }   // wave bookkeeping starts here
     }
 }
 
@@ -395,8 +398,12 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= r.tol[d]);
         if (steps > r.H || conv) break;                          // planner.py:428
         // record (planner.py:432-433): lane d keeps component d
-        store_uniform<S::N>(hx + cnt * S::N, xn, lane);
-        store_uniform<S::M>(hu + cnt * S::M, u, lane);
+        if (lane == 0) {                                         // wave-uniform values: one lane writes the LDS history
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) hx[cnt * S::N + d] = xn[d];
+#pragma unroll
+            for (int j = 0; j < S::M; ++j) hu[cnt * S::M + j] = u[j];
+        }
         ++cnt;
 #pragma unroll
         for (int d = 0; d < S::N; ++d) x[d] = xn[d];
@@ -510,13 +517,15 @@ __global__ void k_tree_root(Params P, TreeView tv, const double* __restrict__ x0
 //   redo when want differs from the parent the record was computed with, when that in-wave parent
 //   was itself recomputed last round, or when a redo was deferred.  A redo whose in-wave parent is
 //   also redone this round is deferred (its start state is about to change).
-// ctrl[0]=listed, ctrl[1]=deferred, ctrl[2]=L; summary[0..3W) = len, flags, parent per sample.
+// ctrl[0]=listed, ctrl[1]=deferred, ctrl[2]=L, ctrl[3]=sequence number (written last);
+// summary[0..3W) = len, flags, parent per sample.
 __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ rec, RecLayout L, int W,
                                                  const double* __restrict__ pcost, const int* __restrict__ pidx, int n_chunks, int chunk,
                                                  int* __restrict__ par_done, int* __restrict__ par_want,
                                                  unsigned char* __restrict__ changed, unsigned char* __restrict__ stale,
                                                  unsigned char* __restrict__ need, int* __restrict__ list,
-                                                 int* __restrict__ ctrl, int* __restrict__ summary) {
+                                                 int* __restrict__ ctrl, int* __restrict__ summary, int* __restrict__ dev_count,
+                                                 int seq) {
     __shared__ int n_list, n_defer, horizon;
     if (threadIdx.x == 0) { n_list = 0; n_defer = 0; horizon = W - 1; }
     __syncthreads();
@@ -569,7 +578,16 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ rec,
     }
     __syncthreads();
     for (int t = threadIdx.x; t < W; t += blockDim.x) summary[2 * W + t] = par_done[t];
-    if (threadIdx.x == 0) { ctrl[0] = n_list; ctrl[1] = n_defer; ctrl[2] = hz; }
+    // ctrl/summary live in pinned host memory: publish them with a system-scope release so that the
+    // host, which spins on ctrl[3] == seq, never needs a copy or a stream synchronisation.
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        dev_count[0] = n_list;                       // read by the re-steer launch that follows
+        ctrl[0] = n_list; ctrl[1] = n_defer; ctrl[2] = hz;
+        __threadfence_system();
+        __hip_atomic_store(&ctrl[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Append the first C samples' accepted records to the tree (tree.py:77-96).  rank[t] = number of
