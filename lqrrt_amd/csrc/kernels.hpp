@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
     // one node = N state doubles + 2*NW trig doubles + 1 eligibility flag, padded to an even count so
     // that every node starts 16-byte aligned in LDS (ds_read_b128 broadcasts)
     constexpr int NV = S::N + 2 * S::NW;
-    constexpr int NVP = (NV + 2) & ~1;
+    constexpr int NVP = (NV + 1 + S::NW + 1) & ~1;      // + flag + one precomputed angle error per wrapped state
     __shared__ __attribute__((aligned(16))) double tile[64 * NVP];
     const int lane = threadIdx.x;
     const int t = blockIdx.x * 64 + lane;
@@ -152,6 +152,13 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
 #pragma unroll
     for (int d = 0; d < S::N; ++d) xg[d] = xs[(size_t)ts * S::N + d];
     trig_of<S>(xg, gtrig);
+    // When every sample of this wavefront has the same angular coordinates (e.g. the boat demos sample
+    // the heading over the empty interval (0,0), demo_boat_advanced.py:231), the angle error of a node is
+    // the same for all 64 lanes: compute it once per node while staging instead of once per pair.
+    bool same_angles = S::NW > 0;
+#pragma unroll
+    for (int j = 0; j < 2 * S::NW; ++j) same_angles = same_angles && (gtrig[j] == __shfl(gtrig[j], 0));
+    same_angles = S::NW > 0 && __all(same_angles) != 0;
 
     double best = INFINITY, best_all = INFINITY;
     int bidx = -1, bidx_all = -1;
@@ -169,6 +176,11 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
             if constexpr (TRI) ign = !(nv.len[(long long)i * nv.sn] > 0.0);
             else ign = nv.ignore ? ((nv.ignore[i >> 6] >> (i & 63)) & 1ull) != 0 : false;
             nd[NV] = ign ? 1.0 : 0.0;
+            if (same_angles) {
+#pragma unroll
+                for (int k = 0; k < S::NW; ++k)
+                    nd[NV + 1 + k] = wrap_err(gtrig[2 * k], gtrig[2 * k + 1], nd[S::N + 2 * k], nd[S::N + 2 * k + 1]);
+            }
         }
         __syncthreads();
 #pragma unroll 2
@@ -179,7 +191,14 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
             for (int d = 0; d < S::N; ++d) x[d] = nd[d];
 #pragma unroll
             for (int k = 0; k < 2 * S::NW; ++k) trig[k] = nd[S::N + k];
-            erf_cached<S>(xg, gtrig, x, trig, e);
+            if (same_angles) {
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) e[d] = xg[d] - x[d];
+#pragma unroll
+                for (int k = 0; k < S::NW; ++k) e[S::wd(k)] = nd[NV + 1 + k];
+            } else {
+                erf_cached<S>(xg, gtrig, x, trig, e);
+            }
             const double c = quad_cost<S, DENSE>(e, Sd);
             const int i = base + j;
             const bool ign = nd[NV] != 0.0;
