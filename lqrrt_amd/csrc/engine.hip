@@ -106,6 +106,8 @@ struct lqrrt_engine {
     double* d_vps = nullptr;
     double* d_obs = nullptr;
     double* d_oc = nullptr;       // derived circle table [O][4]
+    int* d_cell_start = nullptr;  // box obstacles: uniform grid (CSR) over the boxes' bounding volume
+    int* d_cell_items = nullptr;
     double* d_S = nullptr;        // dense system S (n x n) or null = identity
 
     // tree
@@ -198,6 +200,8 @@ static double exact_sq_threshold(double r) {
 
 static size_t geo_lds_bytes(const lqrrt_engine* e);
 
+static int build_box_grid(lqrrt_engine* e, const lqrrt_system_desc* sys);
+
 static bool model_dims(int model, int* n, int* m, int* nw) {
     switch (model) {
         case LQRRT_MODEL_BOAT_ADVANCED:
@@ -280,7 +284,8 @@ static void prof_flush(lqrrt_engine* e) {
 
 static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
     const int groups = (W + 63) / 64;
-    int want = 8192 / (groups > 0 ? groups : 1);
+    static const int target_waves = getenv("LQRRT_NN_WAVES") ? atoi(getenv("LQRRT_NN_WAVES")) : 2048;
+    int want = target_waves / (groups > 0 ? groups : 1);
     want = std::max(1, std::min(want, (int)lqrrt_engine::MAXCH));
     int c = (count + want - 1) / want;
     c = std::max(c, 8);
@@ -348,7 +353,7 @@ extern "C" int lqrrt_device_count(void) {
 }
 
 static void free_all(lqrrt_engine* e) {
-    void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_S, e->tv.state, e->tv.trig, e->tv.K, e->tv.pID, e->tv.elen,
+    void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_cell_start, e->d_cell_items, e->d_S, e->tv.state, e->tv.trig, e->tv.K, e->tv.pID, e->tv.elen,
                     e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_pcost_all, e->d_wcost,
                     e->d_pidx, e->d_pidx_all, e->d_wid, e->d_par_done, e->d_par_want, e->d_list,
                     e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_cand, e->d_flags};
@@ -370,6 +375,55 @@ static int alloc_wave(lqrrt_engine* e) {
     TRY(dalloc(&e->tv.uedge, (size_t)e->cap * e->H * e->m));
     TRY(dalloc(&e->d_rec, (size_t)e->maxW * e->L.R));
     HIPCHK(hipMemset(e->d_rec, 0, (size_t)e->maxW * e->L.R * sizeof(double)));
+    return 0;
+}
+
+// Uniform grid over the bounding volume of the box obstacles (BASELINE.json config 5: 100k boxes).  Every
+// box is registered in each cell it overlaps (closed intervals, one cell of slack), so "point inside some
+// box" is decided from the point's own cell only -- the same boolean as the brute-force sweep.
+static int build_box_grid(lqrrt_engine* e, const lqrrt_system_desc* sys) {
+    const int O = sys->n_obstacles;
+    const double* b = sys->obs;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, ext = 0.0;
+    for (int o = 0; o < O; ++o)
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = std::min(lo[d], b[6 * o + d]); hi[d] = std::max(hi[d], b[6 * o + 3 + d]);
+            ext = std::max(ext, b[6 * o + 3 + d] - b[6 * o + d]);
+        }
+    // cell edge: at least the largest box edge, and coarse enough for <= ~2M cells
+    double vol = 1.0;
+    for (int d = 0; d < 3; ++d) vol *= std::max(hi[d] - lo[d], 1e-9);
+    double cell = std::max(ext, std::cbrt(vol / std::max(1, std::min(O * 2, 2000000))));
+    if (!(cell > 0.0) || !std::isfinite(cell)) cell = 1.0;
+    int dim[3];
+    for (int d = 0; d < 3; ++d) dim[d] = std::max(1, (int)std::floor((hi[d] - lo[d]) / cell) + 1);
+    const size_t ncell = (size_t)dim[0] * dim[1] * dim[2];
+    auto cidx = [&](double v, int d) {
+        int c = (int)std::floor((v - lo[d]) / cell);
+        return std::min(std::max(c, 0), dim[d] - 1);
+    };
+    std::vector<int> count(ncell + 1, 0);
+    auto for_cells = [&](int o, auto&& fn) {
+        int c0[3], c1[3];
+        for (int d = 0; d < 3; ++d) {
+            c0[d] = std::max(cidx(b[6 * o + d], d) - 1, 0);          // one cell of slack on both sides
+            c1[d] = std::min(cidx(b[6 * o + 3 + d], d) + 1, dim[d] - 1);
+        }
+        for (int i = c0[0]; i <= c1[0]; ++i)
+            for (int j = c0[1]; j <= c1[1]; ++j)
+                for (int k = c0[2]; k <= c1[2]; ++k) fn(((size_t)i * dim[1] + j) * dim[2] + k);
+    };
+    for (int o = 0; o < O; ++o) for_cells(o, [&](size_t c) { count[c + 1]++; });
+    for (size_t c = 0; c < ncell; ++c) count[c + 1] += count[c];
+    std::vector<int> items((size_t)count[ncell] + 1), fill(count.begin(), count.end() - 1);
+    for (int o = 0; o < O; ++o) for_cells(o, [&](size_t c) { items[(size_t)fill[c]++] = o; });
+    TRY(dalloc(&e->d_cell_start, ncell + 1));
+    TRY(dalloc(&e->d_cell_items, items.size()));
+    HIPCHK(hipMemcpy(e->d_cell_start, count.data(), sizeof(int) * (ncell + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_cell_items, items.data(), sizeof(int) * items.size(), hipMemcpyHostToDevice));
+    e->geo.cell_start = e->d_cell_start; e->geo.cell_items = e->d_cell_items;
+    for (int d = 0; d < 3; ++d) { e->geo.glo[d] = lo[d]; e->geo.ghi[d] = hi[d]; e->geo.gdim[d] = dim[d]; }
+    e->geo.gcell = cell;
     return 0;
 }
 
@@ -429,6 +483,8 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
         rc = up(&e->d_oc, oc.data(), (size_t)4 * sys->n_obstacles);
         e->geo.oc = e->d_oc;
     }
+    e->geo.cell_start = nullptr; e->geo.cell_items = nullptr;
+    if (!rc && e->geo.stride == 6 && sys->n_obstacles > 0) rc = build_box_grid(e, sys);
     e->tv.cap = e->cap;
     if (!rc) rc = dalloc(&e->tv.state, (size_t)n * e->cap);
     if (!rc) rc = dalloc(&e->tv.trig, (size_t)(2 * nw + 1) * e->cap);

@@ -592,11 +592,16 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ rec,
             }
         }
         changed[t] = ch;
-        summary[t] = (int)rec[(size_t)t * L.R + L.off_len];
-        summary[W + t] = (int)rec[(size_t)t * L.R + L.off_flags];
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < W; t += blockDim.x) summary[2 * W + t] = par_done[t];
+    if (n_list == 0 && n_defer == 0) {
+        // converged: only now does the host need the per-sample summary (it commits from it)
+        for (int t = threadIdx.x; t < W; t += blockDim.x) {
+            summary[t] = (int)rec[(size_t)t * L.R + L.off_len];
+            summary[W + t] = (int)rec[(size_t)t * L.R + L.off_flags];
+            summary[2 * W + t] = par_done[t];
+        }
+    }
     // ctrl/summary live in pinned host memory: publish them with a system-scope release so that the
     // host, which spins on ctrl[3] == seq, never needs a copy or a stream synchronisation.
     __threadfence_system();

@@ -40,6 +40,10 @@ struct Geo {
     const double* vps;   // [2][V] body-frame hull points
     const double* obs;   // [O][stride] raw obstacles (circles [x,y,r] or boxes [lo3,hi3])
     const double* oc;    // [O][4] derived circle table (null for box obstacles)
+    const int* cell_start;   // box obstacles: CSR uniform grid over the boxes' bounding volume (or null)
+    const int* cell_items;
+    double glo[3], ghi[3], gcell;
+    int gdim[3];
     int V, O, stride, pad;
 };
 
@@ -359,9 +363,27 @@ struct DoubleIntegratorT {
     }
     __device__ static bool feasible(const double*, const Geo& g, const GeoL&, const double* x, const double*, const double*, int lane) {
         bool hit = false;
-        for (int o = lane; o < g.O; o += 64) {
-            const double* b = g.obs + (size_t)o * g.stride;
-            hit |= (x[0] >= b[0]) & (x[0] <= b[3]) & (x[1] >= b[1]) & (x[1] <= b[4]) & (x[2] >= b[2]) & (x[2] <= b[5]);
+        if (g.cell_start) {
+            // uniform grid: only the boxes registered in the point's cell can contain it
+            if (x[0] < g.glo[0] || x[0] > g.ghi[0] || x[1] < g.glo[1] || x[1] > g.ghi[1] || x[2] < g.glo[2] || x[2] > g.ghi[2])
+                return true;
+            int c[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                int v = (int)floor((x[d] - g.glo[d]) / g.gcell);
+                c[d] = v < 0 ? 0 : (v >= g.gdim[d] ? g.gdim[d] - 1 : v);
+            }
+            const size_t cell = ((size_t)c[0] * g.gdim[1] + c[1]) * g.gdim[2] + c[2];
+            const int i0 = g.cell_start[cell], i1 = g.cell_start[cell + 1];
+            for (int i = i0 + lane; i < i1; i += 64) {
+                const double* b = g.obs + (size_t)g.cell_items[i] * g.stride;
+                hit |= (x[0] >= b[0]) & (x[0] <= b[3]) & (x[1] >= b[1]) & (x[1] <= b[4]) & (x[2] >= b[2]) & (x[2] <= b[5]);
+            }
+        } else {
+            for (int o = lane; o < g.O; o += 64) {
+                const double* b = g.obs + (size_t)o * g.stride;
+                hit |= (x[0] >= b[0]) & (x[0] <= b[3]) & (x[1] >= b[1]) & (x[1] <= b[4]) & (x[2] >= b[2]) & (x[2] <= b[5]);
+            }
         }
         return __any(hit) == 0;
     }
