@@ -350,3 +350,50 @@ def test_finish_on_goal_and_user_sampler():
     np.testing.assert_array_equal(pb.tree.state, pa.tree.state)
     with pytest.raises(ValueError):
         pb.update_plan(c.x0, c.sample_space, xrand_gen="nope")                              # planner.py:216
+
+
+def test_replanning_and_control_surface():
+    """Repeated update_plan on one Planner (a brand-new tree each call, planner.py:172), set_goal / set_runtime /
+    set_resolution between calls, kill_update (:596-601), guide fallback (:311-328) and specific_time."""
+    from systems_np import SYSTEMS, make_oracle_planner
+    s = _system("car")
+    p = _planner(s, 250, wave_size=128)
+    rs = SYSTEMS["car"](0)
+    ref = make_oracle_planner(rs, 250, min_time=2, max_time=3)
+    for seed, goal, x0 in ((11, s.goal, s.x0), (12, [30, 50, 0.5, 0, 0], [5, 5, 0.3, 0.5, 0])):
+        p.set_goal(goal)
+        ref.set_goal(goal)
+        np.random.seed(seed)
+        r1 = p.update_plan(x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10, guide=[35, 35, 0, 0, 0])
+        a_next = np.random.sample()
+        np.random.seed(seed)
+        r2 = ref.update_plan(x0, rs.sample_space, goal_bias=rs.goal_bias, xrand_gen=10, guide=[35, 35, 0, 0, 0])
+        b_next = np.random.sample()
+        assert r1 == r2 and a_next == b_next
+        assert list(p.tree.pID) == list(ref.tree.pID)
+        np.testing.assert_allclose(p.tree.state, ref.tree.state, rtol=0, atol=ATOL)
+        assert list(p.node_seq) == list(ref.node_seq) and p.T == ref.T
+        np.testing.assert_allclose(np.array(p.x_seq), np.array(ref.x_seq), rtol=0, atol=ATOL)
+    # a different resolution re-lays out the edge pools
+    p.set_resolution(horizon=3, FPR=0.5)
+    ref.set_resolution(horizon=3, FPR=0.5)
+    p.set_runtime(max_nodes=120)
+    ref.set_runtime(max_nodes=120)
+    np.random.seed(13)
+    p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10)
+    np.random.seed(13)
+    ref.update_plan(rs.x0, rs.sample_space, goal_bias=rs.goal_bias, xrand_gen=10)
+    assert p.tree.size == ref.tree.size == 121 and list(p.tree.pID) == list(ref.tree.pID)
+    assert max(len(e) for e in p.tree.x_seq) <= 30
+    # kill flag: polled between native calls; returns False and lowers the flag (planner.py:330-336)
+    p.set_runtime(max_nodes=100000)
+    p.kill_update()
+    assert p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10) is False
+    assert p.killed is False and hasattr(p, "node_seq")
+    # wall-clock budget with the real clock: returns True once a plan exists and specific_time elapsed
+    import time
+    p.set_runtime(sys_time=time.time)
+    t0 = time.time()
+    assert p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10, specific_time=0.2) is True
+    assert 0.2 <= time.time() - t0 < 5.0 and p.plan_reached_goal
+    assert p.tree.size > 1000            # the budget buys a much larger tree than the reference's ~20 nodes
