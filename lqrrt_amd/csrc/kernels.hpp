@@ -367,6 +367,13 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
     double* hx = hist;
     double* hu = hist + (size_t)r.H * S::N;
     const int lane = threadIdx.x;
+    // Model constants and tolerances are read every step: keep them in LDS (broadcast reads into VGPRs)
+    // rather than in SGPRs, where ~100 live doubles spill through v_writelane/v_readlane and every
+    // reload is a dependent scalar-cache round trip on the critical path of the rollout.
+    __shared__ double Pl[MAXP];
+    __shared__ double tol_l[MAXN], glo_l[MAXN], ghi_l[MAXN];
+    for (int i = lane; i < MAXP; i += 64) Pl[i] = P.p[i];
+    if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
     const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
     __syncthreads();
     const int t = list ? list[blockIdx.x] : lo + (int)blockIdx.x;
@@ -405,16 +412,16 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
             for (int j = 1; j < S::N; ++j) a += K[i * S::N + j] * e[j];
             u[i] = a; uc[i] = a;
         }
-        S::step(P.p, x, trig, uc, r.dt, xn);                     // planner.py:390 (dynamics gets copies)
+        S::step(Pl, x, trig, uc, r.dt, xn);                     // planner.py:390 (dynamics gets copies)
         trig_of<S>(xn, trn);
-        if (!S::feasible(P.p, g, gl, xn, u, trn, lane)) {        // planner.py:393-396
+        if (!S::feasible(Pl, g, gl, xn, u, trn, lane)) {        // planner.py:393-396
             cnt = (int)(r.FPR * (double)cnt);
             break;
         }
         ++steps;                                                 // planner.py:414
         bool conv = true;
 #pragma unroll
-        for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= r.tol[d]);
+        for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= tol_l[d]);
         if (steps > r.H || conv) break;                          // planner.py:428
         // record (planner.py:432-433): lane d keeps component d
         if (lane == 0) {                                         // wave-uniform values: one lane writes the LDS history
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         for (int d = 0; d < S::N; ++d) x[d] = xn[d];
 #pragma unroll
         for (int j = 0; j < 2 * S::NW; ++j) trig[j] = trn[j];
-        S::gain(P.p, x, trig, u, K);                             // planner.py:436
+        S::gain(Pl, x, trig, u, K);                             // planner.py:436
     }
     __syncthreads();
 
@@ -440,10 +447,10 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
 #pragma unroll
         for (int j = 0; j < S::M; ++j) ul[j] = hu[(cnt - 1) * S::M + j];
         trig_of<S>(x, trig);
-        S::gain(P.p, x, trig, ul, K);                            // planner.py:257: lqr(xnew, u_last)
+        S::gain(Pl, x, trig, ul, K);                            // planner.py:257: lqr(xnew, u_last)
         bool in = true;                                          // planner.py:442-447 (strict)
 #pragma unroll
-        for (int d = 0; d < S::N; ++d) in = in && (r.goal_lo[d] < x[d]) && (x[d] < r.goal_hi[d]);
+        for (int d = 0; d < S::N; ++d) in = in && (glo_l[d] < x[d]) && (x[d] < ghi_l[d]);
         flags = in ? 1 : 0;
         for (int q = lane; q < cnt * S::N; q += 64) my[L.off_xseq + q] = hx[q];
         for (int q = lane; q < cnt * S::M; q += 64) my[L.off_useq + q] = hu[q];

@@ -107,6 +107,9 @@ __device__ __forceinline__ double numpy_row_sum(const double* a) {
 // that is within reach (wave-uniform loop over the ballot), the lanes split the hull points.
 __device__ __forceinline__ bool hull_hits(const GeoL& g, double px, double py, double c, double s,
                                           bool extra2p, int lane) {
+#ifdef ABL_NOFEAS
+    return false;
+#endif
     bool hit = false;
     const double ms = -s;
     for (int o0 = 0; o0 < g.O; o0 += 64) {
@@ -155,6 +158,9 @@ struct BoatCommon {
 
     // "Heading controller trying to keep us car-like" (demo_boat_advanced.py:101-108)
     __device__ static double rudder_term(double gainv, const double* x, double c, double s) {
+#ifdef ABL_NORUDDER
+        return 0.0;
+#endif
         const double vw0 = c * x[3] + (-s) * x[4];
         const double vw1 = s * x[3] + c * x[4];
         const double ang = lq_atan2(vw1, vw0);
