@@ -328,13 +328,13 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
 }
 
 static int launch_steer(lqrrt_engine* e, const double* xs, const int* list, int lo, int count,
-                        const int* par, hipStream_t st) {
+                        const int* par, hipStream_t st, const int* list_count = nullptr) {
     if (count <= 0) return 0;
     const size_t lds = (size_t)e->H * (e->n + e->m) * sizeof(double) + geo_lds_bytes(e);
     EvPair ev;
     prof_begin(e, st, &ev);
     DISPATCH(e, hipLaunchKernelGGL((k_steer<S>), dim3(count), dim3(64), lds, st, e->P, e->geo, e->res, e->tv,
-                                    e->d_rec, e->L, xs, list, lo, par));
+                                    e->d_rec, e->L, xs, list, lo, par, list_count));
     prof_end(e, st, &ev, 1, 0.0);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1104,12 +1104,17 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
                            e->d_par_done, e->d_par_want, e->d_changed, e->d_stale, e->d_need, e->d_list, e->h_summary_dev,
                            e->h_summary_dev + 4, e->d_summary, ++e->seq);
         HIPCHK(hipGetLastError());
+        // The re-steer of whatever k_decide lists is enqueued right behind it, before the host has seen the
+        // count (the kernel reads it from device memory), so the GPU never idles on a host round trip; the
+        // host catches up on the summary while the steer runs.
+        const int pre = std::min(W, 64);
+        TRY(launch_steer(e, xs, e->d_list, 0, pre, e->d_par_done, st, e->d_summary));
         TRY(wait_summary(e, st));
         const int n_list = e->h_summary[0], n_defer = e->h_summary[1];
         if (getenv("LQRRT_TRACE")) fprintf(stderr, "[wave N=%d W=%d] round %d: list=%d defer=%d horizon=%d\n", e->N, W, rounds, n_list, n_defer, e->h_summary[2]);
         if (n_list == 0 && n_defer == 0) break;
         if (n_list == 0) return fail(LQRRT_E_STATE, "exact-mode repair made no progress (deferred=%d)", n_defer);
-        TRY(launch_steer(e, xs, e->d_list, 0, n_list, e->d_par_done, st));
+        if (n_list > pre) TRY(launch_steer(e, xs, e->d_list, pre, n_list - pre, e->d_par_done, st, e->d_summary));
         ws.fix_rounds++;
         ws.resteers += n_list;
         if (++rounds > guard) return fail(LQRRT_E_STATE, "exact-mode repair did not converge");

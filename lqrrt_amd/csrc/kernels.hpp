@@ -362,7 +362,10 @@ template <class S>
 __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView tv, double* __restrict__ rec,
                                               RecLayout L, const double* __restrict__ xs,
                                               const int* __restrict__ list, int lo,
-                                              const int* __restrict__ par) {
+                                              const int* __restrict__ par, const int* __restrict__ list_count) {
+    // list mode with a device-side count: the launch is enqueued before the host knows how many samples
+    // k_decide listed, so surplus workgroups simply leave (and a converged round costs one empty launch)
+    if (list_count && (int)blockIdx.x + lo >= list_count[0]) return;
     extern __shared__ double hist[];
     double* hx = hist;
     double* hu = hist + (size_t)r.H * S::N;
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
     if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
     const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
     __syncthreads();
-    const int t = list ? list[blockIdx.x] : lo + (int)blockIdx.x;
+    const int t = list ? list[blockIdx.x + (list_count ? lo : 0)] : lo + (int)blockIdx.x;
     const int pref = par[t];
     double* my = rec + (size_t)t * L.R;
 
