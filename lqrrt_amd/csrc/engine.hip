@@ -115,6 +115,8 @@ struct lqrrt_engine {
     int N = 0;
     std::vector<int> h_pid, h_elen;
     std::vector<unsigned long long> h_ign;
+    unsigned long long* h_ign_pin = nullptr;   // pinned staging copy (async upload)
+    int ign_hi = 0;                            // highest tree size since the last upload
     bool ign_dirty = false;
     int64_t goal_hits = 0;
     int best_end = -1;
@@ -359,6 +361,7 @@ static void free_all(lqrrt_engine* e) {
                     e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_cand, e->d_flags};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (e->h_ign_pin) (void)hipHostFree(e->h_ign_pin);
     if (e->h_summary) (void)hipHostFree(e->h_summary);
     if (e->h_rank) (void)hipHostFree(e->h_rank);
 }
@@ -515,6 +518,8 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
                 hipHostGetDevicePointer((void**)&e->h_rank_dev, e->h_rank, 0) != hipSuccess))
         rc = fail(LQRRT_E_HIP, "hipHostGetDevicePointer failed");
     if (!rc) memset(e->h_summary, 0, sizeof(int) * 4);
+    if (!rc && hipHostMalloc((void**)&e->h_ign_pin, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1), hipHostMallocDefault) != hipSuccess)
+        rc = fail(LQRRT_E_HIP, "hipHostMalloc failed");
     if (!rc) rc = alloc_wave(e);
     if (rc) { free_all(e); delete e; return rc; }
     e->h_pid.reserve(e->cap); e->h_elen.reserve(e->cap);
@@ -720,6 +725,7 @@ extern "C" int lqrrt_tree_mark(lqrrt_engine* e) {
 extern "C" int lqrrt_tree_rewind(lqrrt_engine* e) {
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     if (e->mark_N < 1 || e->mark_N > e->N) return fail(LQRRT_E_STATE, "no valid mark");
+    e->ign_hi = std::max(e->ign_hi, e->N);
     e->N = e->mark_N;
     e->h_pid.resize(e->N); e->h_elen.resize(e->N);
     e->h_ign = e->mark_ign; e->ign_dirty = true;
@@ -728,11 +734,17 @@ extern "C" int lqrrt_tree_rewind(lqrrt_engine* e) {
     return 0;
 }
 
-static int flush_ignore(lqrrt_engine* e, hipStream_t st) {
+static int flush_ignore(lqrrt_engine* e, hipStream_t st, bool sync_first = false) {
     if (!e->ign_dirty) return 0;
-    HIPCHK(hipMemcpyAsync(e->tv.ignore, e->h_ign.data(), sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1),
-                          hipMemcpyHostToDevice, st));
+    // only the words that cover nodes which exist (or existed since the last upload) can differ
+    const size_t words = std::min((size_t)e->cap / 64 + 1, (size_t)std::max(e->ign_hi, e->N) / 64 + 1);
+    // The staging buffer is reused: inside the wave loop every upload is followed by that wave's summary
+    // wait before the next one can happen; the stand-alone operator path synchronises explicitly.
+    if (sync_first) HIPCHK(hipStreamSynchronize(st));
+    memcpy(e->h_ign_pin, e->h_ign.data(), sizeof(unsigned long long) * words);
+    HIPCHK(hipMemcpyAsync(e->tv.ignore, e->h_ign_pin, sizeof(unsigned long long) * words, hipMemcpyHostToDevice, st));
     e->ign_dirty = false;
+    e->ign_hi = e->N;
     return 0;
 }
 
@@ -801,7 +813,7 @@ extern "C" int lqrrt_nn_argmin(lqrrt_engine* e, const double* xs, int W, const d
     if (e->N < 1) return fail(LQRRT_E_STATE, "no tree: call lqrrt_tree_reset");
     TRY(use_device(e));
     hipStream_t st = (hipStream_t)stream;
-    TRY(flush_ignore(e, st));
+    TRY(flush_ignore(e, st, true));
     return launch_nn(e, tree_view(e, use_ignore != 0), xs, W, S_dev, false, true, id, cost, nullptr, st, true);
 }
 
