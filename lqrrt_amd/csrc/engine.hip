@@ -1048,14 +1048,18 @@ static int pick_wave(const lqrrt_engine* e, int wave_cap) {
 }
 
 static void tune_wave(lqrrt_engine* e, int W, const lqrrt_extend_stats& ws, int wave_cap) {
+    static const double k_cut = getenv("LQRRT_CTL_CUT") ? atof(getenv("LQRRT_CTL_CUT")) : 4.0;
+    static const double k_min = getenv("LQRRT_CTL_MIN") ? atof(getenv("LQRRT_CTL_MIN")) : 128.0;
+    static const int k_hi = getenv("LQRRT_CTL_HI") ? atoi(getenv("LQRRT_CTL_HI")) : 10;
+    static const int k_lo = getenv("LQRRT_CTL_LO") ? atoi(getenv("LQRRT_CTL_LO")) : 5;
     double w = e->ctl_w >= 8.0 ? e->ctl_w : (double)W;
     if (ws.goal_hits && ws.attempts < W) {
         // cut by a goal hit after ws.attempts samples: the rest of the speculation was discarded
-        const double target = std::max(64.0, 2.0 * (double)ws.attempts);
+        const double target = std::max(k_min, k_cut * (double)ws.attempts);
         w = 0.5 * w + 0.5 * target;
-    } else if (ws.fix_rounds > 6) {
-        w = std::max(64.0, 0.5 * w);
-    } else if (ws.fix_rounds <= 3) {
+    } else if (ws.fix_rounds > k_hi) {
+        w = std::max(k_min, 0.5 * w);
+    } else if (ws.fix_rounds <= k_lo) {
         w = std::min((double)wave_cap, 1.5 * w + 32.0);
     }
     e->ctl_w = w;
