@@ -70,6 +70,16 @@ typedef struct {
     int32_t reserved;
     const double* vps;                /* host, may be NULL when V == 0                   */
     const double* obs;                /* host, may be NULL when O == 0                   */
+    /* Optional occupancy-grid collision model for the planar vehicles (the ROS node's is_feasible,
+     * demos/lqrrt_ros/nodes/lqrrt_node.py:719-745): when ogrid != NULL it replaces the circle sweep.
+     * Cell of a hull point p: (int64)(cpm * (p - origin)) (truncation toward zero), value looked up
+     * as ogrid[iy][ix] with NumPy's index rules (negative indices wrap once, anything else outside
+     * is infeasible); feasible iff every value < threshold. */
+    const int8_t* ogrid;              /* host, row-major [og_rows][og_cols], or NULL     */
+    int32_t og_rows, og_cols;
+    double  og_origin[2];
+    double  og_cpm;                   /* cells per metre = 1 / resolution                */
+    double  og_threshold;
 } lqrrt_system_desc;
 
 /* Resolution + goal (Planner.set_resolution planner.py:517-553, set_goal :468-487). */

@@ -24,7 +24,9 @@ class SystemDesc(C.Structure):
     _fields_ = [("model", C.c_int32), ("nstates", C.c_int32), ("ncontrols", C.c_int32),
                 ("n_params", C.c_int32), ("params", C.c_double * MAX_PARAMS),
                 ("n_vertices", C.c_int32), ("n_obstacles", C.c_int32), ("obs_stride", C.c_int32),
-                ("reserved", C.c_int32), ("vps", C.POINTER(C.c_double)), ("obs", C.POINTER(C.c_double))]
+                ("reserved", C.c_int32), ("vps", C.POINTER(C.c_double)), ("obs", C.POINTER(C.c_double)),
+                ("ogrid", C.POINTER(C.c_int8)), ("og_rows", C.c_int32), ("og_cols", C.c_int32),
+                ("og_origin", C.c_double * 2), ("og_cpm", C.c_double), ("og_threshold", C.c_double)]
 
 
 class Resolution(C.Structure):

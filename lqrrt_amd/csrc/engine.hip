@@ -106,6 +106,7 @@ struct lqrrt_engine {
     double* d_vps = nullptr;
     double* d_obs = nullptr;
     double* d_oc = nullptr;       // derived circle table [O][4]
+    signed char* d_og = nullptr;  // occupancy grid
     int* d_cell_start = nullptr;  // box obstacles: uniform grid (CSR) over the boxes' bounding volume
     int* d_cell_items = nullptr;
     double* d_S = nullptr;        // dense system S (n x n) or null = identity
@@ -217,6 +218,7 @@ static bool model_dims(int model, int* n, int* m, int* nw) {
 }
 
 static size_t geo_lds_bytes(const lqrrt_engine* e) {
+    if (e->geo.og) return 0;
     return e->geo.oc ? sizeof(double) * ((size_t)2 * e->geo.V + (size_t)4 * e->geo.O) : 0;
 }
 
@@ -355,7 +357,7 @@ extern "C" int lqrrt_device_count(void) {
 }
 
 static void free_all(lqrrt_engine* e) {
-    void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_cell_start, e->d_cell_items, e->d_S, e->tv.state, e->tv.trig, e->tv.K, e->tv.pID, e->tv.elen,
+    void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_og, e->d_cell_start, e->d_cell_items, e->d_S, e->tv.state, e->tv.trig, e->tv.K, e->tv.pID, e->tv.elen,
                     e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_pcost_all, e->d_wcost,
                     e->d_pidx, e->d_pidx_all, e->d_wid, e->d_par_done, e->d_par_want, e->d_list,
                     e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_cand, e->d_flags};
@@ -485,6 +487,16 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
         }
         rc = up(&e->d_oc, oc.data(), (size_t)4 * sys->n_obstacles);
         e->geo.oc = e->d_oc;
+    }
+    e->geo.og = nullptr;
+    if (!rc && sys->ogrid) {
+        if (sys->og_rows < 1 || sys->og_cols < 1 || !(sys->og_cpm > 0)) rc = fail(LQRRT_E_ARG, "bad occupancy grid");
+        if (!rc) rc = dalloc(&e->d_og, (size_t)sys->og_rows * sys->og_cols);
+        if (!rc && hipMemcpy(e->d_og, sys->ogrid, (size_t)sys->og_rows * sys->og_cols, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(LQRRT_E_HIP, "ogrid upload failed");
+        e->geo.og = e->d_og; e->geo.og_rows = sys->og_rows; e->geo.og_cols = sys->og_cols;
+        e->geo.og_ox = sys->og_origin[0]; e->geo.og_oy = sys->og_origin[1];
+        e->geo.og_cpm = sys->og_cpm; e->geo.og_thr = sys->og_threshold;
     }
     e->geo.cell_start = nullptr; e->geo.cell_items = nullptr;
     if (!rc && e->geo.stride == 6 && sys->n_obstacles > 0) rc = build_box_grid(e, sys);

@@ -45,6 +45,10 @@ struct Geo {
     double glo[3], ghi[3], gcell;
     int gdim[3];
     int V, O, stride, pad;
+    // optional occupancy grid (replaces the circle sweep of the planar vehicles when non-null)
+    const signed char* og;
+    double og_ox, og_oy, og_cpm, og_thr;
+    int og_rows, og_cols;
 };
 
 struct GeoL {            // LDS-resident copy used inside a workgroup
@@ -60,6 +64,7 @@ __device__ __forceinline__ GeoL stage_geo(const Geo& g, double* lds, int tid, in
     GeoL L;
     L.V = g.V; L.O = g.O;
     L.vps = lds; L.oc = lds + 2 * g.V;
+    if (g.og) { L.vps = g.vps; return L; }     // occupancy-grid model: hull points are read from HBM/L2
     if (g.oc) {
         for (int i = tid; i < 2 * g.V; i += nthreads) lds[i] = g.vps[i];
         for (int i = tid; i < 4 * g.O; i += nthreads) lds[2 * g.V + i] = g.oc[i];
@@ -105,6 +110,27 @@ __device__ __forceinline__ double numpy_row_sum(const double* a) {
 // accidental vertex at 2p (demo_car.py:175).  One wavefront cooperates: lanes first cull the
 // obstacles by reach of the vehicle centre (one obstacle per lane), then, for each obstacle
 // that is within reach (wave-uniform loop over the ballot), the lanes split the hull points.
+// Occupancy-grid variant (demos/lqrrt_ros/nodes/lqrrt_node.py:730-745): hull points -> cells by
+// (int64)(cpm*(p - origin)) (truncation), ogrid[iy][ix] with NumPy's index rules -- an index in
+// [-dim, -1] wraps around, anything else outside raises IndexError there = infeasible here -- and a hit
+// is any value >= threshold.  Lanes split the hull points.
+__device__ __forceinline__ bool grid_hits(const Geo& g, double px, double py, double c, double s, int lane) {
+    bool hit = false;
+    const double ms = -s;
+    for (int v = lane; v < g.V; v += 64) {
+        const double bx = g.vps[v], by = g.vps[g.V + v];
+        const double vx = px + (c * bx + ms * by);
+        const double vy = py + (s * bx + c * by);
+        long long ix = (long long)(g.og_cpm * (vx - g.og_ox));
+        long long iy = (long long)(g.og_cpm * (vy - g.og_oy));
+        if (ix < 0) ix += g.og_cols;
+        if (iy < 0) iy += g.og_rows;
+        if (ix < 0 || ix >= g.og_cols || iy < 0 || iy >= g.og_rows) hit = true;
+        else hit |= !((double)g.og[iy * g.og_cols + ix] < g.og_thr);
+    }
+    return __any(hit) != 0;
+}
+
 __device__ __forceinline__ bool hull_hits(const GeoL& g, double px, double py, double c, double s,
                                           bool extra2p, int lane) {
 #ifdef ABL_NOFEAS
@@ -225,11 +251,12 @@ struct BoatAdvanced : BoatCommon {
         euler(P + 0, P + 3, P + 6, x, c, s, us, dt, xn);
         carlike(x, P[38], P[39], xn);
     }
-    __device__ static bool feasible(const double* P, const Geo&, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
+    __device__ static bool feasible(const double* P, const Geo& g, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
         // planning speed box first (demo_boat_advanced.py:211-213)
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             if (x[3 + i] > P[46 + i] || x[3 + i] < P[49 + i]) return false;
+        if (g.og) return !grid_hits(g, x[0], x[1], trig[0], trig[1], lane);
         return !hull_hits(gl, x[0], x[1], trig[0], trig[1], false, lane);
     }
 };
@@ -249,7 +276,8 @@ struct BoatIntermediate : BoatCommon {
         euler(P + 0, P + 3, P + 6, x, c, s, u, dt, xn);
         carlike(x, P[13], P[14], xn);
     }
-    __device__ static bool feasible(const double*, const Geo&, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
+    __device__ static bool feasible(const double*, const Geo& g, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
+        if (g.og) return !grid_hits(g, x[0], x[1], trig[0], trig[1], lane);
         return !hull_hits(gl, x[0], x[1], trig[0], trig[1], false, lane);
     }
 };
@@ -302,7 +330,8 @@ struct Car {
         if (xn[3] < 0.0) xn[3] = 0.0;                                   // demo_car.py:66-67
         xn[4] = clipd(fabs(xn[3] / P[8]), 0.0, 1.0) * xn[4];            // demo_car.py:70
     }
-    __device__ static bool feasible(const double*, const Geo&, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
+    __device__ static bool feasible(const double*, const Geo& g, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
+        if (g.og) return !grid_hits(g, x[0], x[1], trig[0], trig[1], lane);   // (the ROS node has no 2p vertex)
         return !hull_hits(gl, x[0], x[1], trig[0], trig[1], true, lane);
     }
 };

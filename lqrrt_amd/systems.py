@@ -102,6 +102,7 @@ class NativeSystem(object):
         self.vps = np.zeros((2, 0))
         self.obs = np.zeros((0, 3))
         self.obs_stride = 3
+        self.ogrid = None         # optional occupancy grid: dict(grid=int8 [rows][cols], origin=(x,y), cpm, threshold)
         self._ops = None
         self._ops_dt = None
 
@@ -123,7 +124,35 @@ class NativeSystem(object):
         d.n_vertices, d.n_obstacles, d.obs_stride = vps.shape[1], obs.shape[0], self.obs_stride
         d.vps = vps.ctypes.data_as(C.POINTER(C.c_double)) if vps.size else None
         d.obs = obs.ctypes.data_as(C.POINTER(C.c_double)) if obs.size else None
-        return d, (vps, obs, p)
+        grid = None
+        if self.ogrid is not None:
+            grid = np.ascontiguousarray(self.ogrid["grid"], dtype=np.int8)
+            d.ogrid = grid.ctypes.data_as(C.POINTER(C.c_int8))
+            d.og_rows, d.og_cols = grid.shape
+            d.og_origin[0], d.og_origin[1] = (float(v) for v in self.ogrid["origin"])
+            d.og_cpm = float(self.ogrid["cpm"])
+            d.og_threshold = float(self.ogrid["threshold"])
+        return d, (vps, obs, p, grid)
+
+    def set_occupancy_grid(self, grid, origin, resolution=None, cpm=None, threshold=90.0, vps=None):
+        """
+        Switches the collision model of a planar vehicle to the ROS node's occupancy-grid test
+        (demos/lqrrt_ros/nodes/lqrrt_node.py:719-745; grid as in nav_msgs/OccupancyGrid: -1 unknown, 0..100).
+        Optionally replaces the hull points (e.g. behaviors/params.py's 0.1 m lattice).  Engines already
+        created keep the old model.
+        """
+        if self.model not in (nat.MODEL_BOAT_ADVANCED, nat.MODEL_BOAT_INTERMEDIATE, nat.MODEL_CAR):
+            raise ValueError("occupancy-grid feasibility is defined for the hull-sweeping vehicles")
+        if (resolution is None) == (cpm is None):
+            raise ValueError("give exactly one of resolution (m/cell) or cpm (cells/m)")
+        grid = np.asarray(grid)
+        if grid.ndim != 2:
+            raise ValueError("grid must be 2-D [rows][cols]")
+        self.ogrid = dict(grid=grid.astype(np.int8), origin=(float(origin[0]), float(origin[1])),
+                          cpm=float(cpm) if cpm is not None else 1.0 / float(resolution), threshold=float(threshold))
+        if vps is not None:
+            self.vps = np.ascontiguousarray(vps, dtype=np.float64).reshape(2, -1)
+        self._ops = None
 
     def Smatrix(self):
         return np.eye(self.nstates) if self.S is None else np.asarray(self.S, dtype=np.float64)

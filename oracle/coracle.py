@@ -29,6 +29,7 @@ def lib():
         L.orc_enable_trace.argtypes = [C.c_void_p, C.c_longlong]
         L.orc_get_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
         L.orc_set_resolution.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int] + [C.c_void_p] * 4
+        L.orc_set_ogrid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
         _lib = L
     return _lib
 
@@ -54,6 +55,11 @@ class COracle(object):
                                              _p(obs), obs.shape[0], system.obs_stride, int(capacity)))
         if not self.h:
             raise ValueError("unknown model")
+        og = getattr(system, "ogrid", None)
+        if og is not None:
+            grid = np.ascontiguousarray(og["grid"], dtype=np.int8)
+            lib().orc_set_ogrid(self.h, _p(grid), grid.shape[0], grid.shape[1], float(og["origin"][0]),
+                                float(og["origin"][1]), float(og["cpm"]), float(og["threshold"]))
         self.H = 1
         self.S = None if system.S is None else _f(system.S)
 

@@ -35,6 +35,9 @@ typedef struct {
     double P[96];
     int V, O, stride;
     double *vps, *obs;
+    signed char* og;               /* optional occupancy grid (lqrrt_node.py:719-745) */
+    int og_rows, og_cols;
+    double og_ox, og_oy, og_cpm, og_thr;
     double dt, FPR, tol[MAXN], goal[MAXN], glo[MAXN], ghi[MAXN];
     int H;
     double centers[MAXN], spans[MAXN], bias[MAXN];
@@ -112,6 +115,22 @@ static int hull_hits(const orc* o, double px, double py, double c, double s, int
             const double dx = (px + px) - ox, dy = (py + py) - oy;
             if (sqrt(dx * dx + dy * dy) <= r) return 1;
         }
+    }
+    return 0;
+}
+
+/* occupancy-grid collision model of the ROS node (demos/lqrrt_ros/nodes/lqrrt_node.py:730-745) */
+static int grid_hits(const orc* o, double px, double py, double c, double s) {
+    const double ms = -s;
+    for (int v = 0; v < o->V; ++v) {
+        const double bx = o->vps[v], by = o->vps[o->V + v];
+        const double vx = px + (c * bx + ms * by), vy = py + (s * bx + c * by);
+        long long ix = (long long)(o->og_cpm * (vx - o->og_ox));      /* .astype(np.int64): truncation */
+        long long iy = (long long)(o->og_cpm * (vy - o->og_oy));
+        if (ix < 0) ix += o->og_cols;                                  /* numpy: negative indices wrap once */
+        if (iy < 0) iy += o->og_rows;
+        if (ix < 0 || ix >= o->og_cols || iy < 0 || iy >= o->og_rows) return 1;   /* IndexError -> infeasible */
+        if (!((double)o->og[iy * o->og_cols + ix] < o->og_thr)) return 1;
     }
     return 0;
 }
@@ -236,15 +255,20 @@ static int feasible(const orc* o, const double* x, const double* u, const double
     switch (o->model) {
         case BOAT_ADV:
             for (int i = 0; i < 3; ++i) if (x[3 + i] > P[46 + i] || x[3 + i] < P[49 + i]) return 0;
+            if (o->og) return !grid_hits(o, x[0], x[1], tr[0], tr[1]);
             return !hull_hits(o, x[0], x[1], tr[0], tr[1], 0);
-        case BOAT_INT: return !hull_hits(o, x[0], x[1], tr[0], tr[1], 0);
+        case BOAT_INT:
+            if (o->og) return !grid_hits(o, x[0], x[1], tr[0], tr[1]);
+            return !hull_hits(o, x[0], x[1], tr[0], tr[1], 0);
         case BOAT_NOV:
             for (int ob = 0; ob < o->O; ++ob) {
                 const double dx = x[0] - o->obs[ob * o->stride], dy = x[1] - o->obs[ob * o->stride + 1];
                 if (sqrt(dx * dx + dy * dy) <= P[18] + o->obs[ob * o->stride + 2]) return 0;
             }
             return 1;
-        case CAR: return !hull_hits(o, x[0], x[1], tr[0], tr[1], 1);
+        case CAR:
+            if (o->og) return !grid_hits(o, x[0], x[1], tr[0], tr[1]);
+            return !hull_hits(o, x[0], x[1], tr[0], tr[1], 1);
         case PEND: return !(fabs(u[0]) > P[13]);
         case DINT:
             for (int ob = 0; ob < o->O; ++ob) {
@@ -290,9 +314,17 @@ static void free_tree(orc* o) {
     o->state = o->trig = o->K = o->xedge = o->uedge = 0; o->pid = o->elen = 0; o->ign = 0;
 }
 
+void orc_set_ogrid(orc* o, const signed char* grid, int rows, int cols, double ox, double oy, double cpm, double thr) {
+    free(o->og);
+    o->og = (signed char*)malloc((size_t)rows * cols);
+    memcpy(o->og, grid, (size_t)rows * cols);
+    o->og_rows = rows; o->og_cols = cols; o->og_ox = ox; o->og_oy = oy; o->og_cpm = cpm; o->og_thr = thr;
+}
+
 void orc_destroy(orc* o) {
     if (!o) return;
     free_tree(o);
+    free(o->og);
     free(o->vps); free(o->obs); free(o->trace_near); free(o->trace_len);
     free(o);
 }

@@ -78,6 +78,24 @@ class _HeadingSystem(object):
         E[:, 2] = wrap_err(xgoal[2], X[:, 2])
         return E
 
+    ogrid = None      # optional dict(grid, origin, cpm, threshold): the ROS node's collision model
+
+    def set_occupancy_grid(self, grid, origin, cpm, threshold, vps=None):
+        self.ogrid = dict(grid=np.asarray(grid), origin=np.asarray(origin, dtype=np.float64), cpm=cpm, threshold=threshold)
+        if vps is not None:
+            self.vps = np.asarray(vps, dtype=np.float64)
+
+    def _grid_feasible(self, x):
+        """demos/lqrrt_ros/nodes/lqrrt_node.py:730-745."""
+        og = self.ogrid
+        points = x[:2] + rot2(x[2]).dot(self.vps).T
+        idx = (og["cpm"] * (points - og["origin"])).astype(np.int64)
+        try:
+            values = og["grid"][idx[:, 1], idx[:, 0]]
+        except IndexError:
+            return False
+        return bool(np.all(values < og["threshold"]))
+
     def _hull_hits(self, verts):
         for ob in self.obs:
             if np.any(npl.norm(verts - ob[:2], axis=1) <= ob[2]):
@@ -154,6 +172,8 @@ class BoatAdvanced(_HeadingSystem):
         v = x[3:]
         if np.any(v > self.velmax_pos_plan) or np.any(v < self.velmax_neg_plan):
             return False
+        if self.ogrid is not None:
+            return self._grid_feasible(x)
         verts = x[:2] + rot2(x[2]).dot(self.vps).T
         return not self._hull_hits(verts)
 

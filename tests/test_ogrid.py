@@ -1,0 +1,95 @@
+"""
+Occupancy-grid feasibility (demos/lqrrt_ros/nodes/lqrrt_node.py:719-745): the fixture
+tests/golden/ops_ogrid.npz was produced by the reference's own method text (tools/gen_golden.py:gen_ogrid),
+768 poses around and beyond a 300 x 400 grid with the ROS package's 1512-point hull lattice.
+"""
+import os
+
+import numpy as np
+import pytest
+
+
+def _fixture(golden_dir):
+    path = os.path.join(golden_dir, "ops_ogrid.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture missing")
+    return np.load(path)
+
+
+def _native_boat(g):
+    import lqrrt_amd
+    s = lqrrt_amd.systems.BoatAdvanced(0)
+    # park the planning speed box far away so that the grid alone decides (the ROS node has no speed box)
+    s.velmax_pos_plan = np.full(3, 1e9)
+    s.velmax_neg_plan = np.full(3, -1e9)
+    s.set_occupancy_grid(g["grid"], g["origin"], cpm=float(g["cpm"]), threshold=float(g["threshold"]), vps=g["vps"])
+    return s
+
+
+def test_oracles_match_reference_ogrid(golden_dir):
+    import coracle
+    from systems_np import SYSTEMS
+    g = _fixture(golden_dir)
+    rs = SYSTEMS["boat_advanced"](0)
+    rs.velmax_pos_plan, rs.velmax_neg_plan = np.full(3, 1e9), np.full(3, -1e9)
+    rs.set_occupancy_grid(g["grid"], g["origin"], float(g["cpm"]), float(g["threshold"]), vps=g["vps"])
+    ok = np.array([rs.is_feasible(np.copy(x), np.zeros(3)) for x in g["x"]])
+    np.testing.assert_array_equal(ok, g["ok"])
+    o = coracle.make(_native_boat(g), 16)
+    okc = np.array([o.feasible(x, np.zeros(3)) for x in g["x"]])
+    np.testing.assert_array_equal(okc, g["ok"])
+    assert 0.2 < g["ok"].mean() < 0.8
+
+
+def test_ogrid_argument_checks():
+    import lqrrt_amd
+    b = lqrrt_amd.systems.BoatNovice(0)
+    with pytest.raises(ValueError):
+        b.set_occupancy_grid(np.zeros((4, 4)), (0, 0), resolution=0.5)          # centre-point model has no hull
+    a = lqrrt_amd.systems.BoatAdvanced(0)
+    with pytest.raises(ValueError):
+        a.set_occupancy_grid(np.zeros((4, 4)), (0, 0))                          # resolution xor cpm
+    with pytest.raises(ValueError):
+        a.set_occupancy_grid(np.zeros(16), (0, 0), resolution=0.5)
+
+
+@pytest.mark.gpu
+def test_hip_ogrid_feasibility_golden(golden_dir):
+    g = _fixture(golden_dir)
+    s = _native_boat(g)
+    ok = s._engine(0.1).feasible_batch(g["x"])
+    np.testing.assert_array_equal(ok, g["ok"])
+
+
+@pytest.mark.gpu
+def test_hip_ogrid_tree_bit_exact_vs_coracle(golden_dir):
+    """Plan through the occupancy grid: engine and sequential C oracle grow the same tree."""
+    import coracle
+    from lqrrt_amd.engine import Engine
+    g = _fixture(golden_dir)
+    import lqrrt_amd
+    s = lqrrt_amd.systems.BoatIntermediate(0)
+    grid = np.array(g["grid"])
+    cpm, origin = float(g["cpm"]), g["origin"]
+    for px, py in ((s.x0[0], s.x0[1]), (s.goal[0], s.goal[1])):          # keep start and goal areas free
+        c, r = int(cpm * (px - origin[0])), int(cpm * (py - origin[1]))
+        grid[max(r - 40, 0):r + 40, max(c - 40, 0):c + 40] = 0
+    s.set_occupancy_grid(grid, origin, cpm=cpm, threshold=float(g["threshold"]))
+    nodes, wave, budget = 1500, 256, 12000
+    eng = Engine(s, capacity=nodes + wave + 8, max_wave=wave)
+    kw = s.plan_kwargs
+    eng.set_resolution(kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer))
+    space = np.array(s.sample_space, dtype=np.float64)
+    eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), np.array(s.goal_bias, dtype=np.float64), 10)
+    st = np.random.RandomState(3).get_state()
+    eng.set_mt19937(st[1], st[2])
+    eng.tree_reset(s.x0)
+    stats = eng.extend(wave, max_attempts=budget, node_limit=nodes)       # bounded: a cluttered map may saturate
+    o = coracle.make(s, nodes + wave + 8, seed=3)
+    o.extend(max_iters=budget, max_nodes=nodes)
+    assert eng.size == o.size and eng.size > 300
+    assert stats.attempts == o.iterations and stats.candidates == o.candidates
+    np.testing.assert_array_equal(eng.parents(), o.parents())
+    np.testing.assert_array_equal(eng.states(), o.states())
+    np.testing.assert_array_equal(eng.edge_lengths(), o.edge_lengths())
+    assert (eng.edge_lengths() < 20).mean() > 0.05          # the grid actually cut edges

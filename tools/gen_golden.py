@@ -215,6 +215,48 @@ def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None):
         bool(planner.plan_reached_goal), int(np.sum(ties)), wall))
 
 
+# --------------------------------------------------------------------------- occupancy grid (8f-3)
+
+def gen_ogrid():
+    """
+    Fixture for the ROS node's occupancy-grid feasibility (demos/lqrrt_ros/nodes/lqrrt_node.py:719-745).
+    The node cannot be imported here (rospy, cv2), so only the text of that one method is compiled, at
+    generation time, against a stand-in `self`; behaviors/params.py (numpy only) supplies the hull points.
+    """
+    import ast
+    import importlib.util
+    import textwrap
+    import types
+    node_path = os.path.join(rl.REF, "demos", "lqrrt_ros", "nodes", "lqrrt_node.py")
+    src = open(node_path).read()
+    fn = [n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "is_feasible"][0]
+    text = textwrap.dedent("\n".join(src.split("\n")[fn.lineno - 1:fn.end_lineno]))
+    spec = importlib.util.spec_from_file_location("ref_params", os.path.join(rl.REF, "demos", "lqrrt_ros", "behaviors", "params.py"))
+    params = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(params)
+    ns = {"np": np, "params": params}
+    exec(compile(text, node_path, "exec"), ns)
+    rng = np.random.RandomState(77)
+    rows, cols, res = 300, 400, 0.25
+    grid = np.zeros((rows, cols), dtype=np.int64)
+    for _ in range(60):                                    # blobs of occupancy 0..100 and unknown (-1) patches
+        r, c = rng.randint(rows), rng.randint(cols)
+        h, w = rng.randint(2, 14), rng.randint(2, 14)
+        grid[max(r - h, 0):r + h, max(c - w, 0):c + w] = rng.choice([100, 95, 91, 90, 89, 50, -1])
+    me = types.SimpleNamespace(ogrid=grid, blind=False, ogrid_origin=np.array([-20.0, -15.0]), ogrid_cpm=1 / res,
+                               ogrid_threshold=float("90"))
+    xs = np.zeros((768, 6))
+    xs[:, 0] = rng.uniform(-30, 90, len(xs))                # beyond the grid on every side (IndexError / wrap quirks)
+    xs[:, 1] = rng.uniform(-25, 70, len(xs))
+    xs[:, 2] = rng.uniform(-7, 7, len(xs))
+    ok = np.array([bool(ns["is_feasible"](me, np.copy(x), np.zeros(3))) for x in xs])
+    out = dict(grid=grid.astype(np.int8), origin=me.ogrid_origin, cpm=np.float64(me.ogrid_cpm),
+               threshold=np.float64(me.ogrid_threshold), vps=np.array(params.vps, dtype=np.float64), x=xs, ok=ok)
+    path = os.path.join(OUT, "ops_ogrid.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "feasible fraction %.2f, hull points %d" % (ok.mean(), params.vps.shape[1]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--long", action="store_true", help="also run boat_advanced to 10k nodes (~20 min)")
@@ -228,6 +270,8 @@ def main():
     if "ops" in what:
         for name in rl.DEMOS:
             gen_ops(name)
+    if "ogrid" in what or "ops" in what:
+        gen_ogrid()
     if "traj" in what:
         run_traj("boat_advanced", 200)
         run_traj("boat_intermediate", 300)
