@@ -286,6 +286,11 @@ static void prof_flush(lqrrt_engine* e) {
 // --------------------------------------------------------------------------------------------
 // kernel launch wrappers
 
+static int tri_chunk() {
+    static const int c = getenv("LQRRT_TRI_CHUNK") ? atoi(getenv("LQRRT_TRI_CHUNK")) : 16;
+    return c;
+}
+
 static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
     const int groups = (W + 63) / 64;
     static const int target_waves = getenv("LQRRT_NN_WAVES") ? atoi(getenv("LQRRT_NN_WAVES")) : 2048;
@@ -303,7 +308,7 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
                      bool profile, int* n_chunks_out = nullptr, int wave_lo = -1) {
     if (W <= 0) return 0;
     int chunk, n_chunks;
-    if (tri) { chunk = 16; n_chunks = (nv.count + 15) / 16; }   // in-wave pass: the reduction is fused into k_decide
+    if (tri) { chunk = tri_chunk(); n_chunks = (nv.count + chunk - 1) / chunk; }   // in-wave pass: the reduction is fused into k_decide
     else pick_chunks(nv.count, W, &chunk, &n_chunks);
     if (n_chunks_out) *n_chunks_out = n_chunks;
     dim3 grid((W + 63) / 64, n_chunks);
@@ -1128,7 +1133,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
             HIPCHK(hipMemsetAsync(e->d_pidx, 0xff, sizeof(int), st));        // no in-wave candidate
             HIPCHK(hipMemsetAsync(e->d_pcost, 0x7f, sizeof(double), st));    // large finite cost
         }
-        hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, st, e->d_rec, e->L, W, e->d_pcost, e->d_pidx, n_chunks, 16,
+        hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, st, e->d_rec, e->L, W, e->d_pcost, e->d_pidx, n_chunks, tri_chunk(),
                            e->d_par_done, e->d_par_want, e->d_changed, e->d_stale, e->d_need, e->d_list, e->h_summary_dev,
                            e->h_summary_dev + 4, e->d_summary, ++e->seq);
         HIPCHK(hipGetLastError());

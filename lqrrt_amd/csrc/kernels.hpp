@@ -612,15 +612,17 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ rec,
             summary[2 * W + t] = par_done[t];
         }
     }
-    // ctrl/summary live in pinned host memory: publish them with a system-scope release so that the
-    // host, which spins on ctrl[3] == seq, never needs a copy or a stream synchronisation.
-    __threadfence_system();
+    // ctrl/summary live in pinned host memory: publish them with ONE system-scope release so that the
+    // host, which spins on ctrl[3] == seq, never needs a copy or a stream synchronisation.  Every wave first
+    // drains its own stores, the barrier orders them before lane 0, whose release then covers them all.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         dev_count[0] = n_list;                       // read by the re-steer launch that follows
         ctrl[0] = n_list; ctrl[1] = n_defer; ctrl[2] = hz;
         __threadfence_system();
-        __hip_atomic_store(&ctrl[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&ctrl[3], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
