@@ -131,8 +131,8 @@ struct lqrrt_engine {
     // wave buffers
     RecLayout L{};
     double* d_rec = nullptr;
-    double *d_pcost = nullptr, *d_pcost_all = nullptr, *d_wcost = nullptr;
-    int *d_pidx = nullptr, *d_pidx_all = nullptr, *d_wid = nullptr;
+    double *d_pcost = nullptr, *d_pcost_all = nullptr;
+    int *d_pidx = nullptr, *d_pidx_all = nullptr;
     int *d_par_done = nullptr, *d_par_want = nullptr, *d_list = nullptr;
     unsigned char *d_changed = nullptr, *d_stale = nullptr, *d_need = nullptr;
     int* d_summary = nullptr;     // [4]: device-side copy of the listed count (index 0)
@@ -155,7 +155,6 @@ struct lqrrt_engine {
     std::vector<int64_t> pool_rows_end;  // candidate rows consumed through each pooled sample
     bool explicit_samples = false; // samples pushed by the host (callable xrand_gen) instead of the sampler
     int tries_carry = 0;          // tries already spent on the sample under construction
-    std::vector<double> carry_row;
     double* d_pool = nullptr;     // device mirror of the samples [cursor_at_upload ..)
     int64_t d_pool_base = 0, d_pool_count = 0;
     int64_t d_pool_cap = 0;
@@ -363,8 +362,8 @@ extern "C" int lqrrt_device_count(void) {
 
 static void free_all(lqrrt_engine* e) {
     void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_og, e->d_cell_start, e->d_cell_items, e->d_S, e->tv.state, e->tv.trig, e->tv.K, e->tv.pID, e->tv.elen,
-                    e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_pcost_all, e->d_wcost,
-                    e->d_pidx, e->d_pidx_all, e->d_wid, e->d_par_done, e->d_par_want, e->d_list,
+                    e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_pcost_all,
+                    e->d_pidx, e->d_pidx_all, e->d_par_done, e->d_par_want, e->d_list,
                     e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_cand, e->d_flags};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -517,8 +516,6 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     if (!rc) rc = dalloc(&e->d_pcost_all, pw);
     if (!rc) rc = dalloc(&e->d_pidx, pw);
     if (!rc) rc = dalloc(&e->d_pidx_all, pw);
-    if (!rc) rc = dalloc(&e->d_wcost, (size_t)e->maxW);
-    if (!rc) rc = dalloc(&e->d_wid, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_par_done, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_par_want, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_list, (size_t)e->maxW);
@@ -649,8 +646,7 @@ extern "C" int lqrrt_tree_reset(lqrrt_engine* e, const double* x0_host, void* st
     if (!e || !x0_host) return fail(LQRRT_E_ARG, "null argument");
     TRY(use_device(e));
     hipStream_t st = (hipStream_t)stream;
-    double* d_x0 = e->d_wcost;    // scratch (>= 1 double... need n): use pcost
-    d_x0 = e->d_pcost;
+    double* d_x0 = e->d_pcost;    // scratch: the scan partials are idle while the tree is being reset
     HIPCHK(hipMemcpyAsync(d_x0, x0_host, sizeof(double) * e->n, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(e->tv.ignore, 0, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1), st));
     DISPATCH(e, hipLaunchKernelGGL((k_tree_root<S>), dim3(1), dim3(64), 0, st, e->P, e->tv, d_x0));
