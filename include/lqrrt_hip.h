@@ -92,6 +92,16 @@ typedef struct {
     double  goal[LQRRT_MAX_STATES];      /* planner.py:476                                */
     double  goal_lo[LQRRT_MAX_STATES];   /* goal - buffer, strict test planner.py:442-447 */
     double  goal_hi[LQRRT_MAX_STATES];   /* goal + buffer                                 */
+    /* Adaptive-horizon heuristic (horizon given as (min,max), planner.py:418-425, 538-547).  Because the
+     * reference doubles horizon_iters whenever the step counter reaches it, a rollout is never stopped
+     * by the horizon before max/dt steps; what the mode changes is the extra stop rule "every error
+     * component grew -> discard the edge".  horizon_iters above must then be int(max/dt); the engine
+     * replays the halving/doubling of the reference's horizon_iters over the committed attempts
+     * (lqrrt_engine_horizon_iters) starting from horizon_iters_state, clipped to [hspan_min, horizon_iters]. */
+    int32_t adaptive;
+    int32_t hspan_min;
+    int32_t horizon_iters_state;
+    int32_t reserved;
 } lqrrt_resolution;
 
 /* Default sampler description (planner.py:176-211). */
@@ -138,6 +148,9 @@ int lqrrt_engine_destroy(lqrrt_engine* e);
 
 /* Changing horizon_iters re-lays out the edge pools: call lqrrt_tree_reset afterwards. */
 int lqrrt_engine_set_resolution(lqrrt_engine* e, const lqrrt_resolution* r);
+
+/* Current value of the reference's Planner.horizon_iters in adaptive mode (planner.py:421,424). */
+int lqrrt_engine_horizon_iters(lqrrt_engine* e);
 
 /* Constant dense cost-to-go matrix S = lqr(x,u)[0] of the system (host, n x n row-major);
  * NULL = identity, which is what every demo of the reference returns (e.g.

@@ -33,7 +33,8 @@ class Resolution(C.Structure):
     _fields_ = [("dt", C.c_double), ("FPR", C.c_double), ("horizon_iters", C.c_int32),
                 ("has_goal", C.c_int32), ("error_tol", C.c_double * MAX_STATES),
                 ("goal", C.c_double * MAX_STATES), ("goal_lo", C.c_double * MAX_STATES),
-                ("goal_hi", C.c_double * MAX_STATES)]
+                ("goal_hi", C.c_double * MAX_STATES), ("adaptive", C.c_int32), ("hspan_min", C.c_int32),
+                ("horizon_iters_state", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SamplerDesc(C.Structure):
@@ -62,6 +63,7 @@ SIGNATURES = {
     "lqrrt_engine_destroy": (_I, [_P]),
     "lqrrt_engine_set_resolution": (_I, [_P, C.POINTER(Resolution)]),
     "lqrrt_engine_set_sampler": (_I, [_P, C.POINTER(SamplerDesc)]),
+    "lqrrt_engine_horizon_iters": (_I, [_P]),
     "lqrrt_engine_set_dense_S": (_I, [_P, _P]),
     "lqrrt_engine_set_mt19937": (_I, [_P, _P, _I]),
     "lqrrt_engine_get_mt19937": (_I, [_P, _P, C.POINTER(_I)]),

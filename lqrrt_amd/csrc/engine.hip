@@ -162,6 +162,9 @@ struct lqrrt_engine {
     unsigned char* d_flags = nullptr;
     int cand_cap = 0;
 
+    // the reference's Planner.horizon_iters in adaptive-horizon mode (replayed over committed attempts)
+    int h_iters = 1, hspan_min = 1;
+
     // adaptive wave size (exactness does not depend on W, only speed does)
     double ctl_w = 0.0;
 
@@ -571,7 +574,9 @@ extern "C" int lqrrt_engine_set_resolution(lqrrt_engine* e, const lqrrt_resoluti
     if (r->horizon_iters < 1 || r->horizon_iters > 4096) return fail(LQRRT_E_ARG, "horizon_iters out of range");
     if (!(r->dt > 0)) return fail(LQRRT_E_ARG, "dt must be positive");
     TRY(use_device(e));
-    e->res.dt = r->dt; e->res.FPR = r->FPR; e->res.H = r->horizon_iters; e->res.pad = 0;
+    e->res.dt = r->dt; e->res.FPR = r->FPR; e->res.H = r->horizon_iters; e->res.adaptive = r->adaptive ? 1 : 0;
+    e->hspan_min = std::max(1, (int)r->hspan_min);
+    e->h_iters = r->adaptive ? std::max(1, (int)r->horizon_iters_state) : r->horizon_iters;
     for (int d = 0; d < MAXN; ++d) {
         e->res.tol[d] = r->error_tol[d];
         e->res.goal_lo[d] = r->goal_lo[d];
@@ -598,6 +603,8 @@ extern "C" int lqrrt_engine_set_resolution(lqrrt_engine* e, const lqrrt_resoluti
     }
     return 0;
 }
+
+extern "C" int lqrrt_engine_horizon_iters(lqrrt_engine* e) { return e ? e->h_iters : LQRRT_E_ARG; }
 
 extern "C" int lqrrt_engine_set_sampler(lqrrt_engine* e, const lqrrt_sampler_desc* s) {
     if (!e || !s) return fail(LQRRT_E_ARG, "null argument");
@@ -1173,6 +1180,20 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
         // ranks are read by the kernel straight from pinned host memory (written before the launch)
         DISPATCH(e, hipLaunchKernelGGL((k_append<S>), dim3(C), dim3(64), 0, st, e->tv, e->d_rec, e->L, C, base, e->h_rank_dev, e->d_par_done));
         HIPCHK(hipGetLastError());
+    }
+    if (e->res.adaptive) {
+        // replay planner.py:418-425 over the committed attempts, in order: horizon_iters doubles whenever
+        // the step counter reaches it and halves when a rollout is stopped by error growth
+        const int hmax = e->res.H;
+        auto clipi = [&](double v) { return (int)std::min((double)hmax, std::max((double)e->hspan_min, v)); };
+        for (int t = 0; t < C; ++t) {
+            const int steps = flg[t] >> 8;
+            const bool grew = (flg[t] & 2) != 0;
+            const int upto = grew ? steps - 1 : steps;
+            for (int i = 1; i <= upto; ++i)
+                if (i == e->h_iters) e->h_iters = clipi(2.0 * e->h_iters);
+            if (grew) e->h_iters = clipi(e->h_iters / 2.0);
+        }
     }
     // host mirrors + goal bookkeeping (planner.py:260-283)
     for (int t = 0; t < C; ++t) {

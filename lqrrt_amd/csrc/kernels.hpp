@@ -29,7 +29,7 @@ struct Res {
     double dt, FPR;
     double tol[MAXN];
     double goal_lo[MAXN], goal_hi[MAXN];
-    int H, pad;
+    int H, adaptive;        // adaptive != 0: also stop (and discard the edge) when every |error| grew, planner.py:418-421
 };
 
 // A table of candidate parent nodes: either the tree (SoA) or the wave records (AoS).
@@ -405,6 +405,10 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
     }
 
     int cnt = 0, steps = 0;
+    bool grew = false;
+    double last[S::N];
+#pragma unroll
+    for (int d = 0; d < S::N; ++d) last[d] = INFINITY;           // planner.py:377
     while (true) {
         double e[S::N], u[S::M], uc[S::M], xn[S::N], trn[2 * S::NW + 1];
         erf_cached<S>(xt, ttrig, x, trig, e);                    // planner.py:386
@@ -422,6 +426,14 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
             break;
         }
         ++steps;                                                 // planner.py:414
+        if (r.adaptive) {                                        // planner.py:418-425
+            bool all_grew = true;
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) all_grew = all_grew && (fabs(e[d]) >= last[d]);
+            if (all_grew) { cnt = 0; grew = true; break; }       // discard the whole edge
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) last[d] = fabs(e[d]);
+        }
         bool conv = true;
 #pragma unroll
         for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= tol_l[d]);
@@ -463,7 +475,9 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
     }
     if (lane == 0) {
         my[L.off_len] = (double)cnt;
-        my[L.off_flags] = (double)flags;
+        // flags: bit 0 = end state in the goal region, bit 1 = stopped by error growth,
+        //        bits 8.. = number of completed steps (for the horizon_iters replay on the host)
+        my[L.off_flags] = (double)(flags | (grew ? 2 : 0) | (steps << 8));
     }
 }
 

@@ -49,9 +49,11 @@ class Engine(object):
             pass
 
     # -- configuration -------------------------------------------------------------------------
-    def set_resolution(self, dt, FPR, horizon_iters, error_tol, goal, goal_buffer):
+    def set_resolution(self, dt, FPR, horizon_iters, error_tol, goal, goal_buffer, adaptive=False, hspan_min=1,
+                       horizon_iters_state=1):
         r = nat.Resolution()
         r.dt, r.FPR, r.horizon_iters = float(dt), float(FPR), int(horizon_iters)
+        r.adaptive, r.hspan_min, r.horizon_iters_state = (1 if adaptive else 0), int(hspan_min), int(horizon_iters_state)
         tol = np.broadcast_to(np.asarray(error_tol, dtype=np.float64), (self.n,))
         for i in range(nat.MAX_STATES):
             r.error_tol[i] = tol[i] if i < self.n else np.inf
@@ -68,6 +70,9 @@ class Engine(object):
                 r.goal_hi[i] = g[i] + b[i]
         nat.check(nat.lib().lqrrt_engine_set_resolution(self.h, C.byref(r)))
         self.horizon_iters = int(horizon_iters)
+
+    def horizon_iters_state(self):
+        return nat.check(nat.lib().lqrrt_engine_horizon_iters(self.h))
 
     def set_sampler(self, centers, spans, goal_bias, tries_limit):
         s = nat.SamplerDesc()

@@ -155,8 +155,14 @@ class Planner:
 
         # Reset the tree on the device (planner.py:172)
         eng = self._get_engine()
-        eng.set_resolution(self.dt, self.FPR, self.horizon_iters, self.error_tol, self.goal,
-                           self.constraints.goal_buffer)
+        if self.hfactor:
+            # adaptive horizon: rollouts go to hspan[1] steps (see include/lqrrt_hip.h, lqrrt_resolution.adaptive)
+            eng.set_resolution(self.dt, self.FPR, int(self.hspan[1]), self.error_tol, self.goal,
+                               self.constraints.goal_buffer, adaptive=True, hspan_min=int(self.hspan[0]),
+                               horizon_iters_state=int(self.horizon_iters))
+        else:
+            eng.set_resolution(self.dt, self.FPR, self.horizon_iters, self.error_tol, self.goal,
+                               self.constraints.goal_buffer)
         eng.tree_reset(x0)
         user_sampler = hasattr(xrand_gen, '__call__')
         if not user_sampler:
@@ -222,6 +228,8 @@ class Planner:
 
         if not user_sampler:
             eng.sync_numpy_global()
+        if self.hfactor:
+            self.horizon_iters = eng.horizon_iters_state()       # planner.py:421,424: the heuristic's state persists
         self.stats = total.as_dict() if total is not None else None
 
         if self.killed or self.tree.size > self.max_nodes:
@@ -350,8 +358,9 @@ class Planner:
                 raise ValueError("The minimum horizon must be at least as big as dt.")
             if self.horizon[0] >= self.horizon[1]:
                 raise ValueError("A horizon range tuple must be given as (min, max) where min < max.")
-            raise NotImplementedError("the adaptive-horizon heuristic (planner.py:418-425) carries state from one "
-                                      "steer to the next and is not available in the wave engine yet")
+            self.horizon_iters = 1
+            self.hspan = np.divide(self.horizon, self.dt).astype(np.int64)
+            self.hfactor = int(2)
         elif self.horizon >= self.dt:
             self.horizon_iters = int(self.horizon / self.dt)
             self.hspan = (self.horizon_iters, self.horizon_iters)

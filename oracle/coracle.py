@@ -80,6 +80,15 @@ class COracle(object):
         centers, spans, bias = _f(np.mean(space, axis=1)), _f(np.diff(space).flatten()), _f(goal_bias)
         lib().orc_set_sampler(self.h, _p(centers), _p(spans), _p(bias), int(tries))
 
+    def set_adaptive(self, hspan_min, hspan_max, state=1):
+        """horizon=(min,max) mode; call after configure (H = hspan_max) and before reset."""
+        lib().orc_set_adaptive(self.h, int(hspan_min), int(hspan_max), int(state))
+        self.H = int(hspan_max)
+
+    @property
+    def horizon_iters(self):
+        return lib().orc_horizon_iters(self.h)
+
     def seed(self, seed):
         st = np.random.RandomState(seed).get_state()
         key = np.ascontiguousarray(st[1], dtype=np.uint32)
@@ -182,12 +191,19 @@ class COracle(object):
         return out
 
 
-def make(system, max_nodes, seed=1, tries=10):
-    """COracle configured with the demo's PLAN kwargs, seeded and reset at x0."""
+def make(system, max_nodes, seed=1, tries=10, horizon=None):
+    """COracle configured with the demo's PLAN kwargs (or an explicit horizon / (min,max) pair), seeded, reset at x0."""
     o = COracle(system, capacity=int(max_nodes) + 8)
     kw = system.plan_kwargs
-    o.configure(kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]), system.error_tol, system.goal, system.goal_buffer,
-                system.sample_space, system.goal_bias, tries)
+    horizon = kw["horizon"] if horizon is None else horizon
+    if hasattr(horizon, "__len__"):
+        hspan = np.divide(horizon, kw["dt"]).astype(np.int64)
+        o.configure(kw["dt"], kw["FPR"], int(hspan[1]), system.error_tol, system.goal, system.goal_buffer,
+                    system.sample_space, system.goal_bias, tries)
+        o.set_adaptive(hspan[0], hspan[1], 1)
+    else:
+        o.configure(kw["dt"], kw["FPR"], int(horizon / kw["dt"]), system.error_tol, system.goal, system.goal_buffer,
+                    system.sample_space, system.goal_bias, tries)
     o.seed(seed)
     o.reset(system.x0)
     return o

@@ -40,6 +40,7 @@ typedef struct {
     double og_ox, og_oy, og_cpm, og_thr;
     double dt, FPR, tol[MAXN], goal[MAXN], glo[MAXN], ghi[MAXN];
     int H;
+    int adaptive, hspan_min, hspan_max, h_iters;   /* adaptive horizon, planner.py:418-425,538-547 */
     double centers[MAXN], spans[MAXN], bias[MAXN];
     int tries;
     /* MT19937 */
@@ -335,6 +336,12 @@ void orc_set_resolution(orc* o, double dt, double FPR, int H, const double* tol,
     for (int d = 0; d < o->n; ++d) { o->tol[d] = tol[d]; o->goal[d] = goal[d]; o->glo[d] = goal_lo[d]; o->ghi[d] = goal_hi[d]; }
 }
 
+/* horizon given as (min,max): H must be int(max/dt); horizon_iters starts at `state` (1 after set_resolution) */
+void orc_set_adaptive(orc* o, int hspan_min, int hspan_max, int state) {
+    o->adaptive = 1; o->hspan_min = hspan_min; o->hspan_max = hspan_max; o->h_iters = state; o->H = hspan_max;
+}
+int orc_horizon_iters(const orc* o) { return o->h_iters; }
+
 void orc_set_sampler(orc* o, const double* centers, const double* spans, const double* bias, int tries) {
     for (int d = 0; d < o->n; ++d) { o->centers[d] = centers[d]; o->spans[d] = spans[d]; o->bias[d] = bias[d]; }
     o->tries = tries;
@@ -409,8 +416,14 @@ static int nearest(const orc* o, const double* xs, const double* Sd, int pruning
     return bi >= 0 ? bi : bai;
 }
 
+static int clip_h(const orc* o, double v) {
+    double t = v < (double)o->hspan_min ? (double)o->hspan_min : v;
+    t = t > (double)o->hspan_max ? (double)o->hspan_max : t;
+    return (int)t;
+}
+
 /* planner.py:354-438; returns the number of recorded steps, xs/us hold them */
-static int steer(const orc* o, int ID, const double* xt, double* xs, double* us) {
+static int steer(orc* o, int ID, const double* xt, double* xs, double* us) {
     const int n = o->n, m = o->m;
     double x[MAXN], K[MAXM * MAXN], tr[4], tt[4];
     memcpy(x, o->state + (size_t)ID * n, sizeof(double) * n);
@@ -418,6 +431,8 @@ static int steer(const orc* o, int ID, const double* xt, double* xs, double* us)
     memcpy(K, o->K + (size_t)ID * m * n, sizeof(double) * m * n);
     trig_of(o, xt, tt);
     int cnt = 0, steps = 0;
+    double last[MAXN];
+    for (int d = 0; d < n; ++d) last[d] = INFINITY;
     for (;;) {
         double e[MAXN], u[MAXM], uc[MAXM], xn[MAXN], trn[4];
         erf_cached(o, xt, tt, x, tr, e);
@@ -430,9 +445,18 @@ static int steer(const orc* o, int ID, const double* xt, double* xs, double* us)
         trig_of(o, xn, trn);
         if (!feasible(o, xn, u, trn)) { cnt = (int)(o->FPR * (double)cnt); break; }
         ++steps;
+        int horizon = o->H;
+        if (o->adaptive) {                                           /* planner.py:418-425 */
+            int grew = 1;
+            for (int d = 0; d < n; ++d) grew = grew && (fabs(e[d]) >= last[d]);
+            if (grew) { cnt = 0; o->h_iters = clip_h(o, o->h_iters / 2.0); break; }
+            if (steps == o->h_iters) o->h_iters = clip_h(o, 2.0 * o->h_iters);
+            for (int d = 0; d < n; ++d) last[d] = fabs(e[d]);
+            horizon = o->h_iters;
+        }
         int conv = 1;
         for (int d = 0; d < n; ++d) conv = conv && (fabs(e[d]) <= o->tol[d]);
-        if (steps > o->H || conv) break;
+        if (steps > horizon || conv) break;
         memcpy(xs + (size_t)cnt * n, xn, sizeof(double) * n);
         memcpy(us + (size_t)cnt * m, u, sizeof(double) * m);
         ++cnt;

@@ -34,7 +34,7 @@ def test_struct_sizes_match_header():
     # sizes implied by include/lqrrt_hip.h (natural alignment)
     import ctypes as C
     assert C.sizeof(nat.SystemDesc) == 16 + 8 * 96 + 16 + 16 + 8 + 8 + 16 + 8 + 8
-    assert C.sizeof(nat.Resolution) == 16 + 8 + 4 * 8 * 12
+    assert C.sizeof(nat.Resolution) == 16 + 8 + 4 * 8 * 12 + 16
     assert C.sizeof(nat.SamplerDesc) == 3 * 8 * 12 + 8
     assert C.sizeof(nat.ExtendStats) == 8 * 8 + 8
 

@@ -17,7 +17,8 @@ import coracle
 import lqrrt_amd
 
 CASES = [("boat_advanced", "200"), ("boat_intermediate", "300"), ("boat_novice", "300"), ("car", "500"),
-         ("pendulum", "150"), ("car", "2000"), ("car", "firstgoal"), ("boat_novice", "firstgoal")]
+         ("pendulum", "150"), ("car", "2000"), ("car", "firstgoal"), ("boat_novice", "firstgoal"),
+         ("boat_intermediate", "adaptive"), ("car", "adaptive")]
 
 
 @pytest.mark.parametrize("name,tag", CASES)
@@ -27,7 +28,7 @@ def test_coracle_trajectory(golden_dir, name, tag):
         pytest.skip("fixture missing")
     g = np.load(path)
     s = lqrrt_amd.systems.SYSTEMS[name](0)
-    o = coracle.make(s, int(g["max_nodes"]), seed=1)
+    o = coracle.make(s, int(g["max_nodes"]), seed=1, horizon=(0.1, 3) if tag == "adaptive" else None)
     o.enable_trace(int(g["iterations"]) + 16)
     first_goal = float(g["min_time"]) == 0.0
     reason = o.extend(max_nodes=int(g["max_nodes"]), stop_on_goal=first_goal)
@@ -54,6 +55,8 @@ def test_coracle_trajectory(golden_dir, name, tag):
             np.testing.assert_allclose(x, g["edge_%s_x" % t], rtol=0, atol=1e-9)
             np.testing.assert_allclose(u, g["edge_%s_u" % t], rtol=0, atol=1e-6)
     assert (o.hits > 0) == bool(g["reached_goal"])
+    if tag == "adaptive":
+        assert o.horizon_iters == int(g["horizon_iters_final"])
 
 
 @pytest.mark.parametrize("name", ["boat_advanced", "boat_intermediate", "boat_novice", "car", "pendulum"])

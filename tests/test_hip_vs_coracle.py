@@ -71,6 +71,31 @@ def test_bit_exact_vs_sequential_oracle(name, nodes, wave):
     _compare(eng, stats, o)
 
 
+def test_bit_exact_adaptive_horizon():
+    """horizon=(min,max): the reference's adaptive-horizon heuristic (planner.py:418-425) in waves."""
+    import coracle
+    import lqrrt_amd
+    from lqrrt_amd.engine import Engine
+    for name, nodes, wave in (("boat_advanced", 1500, 512), ("car", 1200, 256)):
+        s = lqrrt_amd.systems.SYSTEMS[name](0)
+        kw = s.plan_kwargs
+        hspan = np.divide((0.1, 3), kw["dt"]).astype(np.int64)
+        eng = Engine(s, capacity=nodes + wave + 8, max_wave=wave)
+        eng.set_resolution(kw["dt"], kw["FPR"], int(hspan[1]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer),
+                           adaptive=True, hspan_min=int(hspan[0]), horizon_iters_state=1)
+        space = np.array(s.sample_space, dtype=np.float64)
+        eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), np.array(s.goal_bias, dtype=np.float64), 10)
+        st = np.random.RandomState(1).get_state()
+        eng.set_mt19937(st[1], st[2])
+        eng.tree_reset(s.x0)
+        stats = eng.extend(wave, node_limit=nodes)
+        o = coracle.make(s, nodes + wave + 8, seed=1, horizon=(0.1, 3))
+        assert o.extend(max_nodes=nodes) == 2
+        _compare(eng, stats, o)
+        assert eng.horizon_iters_state() == o.horizon_iters
+        assert eng.edge_lengths().max() == 30
+
+
 def test_bit_exact_double_integrator_dense_S():
     """BASELINE.json config 5 at test size: 12-state double integrator, dense DARE cost-to-go matrix,
     box obstacles; exercises the DENSE cost path and numpy's >= 8-term summation order."""

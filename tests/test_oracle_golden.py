@@ -94,15 +94,17 @@ def test_costs_to_go(sys_and_ops):
 
 
 TRAJ = [("boat_advanced", "200"), ("boat_intermediate", "300"), ("boat_novice", "300"), ("car", "500"),
-        ("pendulum", "150"), ("car", "2000"), ("car", "firstgoal"), ("boat_novice", "firstgoal")]
+        ("pendulum", "150"), ("car", "2000"), ("car", "firstgoal"), ("boat_novice", "firstgoal"),
+        ("boat_intermediate", "adaptive"), ("car", "adaptive")]
 
 
 @pytest.mark.parametrize("name,tag", TRAJ)
 def test_trajectory(golden_dir, name, tag):
     g = _load(golden_dir, "traj_%s_%s.npz" % (name, tag))
     s = SYSTEMS[name](0)
+    extra = dict(horizon=(0.1, 3)) if tag == "adaptive" else {}       # adaptive-horizon heuristic, planner.py:418-425
     p = make_oracle_planner(s, int(g["max_nodes"]), min_time=float(g["min_time"]),
-                            max_time=max(float(g["min_time"]), 1.0))
+                            max_time=max(float(g["min_time"]), 1.0), **extra)
     np.random.seed(1)
     ret = p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10, trace=True)
     assert ret == bool(g["returned"])
@@ -127,6 +129,8 @@ def test_trajectory(golden_dir, name, tag):
     np.testing.assert_allclose(np.array(p.x_seq), g["plan_x"], rtol=0, atol=ATOL)
     np.testing.assert_allclose(np.array(p.u_seq), g["plan_u"], rtol=0, atol=1e-7)
     assert p.T == float(g["plan_T"])
+    if tag == "adaptive":
+        assert p.horizon_iters == int(g["horizon_iters_final"])
     # interpolators (planner.py:451-464)
     tq = 0.37 * p.T
     assert np.all(np.isfinite(p.get_state(tq))) and np.all(np.isfinite(p.get_effort(tq)))

@@ -147,9 +147,11 @@ def gen_ops(name):
 
 # --------------------------------------------------------------------------- trajectory level
 
-def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None):
+def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None, horizon=None):
     ns = rl.load_demo(name, OBS_SEED)
     planner = rl.make_planner(name, ns, max_nodes, min_time=min_time)
+    if horizon is not None:
+        planner.set_resolution(horizon=horizon)            # (min, max) -> adaptive-horizon heuristic
     n = ns["nstates"]
 
     xrands, nearest, slen, ties = [], [], [], []
@@ -201,7 +203,7 @@ def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None):
         plan_x=np.array(planner.x_seq, dtype=np.float64), plan_u=np.array(planner.u_seq, dtype=np.float64),
         plan_T=np.float64(planner.T), pid_hash=np.array(pid_hash(tree.pID)),
         state_sum=np.float64(tree.state.sum()), ref_wall_s=np.float64(wall),
-        tie_iterations=np.int64(np.sum(ties)),
+        tie_iterations=np.int64(np.sum(ties)), horizon_iters_final=np.int64(planner.horizon_iters),
     )
     # a few complete edges (first, a middle one, the last) to pin x_seq/u_seq contents
     for tagid, ID in (("a", 1), ("b", tree.size // 2), ("c", tree.size - 1)):
@@ -281,6 +283,9 @@ def main():
         run_traj("car", 2000, keep_xrand=64)
         run_traj("car", 2000, keep_xrand=64, tag="firstgoal", min_time=0)
         run_traj("boat_novice", 1000, keep_xrand=64, tag="firstgoal", min_time=0)
+    if "adaptive" in what or "traj" in what:
+        run_traj("boat_intermediate", 400, keep_xrand=64, tag="adaptive", horizon=(0.1, 3))
+        run_traj("car", 400, keep_xrand=64, tag="adaptive", horizon=(0.1, 3))
         run_traj("boat_advanced", 3000, keep_xrand=64)
 
 
