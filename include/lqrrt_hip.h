@@ -50,6 +50,7 @@ extern "C" {
 #define LQRRT_MODEL_CAR                4  /* demos/demo_car.py:46-180               */
 #define LQRRT_MODEL_PENDULUM           5  /* demos/demo_pendulum.py:54-157          */
 #define LQRRT_MODEL_DOUBLE_INTEGRATOR  6  /* BASELINE.json config 5 (not in the reference) */
+#define LQRRT_MODEL_ROS_BOAT           7  /* demos/lqrrt_ros/behaviors/{boat,car,escape}.py  */
 
 #define LQRRT_MAX_STATES   12
 #define LQRRT_MAX_CONTROLS 6

@@ -189,6 +189,7 @@ struct lqrrt_engine {
         case LQRRT_MODEL_CAR:               { using S = Car;              __VA_ARGS__; } break;   \
         case LQRRT_MODEL_PENDULUM:          { using S = Pendulum;         __VA_ARGS__; } break;   \
         case LQRRT_MODEL_DOUBLE_INTEGRATOR: { using S = DoubleIntegratorT<6>; __VA_ARGS__; } break; \
+        case LQRRT_MODEL_ROS_BOAT:          { using S = RosBoat;          __VA_ARGS__; } break;   \
         default: return fail(LQRRT_E_ARG, "unknown model %d", (e)->model);                        \
     }
 
@@ -211,6 +212,7 @@ static bool model_dims(int model, int* n, int* m, int* nw) {
     switch (model) {
         case LQRRT_MODEL_BOAT_ADVANCED:
         case LQRRT_MODEL_BOAT_INTERMEDIATE:
+        case LQRRT_MODEL_ROS_BOAT:
         case LQRRT_MODEL_BOAT_NOVICE: *n = 6; *m = 3; *nw = 1; return true;
         case LQRRT_MODEL_CAR: *n = 5; *m = 2; *nw = 1; return true;
         case LQRRT_MODEL_PENDULUM: *n = 4; *m = 1; *nw = 2; return true;

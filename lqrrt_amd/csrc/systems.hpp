@@ -305,6 +305,77 @@ struct BoatNovice : BoatCommon {
     }
 };
 
+// The three behaviours of the reference's ROS package (demos/lqrrt_ros/behaviors/{boat,car,escape}.py) are
+// one 4-thruster boat with different heading terms, saturation rules and gains; `mode` words select them.
+struct RosBoat : BoatCommon {
+    // params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 B[3][4] | 21 invB[4][3] | 33 thrust_max[4] | 37 rudder gain
+    //         38 rudder mode (0 none, 1 stare at focus point: boat.py:34-42, 2 along the velocity: car.py:36-43)
+    //         39 focus[2] | 41 saturation (0 even downscaling: boat.py:44-48, 1 per-thruster clip: car.py:46)
+    //         42 no-reverse rule (car.py:54-56) | 43 kp[3] | 46 kd[3]
+    __device__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
+        gain_pd(P + 43, P + 46, trig, K);
+    }
+    __device__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+        const double c = trig[0], s = trig[1];
+        const int rmode = (int)P[38];
+        if (rmode == 1) {            // u[2] is REPLACED, not incremented (boat.py:42)
+            const double ang = lq_atan2(P[40] - x[1], P[39] - x[0]);
+            double cg, sg;
+            lq_sincos(ang, &sg, &cg);
+            u[2] = P[37] * wrap_err(cg, sg, c, s);
+        } else if (rmode == 2) {     // car.py:43
+            u[2] = rudder_term(P[37], x, c, s);
+        }
+        double t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double a = P[21 + 3 * j] * u[0];
+            a += P[21 + 3 * j + 1] * u[1];
+            a += P[21 + 3 * j + 2] * u[2];
+            t[j] = a;
+        }
+        double us[3] = {u[0], u[1], u[2]};
+        bool remap = false;
+        if ((int)P[41] == 0) {
+            // ratios = thrust_max / clip(|thrusts|, 1e-6, inf); if any < 1: u = B.(min(ratios) * thrusts)
+            double rmin = INFINITY;
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double ratio = P[33 + j] / clipd(fabs(t[j]), 1e-6, INFINITY);
+                any = any || (ratio < 1.0);
+                rmin = ratio < rmin ? ratio : rmin;
+            }
+            if (any) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = rmin * t[j];
+                remap = true;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = clipd(t[j], -P[33 + j], P[33 + j]);
+            remap = true;
+        }
+        if (remap) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double a = P[9 + 4 * i] * t[0];
+                a += P[9 + 4 * i + 1] * t[1];
+                a += P[9 + 4 * i + 2] * t[2];
+                a += P[9 + 4 * i + 3] * t[3];
+                us[i] = a;
+            }
+        }
+        euler(P + 0, P + 3, P + 6, x, c, s, us, dt, xn);
+        if ((int)P[42] && xn[3] < 0.0) xn[3] = fabs(x[3]);
+    }
+    __device__ static bool feasible(const double*, const Geo& g, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
+        if (g.og) return !grid_hits(g, x[0], x[1], trig[0], trig[1], lane);   // lqrrt_node.py:719-745
+        if (g.O == 0) return true;                                            // no map yet: anywhere is valid (:726-727)
+        return !hull_hits(gl, x[0], x[1], trig[0], trig[1], false, lane);
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Car: state [x, y, h, vx, vh], effort [ux, uh]  (demos/demo_car.py)
 

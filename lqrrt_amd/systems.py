@@ -141,7 +141,7 @@ class NativeSystem(object):
         Optionally replaces the hull points (e.g. behaviors/params.py's 0.1 m lattice).  Engines already
         created keep the old model.
         """
-        if self.model not in (nat.MODEL_BOAT_ADVANCED, nat.MODEL_BOAT_INTERMEDIATE, nat.MODEL_CAR):
+        if self.model not in (nat.MODEL_BOAT_ADVANCED, nat.MODEL_BOAT_INTERMEDIATE, nat.MODEL_CAR, nat.MODEL_ROS_BOAT):
             raise ValueError("occupancy-grid feasibility is defined for the hull-sweeping vehicles")
         if (resolution is None) == (cpm is None):
             raise ValueError("give exactly one of resolution (m/cell) or cpm (cells/m)")
@@ -322,6 +322,91 @@ class BoatNovice(_Boat):
                                np.diag(self.kd), [self.boat_length / 2]))
 
 
+class RosBoat(_Boat):
+    """
+    The boat of the reference's ROS package with its three behaviours
+    (demos/lqrrt_ros/behaviors/{params,boat,car,escape}.py):
+      'boat'   holonomic, optional focus point to stare at, even-downscaling thruster saturation
+      'car'    heading along the velocity line, per-thruster clipping, no reversing, S = diag(1,1,1,0,0,0)
+      'escape' holonomic, no heading term, even downscaling
+    They are meant to be planned with horizon=(0.1, 3) (adaptive-horizon heuristic) and FPR=0, and with the
+    occupancy-grid feasibility of the node (set_occupancy_grid); without a map everything is feasible.
+    params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 B[3][4] | 21 invB[4][3] | 33 thrust_max[4] | 37 rudder |
+            38 rudder mode | 39 focus[2] | 41 saturation mode | 42 no-reverse | 43 kp[3] | 46 kd[3]
+    """
+    model = nat.MODEL_ROS_BOAT
+    plan_kwargs = dict(horizon=(0.1, 3), dt=0.1, FPR=0)     # behaviors/params.py:31-33
+
+    def __init__(self, behavior="boat", focus=None):
+        NativeSystem.__init__(self)
+        if behavior not in ("boat", "car", "escape"):
+            raise ValueError("behavior must be 'boat', 'car' or 'escape'")
+        self.behavior = behavior
+        self.focus = None if focus is None else np.array(focus, dtype=np.float64)
+        m, I = 350, 400                                                     # params.py:40-42
+        self.invM = np.array([1 / m, 1 / m, 1 / I])
+        self.velmax_pos = np.array([1.2, 0.6, 0.22])
+        self.velmax_neg = np.array([-0.6, -0.6, -0.22])
+        self.thrust_max = np.array([220, 220, 220, 220])
+        positions = np.array([[-1.9000, 1.0000, -0.0123], [-1.9000, -1.0000, -0.0123],
+                              [1.6000, 0.6000, -0.0123], [1.6000, -0.6000, -0.0123]])
+        directions = np.array([[0.7071, 0.7071, 0.0000], [0.7071, -0.7071, 0.0000],
+                               [0.7071, -0.7071, 0.0000], [0.7071, 0.7071, 0.0000]])
+        levers = np.cross(positions, directions)
+        self.B = np.concatenate((directions.T, levers.T))[[0, 1, 5]]      # params.py:66
+        self.invB = npl.pinv(self.B)
+        Fx_max = self.B.dot(self.thrust_max * [1, 1, 1, 1])[0]
+        Fy_max = self.B.dot(self.thrust_max * [1, -1, -1, 1])[1]
+        Mz_max = self.B.dot(self.thrust_max * [-1, 1, -1, 1])[2]
+        self.D_pos = np.abs([Fx_max, Fy_max, Mz_max] / self.velmax_pos)
+        self.D_neg = np.abs([Fx_max, Fy_max, Mz_max] / self.velmax_neg)
+        self.boat_length = 210 * 0.0254
+        self.boat_width = 96 * 0.0254
+        self.vps = hull_grid(self.boat_length, self.boat_width, 0.15, 0.1)  # params.py:83-93 (1512 points)
+        self.obs = np.zeros((0, 3))
+        real_tol = [0.5, 0.5, np.deg2rad(10), np.inf, np.inf, np.inf]
+        free_radius = 6
+        if behavior == "boat":
+            self.rudder, self.rudder_mode, self.sat_mode, self.no_reverse = 8000, (1 if focus is not None else 0), 0, 0
+            self.kp, self.kd = np.diag([250, 250, 2500]), np.diag([5, 5, 0.001])
+            self.goal_buffer = [real_tol[0], real_tol[1], real_tol[2], 10, 10, 6]
+            self.error_tol = np.copy(self.goal_buffer)
+        elif behavior == "car":
+            self.rudder, self.rudder_mode, self.sat_mode, self.no_reverse = 6000, 2, 1, 1
+            self.kp, self.kd = np.diag([150, 150, 0]), np.diag([150, 5, 0])
+            self.S = np.diag([1.0, 1.0, 1.0, 0.0, 0.0, 0.0])                # car.py:65
+            self.goal_buffer = [0.5 * free_radius, 0.5 * free_radius, np.inf, np.inf, np.inf, np.inf]
+            self.error_tol = np.copy(self.goal_buffer) / 10
+        else:
+            self.rudder, self.rudder_mode, self.sat_mode, self.no_reverse = 0, 0, 0, 0
+            self.kp, self.kd = np.diag([150, 150, 2000]), np.diag([120, 120, 0.01])
+            self.goal_buffer = [free_radius, free_radius, np.inf, np.inf, np.inf, np.inf]
+            self.error_tol = np.copy(self.goal_buffer)
+        self.x0 = np.zeros(6)
+        self.goal = [30, 20, np.deg2rad(45), 0, 0, 0]
+        self.sample_space = self.gen_ss(self.x0, self.goal)
+        self.goal_bias = [0.3, 0.3, 0, 0, 0, 0]
+
+    def gen_ss(self, seed, goal, buff=None):
+        """Sample space for a seed and goal state (boat.py:86-96, car.py:84-94, escape.py:67-77)."""
+        vp, vn = self.velmax_pos, self.velmax_neg
+        if self.behavior == "escape":
+            buff = 40 if buff is None else buff
+            return [(seed[0] - buff, seed[0] + buff), (seed[1] - buff, seed[1] + buff), (seed[2], seed[2]),
+                    (-abs(vn[0]), vp[0]), (-abs(vn[1]), vp[1]), (-abs(vn[2]), vp[2])]
+        buff = [10] * 4 if buff is None else buff
+        vx = (0.9 * vp[0], vp[0]) if self.behavior == "car" else (-abs(vn[0]), vp[0])
+        return [(min([seed[0], goal[0]]) - buff[0], max([seed[0], goal[0]]) + buff[1]),
+                (min([seed[1], goal[1]]) - buff[2], max([seed[1], goal[1]]) + buff[3]),
+                (-np.pi, np.pi), vx, (-abs(vn[1]), vp[1]), (-abs(vn[2]), vp[2])]
+
+    def params(self):
+        focus = self.focus[:2] if self.focus is not None else [0.0, 0.0]
+        return np.concatenate((self.invM, self.D_pos, self.D_neg, self.B.ravel(), self.invB.ravel(), self.thrust_max,
+                               [self.rudder, self.rudder_mode], focus, [self.sat_mode, self.no_reverse],
+                               np.diag(self.kp), np.diag(self.kd)))
+
+
 # --------------------------------------------------------------------------- car
 
 class Car(NativeSystem):
@@ -457,4 +542,5 @@ SYSTEMS = {
     "car": Car,
     "pendulum": DoublePendulum,
     "double_integrator": DoubleIntegrator,
+    "ros_boat": RosBoat,
 }

@@ -28,7 +28,7 @@
 #define MAXN 12
 #define MAXM 6
 
-enum { BOAT_ADV = 1, BOAT_INT = 2, BOAT_NOV = 3, CAR = 4, PEND = 5, DINT = 6 };
+enum { BOAT_ADV = 1, BOAT_INT = 2, BOAT_NOV = 3, CAR = 4, PEND = 5, DINT = 6, ROS_BOAT = 7 };
 
 typedef struct {
     int model, n, m, nw, wd[2];
@@ -146,6 +146,7 @@ static void gain(const orc* o, const double* x, const double* tr, const double* 
         case BOAT_ADV: kp = P + 40; kd = P + 43; break;
         case BOAT_INT: kp = P + 15; kd = P + 18; break;
         case BOAT_NOV: kp = P + 12; kd = P + 15; break;
+        case ROS_BOAT: kp = P + 43; kd = P + 46; break;
         case CAR:
             K[0] = P[9] * c; K[1] = P[9] * s; K[2] = P[9] * 0.0; K[3] = P[11]; K[4] = 0.0;
             K[5] = P[10] * 0.0; K[6] = P[10] * 0.0; K[7] = P[10] * 1.0; K[8] = 0.0; K[9] = P[12];
@@ -220,6 +221,47 @@ static void step(const orc* o, const double* x, const double* tr, double* u, dou
             for (int i = 0; i < 3; ++i) if (fabs(u[i]) > P[9 + i]) u[i] = P[9 + i] * (u[i] > 0.0 ? 1.0 : -1.0);
             boat_euler(P, P + 3, P + 6, x, c, s, u, dt, xn);
             break;
+        case ROS_BOAT: {                     /* demos/lqrrt_ros/behaviors/{boat,car,escape}.py */
+            const int rmode = (int)P[38];
+            if (rmode == 1) {
+                const double ang = lq_atan2(P[40] - x[1], P[39] - x[0]);
+                double cg, sg;
+                lq_sincos(ang, &sg, &cg);
+                u[2] = P[37] * wrap_err(cg, sg, c, s);
+            } else if (rmode == 2) {
+                u[2] = rudder_term(P[37], x, c, s);
+            }
+            double t[4], us[3] = {u[0], u[1], u[2]};
+            int remap = 0;
+            for (int j = 0; j < 4; ++j) {
+                double a = P[21 + 3 * j] * u[0];
+                a += P[21 + 3 * j + 1] * u[1];
+                a += P[21 + 3 * j + 2] * u[2];
+                t[j] = a;
+            }
+            if ((int)P[41] == 0) {
+                double rmin = INFINITY;
+                int any = 0;
+                for (int j = 0; j < 4; ++j) {
+                    const double ratio = P[33 + j] / clipd(fabs(t[j]), 1e-6, INFINITY);
+                    any = any || (ratio < 1.0);
+                    rmin = ratio < rmin ? ratio : rmin;
+                }
+                if (any) { for (int j = 0; j < 4; ++j) t[j] = rmin * t[j]; remap = 1; }
+            } else {
+                for (int j = 0; j < 4; ++j) t[j] = clipd(t[j], -P[33 + j], P[33 + j]);
+                remap = 1;
+            }
+            if (remap) for (int i = 0; i < 3; ++i) {
+                double a = P[9 + 4 * i] * t[0];
+                a += P[9 + 4 * i + 1] * t[1];
+                a += P[9 + 4 * i + 2] * t[2];
+                a += P[9 + 4 * i + 3] * t[3];
+                us[i] = a;
+            }
+            boat_euler(P, P + 3, P + 6, x, c, s, us, dt, xn);
+            if ((int)P[42] && xn[3] < 0.0) xn[3] = fabs(x[3]);
+        } break;
         case CAR: {
             const double vwx = c * x[3], vwy = s * x[3];
             const double u0 = clipd(u[0], P[4], P[6]), u1 = clipd(u[1], P[5], P[7]);
@@ -261,6 +303,10 @@ static int feasible(const orc* o, const double* x, const double* u, const double
         case BOAT_INT:
             if (o->og) return !grid_hits(o, x[0], x[1], tr[0], tr[1]);
             return !hull_hits(o, x[0], x[1], tr[0], tr[1], 0);
+        case ROS_BOAT:
+            if (o->og) return !grid_hits(o, x[0], x[1], tr[0], tr[1]);
+            if (o->O == 0) return 1;
+            return !hull_hits(o, x[0], x[1], tr[0], tr[1], 0);
         case BOAT_NOV:
             for (int ob = 0; ob < o->O; ++ob) {
                 const double dx = x[0] - o->obs[ob * o->stride], dy = x[1] - o->obs[ob * o->stride + 1];
@@ -292,7 +338,7 @@ orc* orc_create(int model, const double* params, int n_params, const double* vps
     orc* o = (orc*)calloc(1, sizeof(orc));
     o->model = model;
     switch (model) {
-        case BOAT_ADV: case BOAT_INT: case BOAT_NOV: o->n = 6; o->m = 3; o->nw = 1; o->wd[0] = 2; break;
+        case BOAT_ADV: case BOAT_INT: case BOAT_NOV: case ROS_BOAT: o->n = 6; o->m = 3; o->nw = 1; o->wd[0] = 2; break;
         case CAR: o->n = 5; o->m = 2; o->nw = 1; o->wd[0] = 2; break;
         case PEND: o->n = 4; o->m = 1; o->nw = 2; o->wd[0] = 0; o->wd[1] = 1; break;
         case DINT: o->n = 12; o->m = 6; o->nw = 0; break;

@@ -291,6 +291,97 @@ class BoatNovice(_HeadingSystem):
         return True
 
 
+class RosBoat(_HeadingSystem):
+    """demos/lqrrt_ros/behaviors/{params,boat,car,escape}.py: one boat, three behaviours."""
+    nstates, ncontrols = 6, 3
+    plan_kwargs = dict(horizon=(0.1, 3), dt=0.1, FPR=0)     # params.py:31-33
+
+    def __init__(self, behavior="boat", focus=None):
+        self.behavior = behavior
+        self.focus = None if focus is None else np.array(focus, dtype=np.float64)
+        m, I = 350, 400
+        self.invM = np.array([1 / m, 1 / m, 1 / I])
+        self.velmax_pos = np.array([1.2, 0.6, 0.22])
+        self.velmax_neg = np.array([-0.6, -0.6, -0.22])
+        self.thrust_max = np.array([220, 220, 220, 220])
+        pos = np.array([[-1.9, 1.0, -0.0123], [-1.9, -1.0, -0.0123], [1.6, 0.6, -0.0123], [1.6, -0.6, -0.0123]])
+        dirs = np.array([[0.7071, 0.7071, 0.0], [0.7071, -0.7071, 0.0], [0.7071, -0.7071, 0.0], [0.7071, 0.7071, 0.0]])
+        levers = np.cross(pos, dirs)
+        self.B = np.concatenate((dirs.T, levers.T))[[0, 1, 5]]
+        self.invB = npl.pinv(self.B)
+        Fx = self.B.dot(self.thrust_max * [1, 1, 1, 1])[0]
+        Fy = self.B.dot(self.thrust_max * [1, -1, -1, 1])[1]
+        Mz = self.B.dot(self.thrust_max * [-1, 1, -1, 1])[2]
+        self.D_pos = np.abs([Fx, Fy, Mz] / self.velmax_pos)
+        self.D_neg = np.abs([Fx, Fy, Mz] / self.velmax_neg)
+        self.vps = hull_grid(210 * 0.0254, 96 * 0.0254, 0.15, 0.1)
+        self.obs = np.zeros((0, 3))
+        real_tol = [0.5, 0.5, np.deg2rad(10), np.inf, np.inf, np.inf]
+        free_radius = 6
+        self.Smat = np.diag([1, 1, 1, 1, 1, 1])
+        if behavior == "boat":
+            self.rudder = 8000
+            self.kp, self.kd = np.diag([250, 250, 2500]), np.diag([5, 5, 0.001])
+            self.goal_buffer = [real_tol[0], real_tol[1], real_tol[2], 10, 10, 6]
+            self.error_tol = np.copy(self.goal_buffer)
+        elif behavior == "car":
+            self.rudder = 6000
+            self.kp, self.kd = np.diag([150, 150, 0]), np.diag([150, 5, 0])
+            self.Smat = np.diag([1, 1, 1, 0, 0, 0])
+            self.goal_buffer = [0.5 * free_radius, 0.5 * free_radius, np.inf, np.inf, np.inf, np.inf]
+            self.error_tol = np.copy(self.goal_buffer) / 10
+        else:
+            self.kp, self.kd = np.diag([150, 150, 2000]), np.diag([120, 120, 0.01])
+            self.goal_buffer = [free_radius, free_radius, np.inf, np.inf, np.inf, np.inf]
+            self.error_tol = np.copy(self.goal_buffer)
+        self.x0 = np.zeros(6)
+        self.goal = [30, 20, np.deg2rad(45), 0, 0, 0]
+        self.goal_bias = [0.3, 0.3, 0, 0, 0, 0]
+        self.sample_space = self.gen_ss(self.x0, self.goal)
+
+    def gen_ss(self, seed, goal, buff=None):
+        vp, vn = self.velmax_pos, self.velmax_neg
+        if self.behavior == "escape":                      # escape.py:67-77
+            buff = 40 if buff is None else buff
+            return [(seed[0] - buff, seed[0] + buff), (seed[1] - buff, seed[1] + buff), (seed[2], seed[2]),
+                    (-abs(vn[0]), vp[0]), (-abs(vn[1]), vp[1]), (-abs(vn[2]), vp[2])]
+        buff = [10] * 4 if buff is None else buff          # boat.py:86-96 / car.py:84-94
+        vx = (0.9 * vp[0], vp[0]) if self.behavior == "car" else (-abs(vn[0]), vp[0])
+        return [(min([seed[0], goal[0]]) - buff[0], max([seed[0], goal[0]]) + buff[1]),
+                (min([seed[1], goal[1]]) - buff[2], max([seed[1], goal[1]]) + buff[3]),
+                (-np.pi, np.pi), vx, (-abs(vn[1]), vp[1]), (-abs(vn[2]), vp[2])]
+
+    def dynamics(self, x, u, dt):
+        R = rot3(x[2])
+        D = np.where(x[3:] >= 0, self.D_pos, self.D_neg)
+        if self.behavior == "boat" and self.focus is not None:          # boat.py:34-42
+            vec = self.focus[:2] - x[:2]
+            u[2] = self.rudder * wrap_err(np.arctan2(vec[1], vec[0]), x[2])
+        elif self.behavior == "car":                                    # car.py:36-43
+            vw = R[:2, :2].dot(x[3:5])
+            u[2] = self.rudder * wrap_err(np.arctan2(vw[1], vw[0]), x[2])
+        if self.behavior == "car":                                      # car.py:46
+            u = self.B.dot(np.clip(self.invB.dot(u), -self.thrust_max, self.thrust_max))
+        else:                                                           # boat.py:44-48 / escape.py:32-36
+            thrusts = self.invB.dot(u)
+            ratios = self.thrust_max / np.clip(np.abs(thrusts), 1E-6, np.inf)
+            if np.any(ratios < 1):
+                u = self.B.dot(np.min(ratios) * thrusts)
+        xdot = np.concatenate((R.dot(x[3:]), self.invM * (u - D * x[3:])))
+        xn = x + xdot * dt
+        if self.behavior == "car" and xn[3] < 0:                        # car.py:54-56
+            xn[3] = abs(x[3])
+        return xn
+
+    def lqr(self, x, u):
+        return (self.Smat, np.hstack((self.kp.dot(rot3(x[2]).T), self.kd)))
+
+    def is_feasible(self, x, u):
+        if self.ogrid is None:                                          # lqrrt_node.py:726-727
+            return True
+        return self._grid_feasible(x)
+
+
 # --------------------------------------------------------------------------- car
 
 class Car(_HeadingSystem):
@@ -471,6 +562,7 @@ SYSTEMS = {
     "car": Car,
     "pendulum": DoublePendulum,
     "double_integrator": DoubleIntegrator,
+    "ros_boat": RosBoat,
 }
 
 

@@ -259,6 +259,100 @@ def gen_ogrid():
     print("wrote", path, "feasible fraction %.2f, hull points %d" % (ok.mean(), params.vps.shape[1]))
 
 
+# --------------------------------------------------------------------------- ROS behaviours (8f-2)
+
+def _load_behavior(name):
+    """Imports demos/lqrrt_ros/behaviors/<name>.py (it does `from params import *` and builds a Planner)."""
+    import importlib.util
+    rl.import_reference()
+    bdir = os.path.join(rl.REF, "demos", "lqrrt_ros", "behaviors")
+    if bdir not in sys.path:
+        sys.path.insert(0, bdir)
+    spec = importlib.util.spec_from_file_location("ref_behavior_" + name, os.path.join(bdir, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_ros_behaviors():
+    """
+    Operator and trajectory fixtures for the boat / car / escape behaviours of the ROS package, run through
+    their own module-level Planner (adaptive horizon (0.1, 3), FPR 0) with the node's occupancy-grid
+    feasibility (method text compiled as in gen_ogrid) and the node's erf (identical to the demos').
+    """
+    import ast
+    import textwrap
+    import types
+    node_path = os.path.join(rl.REF, "demos", "lqrrt_ros", "nodes", "lqrrt_node.py")
+    src = open(node_path).read()
+    fn = [n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "is_feasible"][0]
+    text = textwrap.dedent("\n".join(src.split("\n")[fn.lineno - 1:fn.end_lineno]))
+    erf = rl.load_demo("boat_novice")["erf"]                # same formula as lqrrt_node.py:996-1016
+    og = np.load(os.path.join(OUT, "ops_ogrid.npz"))
+    grid = np.array(og["grid"], dtype=np.int64)
+    cpm, origin = float(og["cpm"]), og["origin"]
+    x0 = np.zeros(6)
+    goal = np.array([30, 20, np.deg2rad(45), 0, 0, 0])
+    for px, py in ((x0[0], x0[1]), (goal[0], goal[1])):      # free start and goal
+        c, r = int(cpm * (px - origin[0])), int(cpm * (py - origin[1]))
+        grid[max(r - 40, 0):r + 40, max(c - 40, 0):c + 40] = 0
+    for name in ("boat", "car", "escape"):
+        mod = _load_behavior(name)
+        ns = {"np": np, "params": sys.modules["params"]}
+        exec(compile(text, node_path, "exec"), ns)
+        me = types.SimpleNamespace(ogrid=grid, blind=False, ogrid_origin=origin, ogrid_cpm=cpm, ogrid_threshold=90.0)
+        feas = lambda x, u, _f=ns["is_feasible"], _me=me: _f(_me, x, u)
+        rng = np.random.RandomState(5)
+        out = {}
+        # operators
+        xs = np.zeros((256, 6))
+        xs[:, :2] = rng.uniform(-10, 40, (256, 2))
+        xs[:, 2] = rng.uniform(-7, 7, 256)
+        xs[:, 3:] = rng.uniform(-1.3, 1.3, (256, 3))
+        us = rng.uniform(-1, 1, (256, 3)) * np.array([900.0, 900.0, 3000.0])
+        out["dyn_x"], out["dyn_u"] = xs, us
+        out["dyn_xnext"] = np.array([mod.dynamics(np.copy(a), np.copy(b), mod.dt) for a, b in zip(xs, us)])
+        if name == "boat":
+            mod.focus = np.array([12.0, -3.0, 0.0])
+            out["focus"] = mod.focus
+            out["dyn_xnext_focus"] = np.array([mod.dynamics(np.copy(a), np.copy(b), mod.dt) for a, b in zip(xs, us)])
+            mod.focus = None
+        SK = [mod.lqr(np.copy(a), np.zeros(3)) for a in xs]
+        out["lqr_S"] = np.array(SK[0][0], dtype=np.float64)
+        out["lqr_K"] = np.array([k for _, k in SK])
+        # trajectory through the module's own planner
+        planner = mod.planner
+        planner.set_system(erf=erf)
+        planner.constraints.set_feasibility_function(feas)
+        planner.set_runtime(min_time=2, max_time=3, max_nodes=300, sys_time=lambda: 0.0)
+        planner.set_goal(goal)
+        ss = mod.gen_ss(x0, goal)
+        nearest, slen = [], []
+        steer = planner._steer
+
+        def spy(ID, xtar, force_arrive=False, _s=steer):
+            r = _s(ID, xtar, force_arrive)
+            nearest.append(int(ID)); slen.append(len(r[0]))
+            return r
+        planner._steer = spy
+        np.random.seed(PLAN_SEED)
+        ret = planner.update_plan(x0, ss, goal_bias=[0.3, 0.3, 0, 0, 0, 0], xrand_gen=10)
+        tree = planner.tree
+        out.update(returned=np.bool_(ret), iterations=np.int64(len(nearest)), pID=np.array(tree.pID, dtype=np.int32),
+                   state=np.array(tree.state), edge_len=np.array([len(e) for e in tree.x_seq], dtype=np.int32),
+                   nearest=np.array(nearest, dtype=np.int32), steer_len=np.array(slen, dtype=np.int16),
+                   K=np.array([lk[1] for lk in tree.lqr]), horizon_iters_final=np.int64(planner.horizon_iters),
+                   reached_goal=np.bool_(planner.plan_reached_goal), node_seq=np.array(planner.node_seq, dtype=np.int32),
+                   plan_x=np.array(planner.x_seq), plan_T=np.float64(planner.T), sample_space=np.array(ss, dtype=np.float64),
+                   goal=goal, goal_buffer=np.array(planner.constraints.goal_buffer), error_tol=np.array(planner.error_tol),
+                   grid=grid.astype(np.int8), origin=origin, cpm=np.float64(cpm), threshold=np.float64(90.0),
+                   pid_hash=np.array(pid_hash(tree.pID)))
+        path = os.path.join(OUT, "ros_%s.npz" % name)
+        np.savez_compressed(path, **out)
+        print("wrote %s: iters=%d nodes=%d goal=%s horizon_iters=%d edges<=%d" % (
+            path, len(nearest), tree.size, bool(planner.plan_reached_goal), planner.horizon_iters, out["edge_len"].max()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--long", action="store_true", help="also run boat_advanced to 10k nodes (~20 min)")
@@ -274,6 +368,8 @@ def main():
             gen_ops(name)
     if "ogrid" in what or "ops" in what:
         gen_ogrid()
+    if "ros" in what or "traj" in what:
+        gen_ros_behaviors()
     if "traj" in what:
         run_traj("boat_advanced", 200)
         run_traj("boat_intermediate", 300)
