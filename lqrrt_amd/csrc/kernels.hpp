@@ -139,13 +139,27 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
     constexpr int NVP = (NV + 1 + S::NW + 1) & ~1;      // + flag + one precomputed angle error per wrapped state
     __shared__ __attribute__((aligned(16))) double tile[64 * NVP];
     const int lane = threadIdx.x;
-    const int t = blockIdx.x * 64 + lane;
+    // XCD-aware tile mapping: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each
+    // with its own L2.  Re-index so that XCD k owns a contiguous band of node chunks (for every sample
+    // group): each L2 then holds 1/8 of the node table instead of all of it.  Speed only; any mapping is
+    // correct because every (group, chunk) pair is still visited exactly once.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int nb = gridDim.x * gridDim.y;
+        if ((nb & 7) == 0) {
+            const int b = blockIdx.y * gridDim.x + blockIdx.x;
+            const int v = (b & 7) * (nb >> 3) + (b >> 3);
+            bx = v % gridDim.x;
+            by = v / gridDim.x;
+        }
+    }
+    const int t = bx * 64 + lane;
     const int ts = t < W ? t : W - 1;
-    const int i0 = blockIdx.y * chunk;
+    const int i0 = by * chunk;
     int i1 = i0 + chunk;
     if (i1 > nv.count) i1 = nv.count;
     if constexpr (TRI) {
-        const int tmax = blockIdx.x * 64 + 63;
+        const int tmax = bx * 64 + 63;
         if (i1 > tmax) i1 = tmax;
     }
     double xg[S::N], gtrig[2 * S::NW + 1];
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
         }
     }
     if (t < W) {
-        const size_t o = (size_t)blockIdx.y * W + t;
+        const size_t o = (size_t)by * W + t;
         pcost[o] = best; pidx[o] = bidx;
         if (pcost_all) { pcost_all[o] = best_all; pidx_all[o] = bidx_all; }
     }
