@@ -569,7 +569,8 @@ __global__ void k_tree_root(Params P, TreeView tv, const double* __restrict__ x0
 // in-wave scan partials, the decision and the host summary.
 //   horizon L  = first sample whose CURRENT record is an accepted goal hit (or W-1): samples after
 //                L cannot be committed by this wave (the wave is cut at the first goal hit because
-//                the ignore set changes there, planner.py:270), so they are left alone;
+//                the ignore set changes there, planner.py:270), so they are left alone (only remembered as
+//                stale when their in-wave parent is recomputed, in case the hit vanishes and L grows again);
 //   want       = in-wave winner s (strictly cheaper than the snapshot parent) else snapshot parent;
 //   redo when want differs from the parent the record was computed with, when that in-wave parent
 //   was itself recomputed last round, or when a redo was deferred.  A redo whose in-wave parent is
@@ -610,7 +611,9 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ rec,
             want = (s >= 0 && wc < csnap) ? ~s : psnap;
             nd = (want != par_done[t]) || (stale[t] != 0);
             if (want < 0 && changed[~want]) nd = true;
-        }
+        } else if (want < 0 && changed[~want]) {
+            stale[t] = 1;     // beyond the horizon now, but its in-wave parent just moved: redo it if the horizon
+        }                     // grows back over it (the goal hit that cut the wave can vanish in a later round)
         par_want[t] = want;
         need[t] = nd ? 1 : 0;
     }

@@ -1,0 +1,106 @@
+#!/usr/bin/env python
+"""Randomised engine-vs-sequential-oracle comparison (bit for bit) over systems, seeds, wave sizes, sampler
+tries, pruning and horizon modes.
+
+    python tools/fuzz_parity.py [cases] [seed] [only_case]      (FUZZ_WAVE=n overrides the wave size)
+
+Found so far: a wave cut at a goal hit whose hit later vanished left samples beyond the old cut with records
+computed from an in-wave parent's previous end state (k_decide now remembers them as stale)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+
+NAMES = ["boat_advanced", "boat_intermediate", "boat_novice", "car", "double_integrator", "ros_boat"]
+
+
+def draw_case(rng):
+    """One random configuration; consumes a fixed pattern of draws so that case k is reproducible."""
+    import lqrrt_amd
+    name = NAMES[rng.randint(len(NAMES))]
+    if name == "double_integrator":
+        s = lqrrt_amd.systems.DoubleIntegrator(n_boxes=int(rng.choice([50, 2000, 20000])), seed=int(rng.randint(5)))
+    elif name == "ros_boat":
+        s = lqrrt_amd.systems.RosBoat(str(rng.choice(["boat", "car", "escape"])), focus=[12.0, -3.0] if rng.rand() < 0.3 else None)
+    else:
+        s = lqrrt_amd.systems.SYSTEMS[name](int(rng.randint(4)))
+    c = dict(name=name, system=s)
+    c["nodes"] = int(rng.choice([40, 150, 400, 900]))
+    c["wave"] = int(rng.choice([1, 2, 3, 7, 16, 64, 100, 256, 512, 1024]))
+    c["seed"] = int(rng.randint(10 ** 6))
+    c["tries"] = int(rng.choice([1, 2, 10]))
+    c["pruning"] = bool(rng.rand() < 0.7)
+    c["stop_goal"] = bool(rng.rand() < 0.2)
+    kw = s.plan_kwargs
+    c["adaptive"] = bool(hasattr(kw["horizon"], "__len__") or (rng.rand() < 0.25))
+    c["horizon"] = kw["horizon"] if hasattr(kw["horizon"], "__len__") else ((0.1, 1.5) if c["adaptive"] else kw["horizon"])
+    return c
+
+
+def run_case(c, verbose=False):
+    """Grow the same tree with the HIP engine (waves) and the sequential C oracle; True when bit-identical."""
+    import coracle
+    from lqrrt_amd.engine import Engine
+    s, nodes, wave, seed, tries = c["system"], c["nodes"], c["wave"], c["seed"], c["tries"]
+    kw = s.plan_kwargs
+    budget = 30 * nodes
+    eng = Engine(s, capacity=nodes + wave + 8, max_wave=wave)
+    if c["adaptive"]:
+        hspan = np.divide(c["horizon"], kw["dt"]).astype(np.int64)
+        eng.set_resolution(kw["dt"], kw["FPR"], int(hspan[1]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer),
+                           adaptive=True, hspan_min=int(hspan[0]), horizon_iters_state=1)
+    else:
+        eng.set_resolution(kw["dt"], kw["FPR"], int(c["horizon"] / kw["dt"]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer))
+    space = np.array(s.sample_space, dtype=np.float64)
+    eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), np.array(s.goal_bias, dtype=np.float64), tries)
+    st = np.random.RandomState(seed).get_state()
+    eng.set_mt19937(st[1], st[2])
+    eng.tree_reset(s.x0)
+    stats = eng.extend(wave, max_attempts=budget, node_limit=nodes, pruning=c["pruning"], stop_on_goal=c["stop_goal"])
+    o = coracle.make(s, nodes + wave + 8, seed=seed, tries=tries, horizon=c["horizon"])
+    o.extend(max_iters=budget, max_nodes=nodes, pruning=c["pruning"], stop_on_goal=c["stop_goal"])
+    ok = (eng.size == o.size and stats.attempts == o.iterations and stats.candidates == o.candidates
+          and np.array_equal(eng.parents(), o.parents()) and np.array_equal(eng.states(), o.states())
+          and np.array_equal(eng.edge_lengths(), o.edge_lengths()) and np.array_equal(eng.ignored(), o.ignored())
+          and eng.plan_best()[0] == o.best()[0] and (not c["adaptive"] or eng.horizon_iters_state() == o.horizon_iters))
+    if verbose:
+        n = min(eng.size, o.size)
+        pe, po, se, so = eng.parents()[:n], o.parents()[:n], eng.states()[:n], o.states()[:n]
+        d = np.nonzero((pe != po) | np.any(se != so, axis=1))[0]
+        print("sizes", eng.size, o.size, "attempts", stats.attempts, o.iterations, "first differing nodes:", d[:5])
+        if len(d):
+            i = d[0]
+            print("engine parent", pe[i], "state", se[i]); print("oracle parent", po[i], "state", so[i])
+    eng.close()
+    return ok
+
+
+def describe(c):
+    return " ".join("%s=%s" % (k, c[k]) for k in ("name", "nodes", "wave", "seed", "tries", "pruning", "stop_goal", "adaptive")) \
+        + (" behavior=%s" % c["system"].behavior if hasattr(c["system"], "behavior") else "")
+
+
+def run(cases, seed, only=-1, wave_override=None):
+    rng = np.random.RandomState(seed)
+    bad = []
+    for k in range(cases):
+        c = draw_case(rng)
+        if wave_override:
+            c["wave"] = int(wave_override)
+        if only >= 0 and k != only:
+            continue
+        if not run_case(c, verbose=only >= 0):
+            bad.append((k, describe(c)))
+    return bad
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+    t0 = time.time()
+    bad = run(cases, seed, only, os.environ.get("FUZZ_WAVE"))
+    for k, d in bad:
+        print("MISMATCH case", k, d)
+    print("cases %d mismatches %d in %.1f s" % (cases, len(bad), time.time() - t0))
+    sys.exit(1 if bad else 0)
