@@ -1,5 +1,5 @@
 /*
- * lqrrt_pmath.h -- portable, bit-reproducible sin / cos / atan2 in IEEE-754 double.
+ * lqrrt_pmath.h -- portable, bit-reproducible sin / cos / atan2 / tanh in IEEE-754 double.
  *
  * Why this exists: the reference's problem plugins call np.sin / np.cos / np.arctan2, whose last
  * bit depends on the host (glibc vs SVML/AVX-512 dispatch inside NumPy), and the boat problem's
@@ -8,12 +8,12 @@
  * "Conditioning".  To be able to prove that the wave-parallel engine reproduces the sequential
  * algorithm EXACTLY (bit-for-bit trees at any size) the device code and the C oracle both
  * evaluate elementary functions through this header, which uses only operations that IEEE-754
- * defines exactly -- + - * / fma floor fabs copysign and comparisons -- in a fixed order.  The
+ * defines exactly -- + - * / fma floor fabs copysign ldexp and comparisons -- in a fixed order.  The
  * same source therefore gives identical bits on gfx950 (hipcc -ffp-contract=off) and on x86-64
  * (gcc -ffp-contract=off; fma() is correctly rounded by the C standard, in hardware or not).
  *
  * Accuracy (measured against 60-digit mpmath, tests/test_pmath.py): sin, cos <= 1 ulp for
- * |x| <= 1e5; atan2 <= 2 ulp.  Domain: finite arguments; |x| < 1.6e6 for sin/cos (beyond that
+ * |x| <= 1e5; atan2 <= 2 ulp; tanh <= 3 ulp.  Domain: finite arguments; |x| < 1.6e6 for sin/cos (beyond that
  * the 33-bit Cody-Waite product n*P1 is no longer exact and libm is used instead).
  *
  * Method: sin/cos -- reduction x = n*(pi/2) + r by a two-level Cody-Waite split of pi/2 with an
@@ -135,6 +135,43 @@ LQ_HD double lq_atan2(double y, double x) {
     if (swap) a = LQ_PI_2_HI - (a - LQ_PI_2_LO);
     if (xneg) a = LQ_PI_HI - (a - LQ_PI_LO);
     return copysign(a, y);
+}
+
+/* ln 2 = LN2_HI + LN2_LO, LN2_HI with 32 significant bits so that k*LN2_HI is exact for |k| < 2^20 */
+#define LQ_LN2_HI    0x1.62e42fee00000p-1
+#define LQ_LN2_LO    0x1.a39ef35793c76p-33
+#define LQ_LOG2E     0x1.71547652b82fep+0
+
+/* hyperbolic tangent.  With y = -2|x| = k ln2 + r (|r| <= ln2/2), p = expm1(r) from its Taylor series
+ * (truncation < 3e-19 relative) and s = 2^k:  tanh|x| = (1 - s(1+p)) / (1 + s(1+p)), where both
+ * (1 -+ s) -+ s p are formed with ONE rounding each (1 -+ s is exact), so there is no cancellation
+ * for small |x| (k = 0: -p / (2 + p)).  <= 3 ulp (tests/test_pmath.py). */
+LQ_HD double lq_tanh(double x) {
+    const double ax = fabs(x);
+    if (!(ax < 22.0)) return x != x ? x : copysign(1.0, x);     /* 1 - tanh 22 < 2^-62 */
+    const double y = -2.0 * ax;
+    const double k = floor(fma(y, LQ_LOG2E, 0.5));
+    double r = fma(-k, LQ_LN2_HI, y);
+    r = fma(-k, LQ_LN2_LO, r);
+    double q = 0x1.ae7f3e733b81fp-41;                          /* 1/15! */
+    q = fma(q, r, 0x1.93974a8c07c9dp-37);                      /* 1/14! */
+    q = fma(q, r, 0x1.6124613a86d09p-33);                      /* 1/13! */
+    q = fma(q, r, 0x1.1eed8eff8d898p-29);                      /* 1/12! */
+    q = fma(q, r, 0x1.ae64567f544e4p-26);                      /* 1/11! */
+    q = fma(q, r, 0x1.27e4fb7789f5cp-22);                      /* 1/10! */
+    q = fma(q, r, 0x1.71de3a556c734p-19);                      /* 1/9! */
+    q = fma(q, r, 0x1.a01a01a01a01ap-16);                      /* 1/8! */
+    q = fma(q, r, 0x1.a01a01a01a01ap-13);                      /* 1/7! */
+    q = fma(q, r, 0x1.6c16c16c16c17p-10);                      /* 1/6! */
+    q = fma(q, r, 0x1.1111111111111p-7);                      /* 1/5! */
+    q = fma(q, r, 0x1.5555555555555p-5);                      /* 1/4! */
+    q = fma(q, r, 0x1.5555555555555p-3);                      /* 1/3! */
+    q = fma(q, r, 0x1.0000000000000p-1);                      /* 1/2! */
+    const double p = fma(r * r, q, r);                           /* expm1(r) */
+    const double s = ldexp(1.0, (int)k);
+    const double num = fma(-s, p, 1.0 - s);
+    const double den = fma(s, p, 1.0 + s);
+    return copysign(num / den, x);
 }
 
 #endif /* LQRRT_PMATH_H */

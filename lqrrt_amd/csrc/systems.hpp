@@ -430,7 +430,7 @@ struct Pendulum {
         const double G0 = P[4] * c0 + P[5] * c01;
         const double G1 = P[5] * c01;
         const double D0 = P[6] * q[2], D1 = P[7] * q[3];
-        const double F0 = P[8] * tanh(P[10] * q[2]), F1 = P[9] * tanh(P[11] * q[3]);
+        const double F0 = P[8] * lq_tanh(P[10] * q[2]), F1 = P[9] * lq_tanh(P[11] * q[3]);
         const double tau = clipd(u[0], -P[12], P[12]);
         const double r0 = (((tau - V0) - G0) - D0) - F0;
         const double r1 = (((0.0 - V1) - G1) - D1) - F1;

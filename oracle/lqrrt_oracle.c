@@ -278,7 +278,7 @@ static void step(const orc* o, const double* x, const double* tr, double* u, dou
             const double V1 = (P[3] * (x[2] * x[2])) * s1;
             const double G0 = P[4] * c0 + P[5] * c01, G1 = P[5] * c01;
             const double D0 = P[6] * x[2], D1 = P[7] * x[3];
-            const double F0 = P[8] * tanh(P[10] * x[2]), F1 = P[9] * tanh(P[11] * x[3]);
+            const double F0 = P[8] * lq_tanh(P[10] * x[2]), F1 = P[9] * lq_tanh(P[11] * x[3]);
             const double tau = clipd(u[0], -P[12], P[12]);
             const double r0 = (((tau - V0) - G0) - D0) - F0, r1 = (((0.0 - V1) - G1) - D1) - F1;
             const double det = M00 * M11 - M01 * M01;

@@ -14,6 +14,7 @@ SRC = """
 #include "lqrrt_pmath.h"
 void v_sincos(const double* x, int n, double* s, double* c){ for(int i=0;i<n;i++) lq_sincos(x[i], &s[i], &c[i]); }
 void v_atan2(const double* y, const double* x, int n, double* a){ for(int i=0;i<n;i++) a[i]=lq_atan2(y[i],x[i]); }
+void v_tanh(const double* x, int n, double* t){ for(int i=0;i<n;i++) t[i]=lq_tanh(x[i]); }
 """
 
 
@@ -67,3 +68,23 @@ def test_atan2_accuracy_and_zeros(pm):
     want = np.array([math.atan2(y, x) for y, x in zip(sy, sx)])
     np.testing.assert_array_equal(sa, want)
     np.testing.assert_array_equal(np.signbit(sa), np.signbit(want))
+
+
+def test_tanh_accuracy_and_limits(pm):
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 50
+    rng = np.random.RandomState(2)
+    xs = np.concatenate([rng.uniform(-1, 1, 2000), rng.uniform(-25, 25, 1500), 10.0 ** rng.uniform(-300, -1, 300),
+                         -10.0 ** rng.uniform(-12, -1, 300), [0.17328679513998632, -0.17328679513998635, 0.34657359027997264, 21.999, 19.0]])
+    t = np.zeros_like(xs)
+    P = C.c_void_p
+    pm.v_tanh(xs.ctypes.data_as(P), len(xs), t.ctypes.data_as(P))
+    assert max(_ulps(a, mp.tanh(mp.mpf(float(x)))) for a, x in zip(t, xs)) <= 3.0
+    sx = np.array([0.0, -0.0, 22.0, -22.0, 1e300, -1e300, np.inf, -np.inf, 5e-324])
+    st = np.zeros_like(sx)
+    pm.v_tanh(sx.ctypes.data_as(P), len(sx), st.ctypes.data_as(P))
+    np.testing.assert_array_equal(st, np.tanh(sx))
+    np.testing.assert_array_equal(np.signbit(st), np.signbit(sx))
+    nan = np.array([np.nan]); out = np.zeros(1)
+    pm.v_tanh(nan.ctypes.data_as(P), 1, out.ctypes.data_as(P))
+    assert np.isnan(out[0])

@@ -11,13 +11,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 
-NAMES = ["boat_advanced", "boat_intermediate", "boat_novice", "car", "double_integrator", "ros_boat"]
+NAMES = ["boat_advanced", "boat_intermediate", "boat_novice", "car", "double_integrator", "ros_boat", "pendulum"]
 
 
-def draw_case(rng):
-    """One random configuration; consumes a fixed pattern of draws so that case k is reproducible."""
+def draw_case(rng, rng2, names=None):
+    """One random configuration; consumes a fixed pattern of draws so that case k is reproducible (rng2 is a second
+    stream for dimensions added later, so that earlier case numbers keep their meaning)."""
     import lqrrt_amd
-    name = NAMES[rng.randint(len(NAMES))]
+    names = names or NAMES
+    name = names[rng.randint(len(names))]
     if name == "double_integrator":
         s = lqrrt_amd.systems.DoubleIntegrator(n_boxes=int(rng.choice([50, 2000, 20000])), seed=int(rng.randint(5)))
     elif name == "ros_boat":
@@ -34,6 +36,9 @@ def draw_case(rng):
     kw = s.plan_kwargs
     c["adaptive"] = bool(hasattr(kw["horizon"], "__len__") or (rng.rand() < 0.25))
     c["horizon"] = kw["horizon"] if hasattr(kw["horizon"], "__len__") else ((0.1, 1.5) if c["adaptive"] else kw["horizon"])
+    c["world"] = int(rng2.choice([1, 1, 1, 2, 3, 8]))      # >1: sample-sharded waves, ranks emulated on one GPU
+    if c["world"] > 1:
+        c["stop_goal"] = False
     return c
 
 
@@ -44,19 +49,48 @@ def run_case(c, verbose=False):
     s, nodes, wave, seed, tries = c["system"], c["nodes"], c["wave"], c["seed"], c["tries"]
     kw = s.plan_kwargs
     budget = 30 * nodes
-    eng = Engine(s, capacity=nodes + wave + 8, max_wave=wave)
-    if c["adaptive"]:
-        hspan = np.divide(c["horizon"], kw["dt"]).astype(np.int64)
-        eng.set_resolution(kw["dt"], kw["FPR"], int(hspan[1]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer),
-                           adaptive=True, hspan_min=int(hspan[0]), horizon_iters_state=1)
+    def make_engine():
+        eng = Engine(s, capacity=nodes + wave + 8, max_wave=wave)
+        if c["adaptive"]:
+            hspan = np.divide(c["horizon"], kw["dt"]).astype(np.int64)
+            eng.set_resolution(kw["dt"], kw["FPR"], int(hspan[1]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer),
+                               adaptive=True, hspan_min=int(hspan[0]), horizon_iters_state=1)
+        else:
+            eng.set_resolution(kw["dt"], kw["FPR"], int(c["horizon"] / kw["dt"]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer))
+        space = np.array(s.sample_space, dtype=np.float64)
+        eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), np.array(s.goal_bias, dtype=np.float64), tries)
+        st = np.random.RandomState(seed).get_state()
+        eng.set_mt19937(st[1], st[2])
+        eng.tree_reset(s.x0)
+        return eng
+
+    world = c.get("world", 1)
+    others = []
+    if world == 1:
+        eng = make_engine()
+        stats = eng.extend(wave, max_attempts=budget, node_limit=nodes, pruning=c["pruning"], stop_on_goal=c["stop_goal"])
     else:
-        eng.set_resolution(kw["dt"], kw["FPR"], int(c["horizon"] / kw["dt"]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer))
-    space = np.array(s.sample_space, dtype=np.float64)
-    eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), np.array(s.goal_bias, dtype=np.float64), tries)
-    st = np.random.RandomState(seed).get_state()
-    eng.set_mt19937(st[1], st[2])
-    eng.tree_reset(s.x0)
-    stats = eng.extend(wave, max_attempts=budget, node_limit=nodes, pruning=c["pruning"], stop_on_goal=c["stop_goal"])
+        import torch
+        from lqrrt_amd.parallel import records_tensor, shard_bounds
+        ranks = [make_engine() for _ in range(world)]
+        recs = [records_tensor(e) for e in ranks]
+        attempts = 0
+        while ranks[0].size <= nodes and attempts < budget:
+            W = ranks[0].wave_suggest(wave)
+            bounds = [shard_bounds(W, r, world) for r in range(world)]
+            for r, e in enumerate(ranks):
+                e.wave_speculate(W, bounds[r][1], bounds[r][2])
+            torch.cuda.synchronize()
+            for r in range(world):
+                lo, hi = bounds[r][1], bounds[r][2]
+                for q in range(world):
+                    if q != r and hi > lo:
+                        recs[q][lo:hi].copy_(recs[r][lo:hi])
+            torch.cuda.synchronize()
+            sts = [e.wave_commit(W, budget - attempts, nodes, c["pruning"]) for e in ranks]
+            attempts += sts[0].attempts
+        eng, others = ranks[0], ranks[1:]
+        stats = eng.counters()
     o = coracle.make(s, nodes + wave + 8, seed=seed, tries=tries, horizon=c["horizon"])
     o.extend(max_iters=budget, max_nodes=nodes, pruning=c["pruning"], stop_on_goal=c["stop_goal"])
     ok = (eng.size == o.size and stats.attempts == o.iterations and stats.candidates == o.candidates
@@ -71,20 +105,35 @@ def run_case(c, verbose=False):
         if len(d):
             i = d[0]
             print("engine parent", pe[i], "state", se[i]); print("oracle parent", po[i], "state", so[i])
+            print("state diff", se[i] - so[i], "edge len", eng.edge_lengths()[i], o.edge_lengths()[i])
+            xe, ue = eng.edge(int(i)); xo, uo = o.edge(int(i))
+            m = min(len(xe), len(xo))
+            bad_steps = np.nonzero(np.any(xe[:m] != xo[:m], axis=1) | np.any(ue[:m] != uo[:m], axis=1))[0]
+            print("first differing edge step", bad_steps[:3], "of", m)
+            if len(bad_steps):
+                j = bad_steps[0]
+                print(" x eng", [float.hex(float(v)) for v in xe[j]]); print(" x orc", [float.hex(float(v)) for v in xo[j]])
+                print(" u eng", [float.hex(float(v)) for v in ue[j]]); print(" u orc", [float.hex(float(v)) for v in uo[j]])
+                if j > 0:
+                    print(" prev x", [float.hex(float(v)) for v in xe[j - 1]], "same", np.array_equal(xe[j - 1], xo[j - 1]))
+                print(" parent state", [float.hex(float(v)) for v in se[pe[i]]], "K equal", np.array_equal(eng.gains()[pe[i]], o.gains()[pe[i]]))
+    for e in others:
+        ok = ok and e.size == eng.size and np.array_equal(e.parents(), eng.parents()) and np.array_equal(e.states(), eng.states())
+        e.close()
     eng.close()
     return ok
 
 
 def describe(c):
-    return " ".join("%s=%s" % (k, c[k]) for k in ("name", "nodes", "wave", "seed", "tries", "pruning", "stop_goal", "adaptive")) \
+    return " ".join("%s=%s" % (k, c[k]) for k in ("name", "nodes", "wave", "seed", "tries", "pruning", "stop_goal", "adaptive", "world")) \
         + (" behavior=%s" % c["system"].behavior if hasattr(c["system"], "behavior") else "")
 
 
-def run(cases, seed, only=-1, wave_override=None):
-    rng = np.random.RandomState(seed)
+def run(cases, seed, only=-1, wave_override=None, names=None):
+    rng, rng2 = np.random.RandomState(seed), np.random.RandomState(seed + 7919)
     bad = []
     for k in range(cases):
-        c = draw_case(rng)
+        c = draw_case(rng, rng2, names)
         if wave_override:
             c["wave"] = int(wave_override)
         if only >= 0 and k != only:
