@@ -39,6 +39,24 @@ def draw_case(rng, rng2, names=None):
     c["world"] = int(rng2.choice([1, 1, 1, 2, 3, 8]))      # >1: sample-sharded waves, ranks emulated on one GPU
     if c["world"] > 1:
         c["stop_goal"] = False
+    c["ogrid"] = False
+    if name in ("boat_advanced", "boat_intermediate", "ros_boat") and rng2.rand() < 0.35:
+        # a synthetic occupancy map over the sample space (lqrrt_node.py:792-860 feasibility model)
+        space = np.array(s.sample_space, dtype=np.float64)
+        cpm = float(rng2.choice([1.0, 2.5, 5.0]))
+        origin = (space[0, 0] - 8.0, space[1, 0] - 8.0)
+        cols = int((space[0, 1] - space[0, 0] + 16.0) * cpm)
+        rows = int((space[1, 1] - space[1, 0] + 16.0) * cpm)
+        grid = rng2.randint(0, 60, size=(rows, cols)).astype(np.int8)
+        for _ in range(int(rng2.randint(3, 25))):
+            r0, c0 = int(rng2.randint(rows)), int(rng2.randint(cols))
+            grid[r0:r0 + int(rng2.randint(1, 6 * cpm + 2)), c0:c0 + int(rng2.randint(1, 6 * cpm + 2))] = int(rng2.randint(80, 101))
+        for px, py in ((s.x0[0], s.x0[1]), (s.goal[0], s.goal[1])):
+            cc, rr = int(cpm * (px - origin[0])), int(cpm * (py - origin[1]))
+            k = int(7 * cpm)
+            grid[max(rr - k, 0):rr + k, max(cc - k, 0):cc + k] = 0
+        s.set_occupancy_grid(grid, origin, cpm=cpm, threshold=float(rng2.choice([50.0, 90.0])))
+        c["ogrid"] = True
     return c
 
 
@@ -125,7 +143,7 @@ def run_case(c, verbose=False):
 
 
 def describe(c):
-    return " ".join("%s=%s" % (k, c[k]) for k in ("name", "nodes", "wave", "seed", "tries", "pruning", "stop_goal", "adaptive", "world")) \
+    return " ".join("%s=%s" % (k, c[k]) for k in ("name", "nodes", "wave", "seed", "tries", "pruning", "stop_goal", "adaptive", "world", "ogrid")) \
         + (" behavior=%s" % c["system"].behavior if hasattr(c["system"], "behavior") else "")
 
 
