@@ -172,7 +172,8 @@ struct lqrrt_engine {
     lqrrt_extend_stats tot{};
 
     // profiling
-    bool prof = false;
+    int prof = 0;                       // 0 off, 1 NN scan only, 2 NN scan + steer
+    std::vector<hipEvent_t> ev_free;    // recycled events (creating one per launch costs more than the record)
     std::vector<EvPair> evs;
     double nn_ms = 0, nn_bytes = 0, steer_ms = 0;
     int64_t nn_launches = 0, steer_launches = 0;
@@ -262,17 +263,11 @@ static NodeView record_view(const lqrrt_engine* e, int W) {
 // --------------------------------------------------------------------------------------------
 // profiling helpers
 
-static void prof_begin(lqrrt_engine* e, hipStream_t st, EvPair* ev) {
-    if (!e->prof) return;
-    (void)hipEventCreate(&ev->a);
-    (void)hipEventCreate(&ev->b);
-    (void)hipEventRecord(ev->a, st);
-}
-static void prof_end(lqrrt_engine* e, hipStream_t st, EvPair* ev, int kind, double bytes) {
-    if (!e->prof) return;
-    (void)hipEventRecord(ev->b, st);
-    ev->kind = kind; ev->bytes = bytes;
-    e->evs.push_back(*ev);
+static hipEvent_t prof_event(lqrrt_engine* e) {
+    hipEvent_t ev = nullptr;
+    if (!e->ev_free.empty()) { ev = e->ev_free.back(); e->ev_free.pop_back(); }
+    else (void)hipEventCreate(&ev);
+    return ev;
 }
 static void prof_flush(lqrrt_engine* e) {
     for (auto& ev : e->evs) {
@@ -281,10 +276,24 @@ static void prof_flush(lqrrt_engine* e) {
         (void)hipEventElapsedTime(&ms, ev.a, ev.b);
         if (ev.kind == 0) { e->nn_ms += ms; e->nn_bytes += ev.bytes; e->nn_launches++; }
         else { e->steer_ms += ms; e->steer_launches++; }
-        (void)hipEventDestroy(ev.a);
-        (void)hipEventDestroy(ev.b);
+        e->ev_free.push_back(ev.a);
+        e->ev_free.push_back(ev.b);
     }
     e->evs.clear();
+}
+static void prof_begin(lqrrt_engine* e, hipStream_t st, EvPair* ev, int kind) {
+    ev->a = nullptr;
+    if (e->prof < 1 + kind) return;
+    if (e->evs.size() >= 2048) prof_flush(e);      // bounded pool; these events completed long ago
+    ev->a = prof_event(e);
+    ev->b = prof_event(e);
+    (void)hipEventRecord(ev->a, st);
+}
+static void prof_end(lqrrt_engine* e, hipStream_t st, EvPair* ev, int kind, double bytes) {
+    if (!ev->a) return;
+    (void)hipEventRecord(ev->b, st);
+    ev->kind = kind; ev->bytes = bytes;
+    e->evs.push_back(*ev);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -320,7 +329,8 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     double* pca = want_all ? e->d_pcost_all : nullptr;
     int* pia = want_all ? e->d_pidx_all : nullptr;
     EvPair ev;
-    if (profile) prof_begin(e, st, &ev);
+    ev.a = nullptr;
+    if (profile) prof_begin(e, st, &ev, 0);
 #define NN_LAUNCH(DENSE, TRI)                                                                            \
     DISPATCH(e, hipLaunchKernelGGL((k_nn_scan<S, DENSE, TRI>), grid, dim3(64), 0, st, nv, xs, W, S_use, chunk, \
                                    e->d_pcost, e->d_pidx, pca, pia))
@@ -345,7 +355,7 @@ static int launch_steer(lqrrt_engine* e, const double* xs, const int* list, int 
     if (count <= 0) return 0;
     const size_t lds = (size_t)e->H * (e->n + e->m) * sizeof(double) + geo_lds_bytes(e);
     EvPair ev;
-    prof_begin(e, st, &ev);
+    prof_begin(e, st, &ev, 1);
     DISPATCH(e, hipLaunchKernelGGL((k_steer<S>), dim3(count), dim3(64), lds, st, e->P, e->geo, e->res, e->tv,
                                     e->d_rec, e->L, xs, list, lo, par, list_count));
     prof_end(e, st, &ev, 1, 0.0);
@@ -554,6 +564,8 @@ extern "C" int lqrrt_engine_destroy(lqrrt_engine* e) {
     if (!e) return 0;
     (void)hipSetDevice(e->device);
     prof_flush(e);
+    for (hipEvent_t ev : e->ev_free) (void)hipEventDestroy(ev);
+    e->ev_free.clear();
     free_all(e);
     delete e;
     return 0;
@@ -1293,7 +1305,7 @@ extern "C" int lqrrt_engine_counters(lqrrt_engine* e, lqrrt_extend_stats* out) {
 extern "C" int lqrrt_profile_enable(lqrrt_engine* e, int on) {
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     prof_flush(e);
-    e->prof = on != 0;
+    e->prof = on < 0 ? 0 : (on > 2 ? 2 : on);
     e->nn_ms = e->nn_bytes = e->steer_ms = 0;
     e->nn_launches = e->steer_launches = 0;
     return 0;
