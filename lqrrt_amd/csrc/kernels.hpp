@@ -20,6 +20,7 @@
 //     redundantly by all lanes (wave-uniform, no divergence) and the lanes split the
 //     hull x obstacle collision sweep; the edge under construction lives in LDS.
 #pragma once
+#include <type_traits>
 #include "systems.hpp"
 
 namespace lq {
@@ -372,6 +373,15 @@ __global__ void k_erf_batch(const double* __restrict__ xg, const double* __restr
 // par[t] >= 0: start at tree node par[t]; par[t] < 0: start at the end node of in-wave sample ~par[t]
 // (read from its record).  Results go to record t: len, flags (bit0 = in goal), xend, trig, K,
 // xseq[len][n], useq[len][m].  Dynamic LDS: H*(n+m) doubles.
+// Systems that provide step_packed() declare `static constexpr bool PACKED = true`.
+template <class S, class = void> struct is_packed : std::false_type {};
+template <class S> struct is_packed<S, std::enable_if_t<S::PACKED>> : std::true_type {};
+
+// A condition the wavefront agrees on by construction (every lane holds the same rollout state) but which the
+// compiler must treat as divergent once values have passed through DPP lane moves: read it from one lane so the
+// branch stays a scalar branch.
+__device__ __forceinline__ bool uniform_true(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
+
 template <class S>
 __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView tv, double* __restrict__ rec,
                                               RecLayout L, const double* __restrict__ xs,
@@ -425,17 +435,22 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
     for (int d = 0; d < S::N; ++d) last[d] = INFINITY;           // planner.py:377
     while (true) {
         double e[S::N], u[S::M], uc[S::M], xn[S::N], trn[2 * S::NW + 1];
-        erf_cached<S>(xt, ttrig, x, trig, e);                    // planner.py:386
+        if constexpr (is_packed<S>::value) {
+            // same arithmetic, elementary functions packed across lanes (systems.hpp packed_heading)
+            S::step_packed(Pl, xt, ttrig, x, trig, K, r.dt, lane, e, u, xn, trn);
+        } else {
+            erf_cached<S>(xt, ttrig, x, trig, e);                // planner.py:386
 #pragma unroll
-        for (int i = 0; i < S::M; ++i) {                         // u = K.dot(e), planner.py:387
-            double a = K[i * S::N] * e[0];
+            for (int i = 0; i < S::M; ++i) {                     // u = K.dot(e), planner.py:387
+                double a = K[i * S::N] * e[0];
 #pragma unroll
-            for (int j = 1; j < S::N; ++j) a += K[i * S::N + j] * e[j];
-            u[i] = a; uc[i] = a;
+                for (int j = 1; j < S::N; ++j) a += K[i * S::N + j] * e[j];
+                u[i] = a; uc[i] = a;
+            }
+            S::step(Pl, x, trig, uc, r.dt, xn);                 // planner.py:390 (dynamics gets copies)
+            trig_of<S>(xn, trn);
         }
-        S::step(Pl, x, trig, uc, r.dt, xn);                     // planner.py:390 (dynamics gets copies)
-        trig_of<S>(xn, trn);
-        if (!S::feasible(Pl, g, gl, xn, u, trn, lane)) {        // planner.py:393-396
+        if (!uniform_true(S::feasible(Pl, g, gl, xn, u, trn, lane))) {   // planner.py:393-396
             cnt = (int)(r.FPR * (double)cnt);
             break;
         }
@@ -444,14 +459,14 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
             bool all_grew = true;
 #pragma unroll
             for (int d = 0; d < S::N; ++d) all_grew = all_grew && (fabs(e[d]) >= last[d]);
-            if (all_grew) { cnt = 0; grew = true; break; }       // discard the whole edge
+            if (uniform_true(all_grew)) { cnt = 0; grew = true; break; }   // discard the whole edge
 #pragma unroll
             for (int d = 0; d < S::N; ++d) last[d] = fabs(e[d]);
         }
         bool conv = true;
 #pragma unroll
         for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= tol_l[d]);
-        if (steps > r.H || conv) break;                          // planner.py:428
+        if (steps > r.H || uniform_true(conv)) break;            // planner.py:428
         // record (planner.py:432-433): lane d keeps component d
         if (lane == 0) {                                         // wave-uniform values: one lane writes the LDS history
 #pragma unroll

@@ -78,6 +78,15 @@ __device__ __forceinline__ double clipd(double v, double lo, double hi) {
     return t > hi ? hi : t;
 }
 
+// Value held by lane Q (0..3) of the caller's quad, for every lane: two DPP moves, no LDS, no SGPRs.
+template <int Q>
+__device__ __forceinline__ double quad_bcast(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, Q * 0x55, 0xf, 0xf, true);      // quad_perm:[Q,Q,Q,Q]
+    hi = __builtin_amdgcn_mov_dpp(hi, Q * 0x55, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 // The demos' angle error: atan2(sg*c - cg*s, cg*c + sg*s)  (e.g. demo_boat_advanced.py:159-164)
 __device__ __forceinline__ double wrap_err(double cg, double sg, double c, double s) {
     return lq_atan2(sg * c - cg * s, cg * c + sg * s);
@@ -195,6 +204,52 @@ struct BoatCommon {
         return gainv * wrap_err(cg, sg, c, s);
     }
 
+    // One rollout step evaluates five elementary functions on the critical path: the heading error of erf
+    // (atan2), the rudder's velocity direction (atan2), its sine/cosine, the rudder's heading error (atan2) and
+    // the sine/cosine of the next heading.  All 64 lanes of the problem's wavefront run the same instruction
+    // stream anyway, so independent evaluations are packed into different lanes: even lanes take the erf
+    // atan2 while odd lanes take the velocity direction; then even lanes take sincos(direction) while odd
+    // lanes take sincos(next heading), which only needs the OLD state (h' = h + vh dt).  Each lane performs
+    // exactly the arithmetic of the sequential code on its own arguments, so every bit is unchanged; the
+    // results are handed round inside each quad with DPP moves.  3 atan2 + 2 sincos become 2 + 1.
+    //   out: e2 = erf heading component, rud = gain * heading error of the direction, trn = trig(h')
+    //   (yb, xb) = arguments of the direction atan2: the world-frame velocity (rudder_term) or, for the ROS
+    //   "stare at a point" behaviour, the vector to the focus point.
+    __device__ static void packed_heading(double gainv, const double* ttrig, const double* x, const double* trig,
+                                          double dt, int lane, double yb, double xb, double& e2, double& rud, double* trn) {
+        const bool odd = (lane & 1) != 0;
+        const double c = trig[0], s = trig[1];
+        const double ya = ttrig[1] * c - ttrig[0] * s, xa = ttrig[0] * c + ttrig[1] * s;     // wrap_err(target, x)
+        const double a = lq_atan2(odd ? yb : ya, odd ? xb : xa);
+        e2 = quad_bcast<0>(a);
+        const double ang = quad_bcast<1>(a);
+        const double hn = x[2] + x[5] * dt;                      // euler(): xn[2] = x[2] + xdot[2]*dt, xdot[2] = x[5]
+        double sn, cs;
+        lq_sincos(odd ? hn : ang, &sn, &cs);
+        const double sg = quad_bcast<0>(sn), cg = quad_bcast<0>(cs);
+        trn[1] = quad_bcast<1>(sn);
+        trn[0] = quad_bcast<1>(cs);
+        rud = gainv * wrap_err(cg, sg, c, s);
+    }
+
+    // erf and u = K e around packed_heading (planner.py:386-387 in the order of the sequential code)
+    __device__ static void packed_erf_effort(double gainv, const double* xt, const double* ttrig, const double* x,
+                                             const double* trig, const double* K, double dt, int lane, double yb, double xb,
+                                             double* e, double* u, double& rud, double* trn) {
+        double e2;
+        packed_heading(gainv, ttrig, x, trig, dt, lane, yb, xb, e2, rud, trn);
+#pragma unroll
+        for (int d = 0; d < 6; ++d) e[d] = xt[d] - x[d];
+        e[2] = e2;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double a = K[i * 6] * e[0];
+#pragma unroll
+            for (int j = 1; j < 6; ++j) a += K[i * 6 + j] * e[j];
+            u[i] = a;
+        }
+    }
+
     // xdot = [R v ; invM*(u - D*v)], xnext = x + xdot*dt  (demo_boat_advanced.py:114-117)
     __device__ static void euler(const double* invM, const double* Dpos, const double* Dneg,
                                  const double* x, double c, double s, const double* u, double dt, double* xn) {
@@ -227,9 +282,25 @@ struct BoatAdvanced : BoatCommon {
     __device__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
         gain_pd(P + 40, P + 43, trig, K);
     }
+    static constexpr bool PACKED = true;
     __device__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+        u[2] = u[2] + rudder_term(P[37], x, trig[0], trig[1]);
+        thrust_and_integrate(P, x, trig, u, dt, xn);
+    }
+    // erf + u = K e + step + trig of the new state with the elementary functions packed across lanes
+    __device__ static void step_packed(const double* P, const double* xt, const double* ttrig, const double* x,
+                                       const double* trig, const double* K, double dt, int lane,
+                                       double* e, double* u, double* xn, double* trn) {
         const double c = trig[0], s = trig[1];
-        u[2] = u[2] + rudder_term(P[37], x, c, s);
+        const double vw0 = c * x[3] + (-s) * x[4];
+        const double vw1 = s * x[3] + c * x[4];
+        double rud;
+        packed_erf_effort(P[37], xt, ttrig, x, trig, K, dt, lane, vw1, vw0, e, u, rud, trn);
+        double uc[3] = {u[0], u[1], u[2] + rud};
+        thrust_and_integrate(P, x, trig, uc, dt, xn);
+    }
+    __device__ static void thrust_and_integrate(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+        const double c = trig[0], s = trig[1];
         // u = B.dot(clip(invB.dot(u), -thrust_max, thrust_max))   (demo_boat_advanced.py:111)
         double t[4];
 #pragma unroll
@@ -267,13 +338,27 @@ struct BoatIntermediate : BoatCommon {
     __device__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
         gain_pd(P + 15, P + 18, trig, K);
     }
+    static constexpr bool PACKED = true;
     __device__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+        u[2] = u[2] + rudder_term(P[12], x, trig[0], trig[1]);
+        saturate_and_integrate(P, x, trig, u, dt, xn);
+    }
+    __device__ static void step_packed(const double* P, const double* xt, const double* ttrig, const double* x,
+                                       const double* trig, const double* K, double dt, int lane,
+                                       double* e, double* u, double* xn, double* trn) {
         const double c = trig[0], s = trig[1];
-        u[2] = u[2] + rudder_term(P[12], x, c, s);
+        const double vw0 = c * x[3] + (-s) * x[4];
+        const double vw1 = s * x[3] + c * x[4];
+        double rud;
+        packed_erf_effort(P[12], xt, ttrig, x, trig, K, dt, lane, vw1, vw0, e, u, rud, trn);
+        double uc[3] = {u[0], u[1], u[2] + rud};
+        saturate_and_integrate(P, x, trig, uc, dt, xn);
+    }
+    __device__ static void saturate_and_integrate(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)          // per-axis saturation (demo_boat_intermediate.py:74-77)
             if (fabs(u[i]) > P[9 + i]) u[i] = P[9 + i] * (u[i] > 0.0 ? 1.0 : -1.0);
-        euler(P + 0, P + 3, P + 6, x, c, s, u, dt, xn);
+        euler(P + 0, P + 3, P + 6, x, trig[0], trig[1], u, dt, xn);
         carlike(x, P[13], P[14], xn);
     }
     __device__ static bool feasible(const double*, const Geo& g, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
@@ -315,6 +400,7 @@ struct RosBoat : BoatCommon {
     __device__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
         gain_pd(P + 43, P + 46, trig, K);
     }
+    static constexpr bool PACKED = true;
     __device__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
         const double c = trig[0], s = trig[1];
         const int rmode = (int)P[38];
@@ -326,6 +412,39 @@ struct RosBoat : BoatCommon {
         } else if (rmode == 2) {     // car.py:43
             u[2] = rudder_term(P[37], x, c, s);
         }
+        thrust_and_integrate(P, x, trig, u, dt, xn);
+    }
+    __device__ static void step_packed(const double* P, const double* xt, const double* ttrig, const double* x,
+                                       const double* trig, const double* K, double dt, int lane,
+                                       double* e, double* u, double* xn, double* trn) {
+        const int rmode = (int)P[38];
+        if (rmode == 0) {            // no heading term: nothing to pack, sequential order
+#pragma unroll
+            for (int d = 0; d < 6; ++d) e[d] = xt[d] - x[d];
+            e[2] = wrap_err(ttrig[0], ttrig[1], trig[0], trig[1]);
+            double uc[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double a = K[i * 6] * e[0];
+#pragma unroll
+                for (int j = 1; j < 6; ++j) a += K[i * 6 + j] * e[j];
+                u[i] = a; uc[i] = a;
+            }
+            thrust_and_integrate(P, x, trig, uc, dt, xn);
+            lq_sincos(xn[2], &trn[1], &trn[0]);
+            return;
+        }
+        const double c = trig[0], s = trig[1];
+        double yb, xb;
+        if (rmode == 1) { yb = P[40] - x[1]; xb = P[39] - x[0]; }
+        else { xb = c * x[3] + (-s) * x[4]; yb = s * x[3] + c * x[4]; }
+        double rud;
+        packed_erf_effort(P[37], xt, ttrig, x, trig, K, dt, lane, yb, xb, e, u, rud, trn);
+        double uc[3] = {u[0], u[1], rud};           // both behaviours REPLACE the yaw effort (boat.py:42, car.py:43)
+        thrust_and_integrate(P, x, trig, uc, dt, xn);
+    }
+    __device__ static void thrust_and_integrate(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+        const double c = trig[0], s = trig[1];
         double t[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
