@@ -131,8 +131,8 @@ struct lqrrt_engine {
     // wave buffers
     RecLayout L{};
     double* d_rec = nullptr;
-    double *d_pcost = nullptr, *d_pcost_all = nullptr;
-    int *d_pidx = nullptr, *d_pidx_all = nullptr;
+    double* d_pcost = nullptr;
+    int* d_pidx = nullptr;
     int *d_par_done = nullptr, *d_par_want = nullptr, *d_list = nullptr;
     unsigned char *d_changed = nullptr, *d_stale = nullptr, *d_need = nullptr;
     int* d_summary = nullptr;     // [4]: device-side copy of the listed count (index 0)
@@ -317,7 +317,7 @@ static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
 
 // NN over a node table for W samples at xs (device, [W][n]); writes id/cost and/or records.
 static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int W, const double* Sd,
-                     bool tri, bool want_all, int* out_id, double* out_cost, double* rec, hipStream_t st,
+                     bool tri, int* out_id, double* out_cost, double* rec, hipStream_t st,
                      bool profile, int* n_chunks_out = nullptr, int wave_lo = -1) {
     if (W <= 0) return 0;
     int chunk, n_chunks;
@@ -326,14 +326,13 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     if (n_chunks_out) *n_chunks_out = n_chunks;
     dim3 grid((W + 63) / 64, n_chunks);
     const double* S_use = Sd ? Sd : e->d_S;
-    double* pca = want_all ? e->d_pcost_all : nullptr;
-    int* pia = want_all ? e->d_pidx_all : nullptr;
+    const int ps_c = tri ? W : 1, ps_t = tri ? 1 : n_chunks;     // chunk-major for k_decide, sample-major for k_nn_reduce
     EvPair ev;
     ev.a = nullptr;
     if (profile) prof_begin(e, st, &ev, 0);
 #define NN_LAUNCH(DENSE, TRI)                                                                            \
     DISPATCH(e, hipLaunchKernelGGL((k_nn_scan<S, DENSE, TRI>), grid, dim3(64), 0, st, nv, xs, W, S_use, chunk, \
-                                   e->d_pcost, e->d_pidx, pca, pia))
+                                   e->d_pcost, e->d_pidx, ps_c, ps_t))
     if (S_use) {
         if (tri) { NN_LAUNCH(true, true); } else { NN_LAUNCH(true, false); }
     } else {
@@ -342,10 +341,14 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
 #undef NN_LAUNCH
     if (profile) prof_end(e, st, &ev, 0, (double)W * (double)nv.count * (8.0 * e->n + 1.0));
     if (tri) { HIPCHK(hipGetLastError()); return 0; }
-    hipLaunchKernelGGL(k_nn_reduce, dim3(W), dim3(64), 0, st, e->d_pcost, e->d_pidx, pca, pia, W,
-                       n_chunks, out_id, out_cost, rec, e->L.R, e->L.off_cost, e->L.off_parent,
-                       wave_lo >= 0 ? e->d_par_done + wave_lo : nullptr, wave_lo >= 0 ? e->d_changed + wave_lo : nullptr,
-                       wave_lo >= 0 ? e->d_stale + wave_lo : nullptr);
+#define RED_LAUNCH(DENSE)                                                                                 \
+    DISPATCH(e, hipLaunchKernelGGL((k_nn_reduce<S, DENSE>), dim3(W), dim3(64), 0, st, e->d_pcost, e->d_pidx, W, n_chunks, nv, \
+                                   xs, S_use, out_id, out_cost, rec, e->L.R, e->L.off_cost, e->L.off_parent,               \
+                                   wave_lo >= 0 ? e->d_par_done + wave_lo : nullptr,                                      \
+                                   wave_lo >= 0 ? e->d_changed + wave_lo : nullptr,                                       \
+                                   wave_lo >= 0 ? e->d_stale + wave_lo : nullptr))
+    if (S_use) { RED_LAUNCH(true); } else { RED_LAUNCH(false); }
+#undef RED_LAUNCH
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -377,8 +380,8 @@ extern "C" int lqrrt_device_count(void) {
 
 static void free_all(lqrrt_engine* e) {
     void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_og, e->d_cell_start, e->d_cell_items, e->d_S, e->tv.state, e->tv.trig, e->tv.K, e->tv.pID, e->tv.elen,
-                    e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_pcost_all,
-                    e->d_pidx, e->d_pidx_all, e->d_par_done, e->d_par_want, e->d_list,
+                    e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost,
+                    e->d_pidx, e->d_par_done, e->d_par_want, e->d_list,
                     e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_cand, e->d_flags};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -528,9 +531,7 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     if (!rc) rc = dalloc(&e->tv.ignore, (size_t)e->cap / 64 + 1);
     const size_t pw = (size_t)lqrrt_engine::MAXCH * e->maxW;
     if (!rc) rc = dalloc(&e->d_pcost, pw);
-    if (!rc) rc = dalloc(&e->d_pcost_all, pw);
     if (!rc) rc = dalloc(&e->d_pidx, pw);
-    if (!rc) rc = dalloc(&e->d_pidx_all, pw);
     if (!rc) rc = dalloc(&e->d_par_done, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_par_want, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_list, (size_t)e->maxW);
@@ -848,7 +849,7 @@ extern "C" int lqrrt_nn_argmin(lqrrt_engine* e, const double* xs, int W, const d
     TRY(use_device(e));
     hipStream_t st = (hipStream_t)stream;
     TRY(flush_ignore(e, st, true));
-    return launch_nn(e, tree_view(e, use_ignore != 0), xs, W, S_dev, false, true, id, cost, nullptr, st, true);
+    return launch_nn(e, tree_view(e, use_ignore != 0), xs, W, S_dev, false, id, cost, nullptr, st, true);
 }
 
 extern "C" int lqrrt_costs_to_go(lqrrt_engine* e, const double* x, const double* S_dev, double* cost, void* stream) {
@@ -1054,7 +1055,7 @@ extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void
     if (cnt > 0) {
         // snapshot NN for the slice: records lo..hi-1 get (cost, parent); the reduce also initialises the
         // slice's wave bookkeeping (parent-in-use, changed, stale)
-        TRY(launch_nn(e, tree_view(e, true), xs + (size_t)lo * e->n, cnt, nullptr, false, true, nullptr, nullptr,
+        TRY(launch_nn(e, tree_view(e, true), xs + (size_t)lo * e->n, cnt, nullptr, false, nullptr, nullptr,
                       e->d_rec + (size_t)lo * e->L.R, st, true, nullptr, lo));
         TRY(launch_steer(e, xs, nullptr, lo, cnt, e->d_par_done, st));
     }
@@ -1145,7 +1146,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     while (true) {
         int n_chunks = 1;
         if (W > 1) {
-            TRY(launch_nn(e, record_view(e, W), xs, W, nullptr, true, false, nullptr, nullptr, nullptr, st, false, &n_chunks));
+            TRY(launch_nn(e, record_view(e, W), xs, W, nullptr, true, nullptr, nullptr, nullptr, st, false, &n_chunks));
         } else {
             HIPCHK(hipMemsetAsync(e->d_pidx, 0xff, sizeof(int), st));        // no in-wave candidate
             HIPCHK(hipMemsetAsync(e->d_pcost, 0x7f, sizeof(double), st));    // large finite cost

@@ -128,12 +128,14 @@ __device__ __forceinline__ double quad_cost(const double* e, const double* Sd) {
 // NN scan.  grid = (ceil(W/64), n_chunks), block = 64.  Lane = sample, uniform loop over the
 // chunk's nodes.  TRI: only nodes with index < sample index are eligible (in-wave pass; a
 // separate instantiation so that profiles tell it apart from the tree scan).
-// Output partial minima [chunk][W]: masked (respecting `ignore`) and unmasked.
+// Output: partial minima over the eligible nodes (not ignored / accepted in-wave record) at
+// [chunk * ps_c + sample * ps_t]: the tree scan writes sample-major (ps_c = 1) so that k_nn_reduce reads a
+// sample's partials contiguously; the in-wave scan writes chunk-major (ps_t = 1), the order k_decide wants.
 template <class S, bool DENSE, bool TRI>
 __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __restrict__ xs, int W,
                                                 const double* __restrict__ Sd, int chunk,
                                                 double* __restrict__ pcost, int* __restrict__ pidx,
-                                                double* __restrict__ pcost_all, int* __restrict__ pidx_all) {
+                                                int ps_c, int ps_t) {
     // one node = N state doubles + 2*NW trig doubles + 1 eligibility flag, padded to an even count so
     // that every node starts 16-byte aligned in LDS (ds_read_b128 broadcasts)
     constexpr int NV = S::N + 2 * S::NW;
@@ -175,8 +177,8 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
     for (int j = 0; j < 2 * S::NW; ++j) same_angles = same_angles && (gtrig[j] == __shfl(gtrig[j], 0));
     same_angles = S::NW > 0 && __all(same_angles) != 0;
 
-    double best = INFINITY, best_all = INFINITY;
-    int bidx = -1, bidx_all = -1;
+    double best = INFINITY;
+    int bidx = -1;
     for (int base = i0; base < i1; base += 64) {
         const int cnt = (i1 - base) < 64 ? (i1 - base) : 64;
         __syncthreads();
@@ -218,14 +220,12 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
             const int i = base + j;
             const bool ign = nd[NV] != 0.0;
             const bool ok = TRI ? (i < t) : true;
-            if (ok && c < best_all) { best_all = c; bidx_all = i; }
             if (ok && !ign && c < best) { best = c; bidx = i; }
         }
     }
     if (t < W) {
-        const size_t o = (size_t)by * W + t;
+        const size_t o = (size_t)by * ps_c + (size_t)t * ps_t;
         pcost[o] = best; pidx[o] = bidx;
-        if (pcost_all) { pcost_all[o] = best_all; pidx_all[o] = bidx_all; }
     }
 }
 
@@ -244,32 +244,48 @@ __device__ __forceinline__ void lexmin_wave(double& c, int& i) {
     }
 }
 
+template <class S, bool DENSE>
 __global__ __launch_bounds__(64) void k_nn_reduce(const double* __restrict__ pcost, const int* __restrict__ pidx,
-                                                  const double* __restrict__ pcost_all, const int* __restrict__ pidx_all,
-                                                  int W, int n_chunks, int* __restrict__ out_id, double* __restrict__ out_cost,
+                                                  int W, int n_chunks, NodeView nv, const double* __restrict__ xs,
+                                                  const double* __restrict__ Sd,
+                                                  int* __restrict__ out_id, double* __restrict__ out_cost,
                                                   double* __restrict__ rec, int R, int off_cost, int off_parent,
                                                   int* __restrict__ par_done, unsigned char* __restrict__ changed,
                                                   unsigned char* __restrict__ stale) {
     const int t = blockIdx.x;
     if (t >= W) return;
     const int lane = threadIdx.x;
-    double b = INFINITY, ba = INFINITY;
-    int bi = -1, bai = -1;
-    for (int c = lane; c < n_chunks; c += 64) {              // ascending per lane, strict '<'
-        const size_t o = (size_t)c * W + t;
-        const double v = pcost[o];
-        const int vi = pidx[o];
+    double b = INFINITY;
+    int bi = -1;
+    const double* pc = pcost + (size_t)t * n_chunks;          // sample-major partials: coalesced
+    const int* pi = pidx + (size_t)t * n_chunks;
+    for (int c = lane; c < n_chunks; c += 64) {               // ascending per lane, strict '<'
+        const double v = pc[c];
+        const int vi = pi[c];
         if (vi >= 0 && (bi < 0 || v < b)) { b = v; bi = vi; }
-        if (pcost_all) {
-            const double va = pcost_all[o];
-            const int vai = pidx_all[o];
-            if (vai >= 0 && (bai < 0 || va < ba)) { ba = va; bai = vai; }
-        }
     }
     lexmin_wave(b, bi);
-    if (pcost_all) lexmin_wave(ba, bai);
-    const bool fallback = bi < 0 && pcost_all;               // every snapshot node is ignored
-    if (fallback) { b = ba; bi = bai; }
+    // Every node ignored (planner.py:241,245): the reference falls back to the overall nearest.  Rare (a tree
+    // that is nothing but goal paths), so it is not worth a second set of partials in the scan: this
+    // wavefront rescans the table without the mask, lanes striding over the nodes.
+    const bool fallback = bi < 0 && nv.ignore != nullptr;
+    if (fallback) {
+        double xg[S::N], gtrig[2 * S::NW + 1];
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) xg[d] = xs[(size_t)t * S::N + d];
+        trig_of<S>(xg, gtrig);
+        for (int i = lane; i < nv.count; i += 64) {
+            double x[S::N], trig[2 * S::NW + 1], e[S::N];
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) x[d] = nv.x[(long long)i * nv.sn + d * nv.sd];
+#pragma unroll
+            for (int j = 0; j < 2 * S::NW; ++j) trig[j] = nv.trig[(long long)i * nv.tn + j * nv.td];
+            erf_cached<S>(xg, gtrig, x, trig, e);
+            const double c = quad_cost<S, DENSE>(e, Sd);
+            if (bi < 0 || c < b) { b = c; bi = i; }
+        }
+        lexmin_wave(b, bi);
+    }
     if (lane == 0) {
         if (out_id) out_id[t] = bi;
         if (out_cost) out_cost[t] = b;
