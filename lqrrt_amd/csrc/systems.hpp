@@ -220,6 +220,12 @@ struct BoatCommon {
         const bool odd = (lane & 1) != 0;
         const double c = trig[0], s = trig[1];
         const double ya = ttrig[1] * c - ttrig[0] * s, xa = ttrig[0] * c + ttrig[1] * s;     // wrap_err(target, x)
+#ifdef ABL_NORUDDER
+        e2 = lq_atan2(ya, xa); rud = 0.0; lq_sincos(x[2] + x[5] * dt, &trn[1], &trn[0]); return;
+#endif
+#ifdef ABL_NOTRIG
+        e2 = ya; rud = yb * 1e-3; trn[1] = s; trn[0] = c; return;
+#endif
         const double a = lq_atan2(odd ? yb : ya, odd ? xb : xa);
         e2 = quad_bcast<0>(a);
         const double ang = quad_bcast<1>(a);
