@@ -49,31 +49,33 @@
 
 /* sin and cos of x together */
 LQ_HD void lq_sincos(double x, double* sn, double* cs) {
-    double r, rt;
-    int q = 0;
     const double ax = fabs(x);
-    if (ax <= LQ_PI_4_HI) {
-        r = x;
-        rt = 0.0;
-    } else if (ax < 1.6e6) {
-        const double fn = floor(x * LQ_2_OVER_PI + 0.5);
-        double r0 = x - fn * LQ_P1;                 /* exact: fn*P1 has <= 53 bits, Sterbenz */
-        double w = fn * LQ_P1T;
-        r = r0 - w;
-        if (fabs(r) < fabs(r0) * 0x1p-16) {         /* x close to a multiple of pi/2: go one level deeper */
-            const double t = r0;
-            w = fn * LQ_P2;
-            r0 = t - w;
-            w = fn * LQ_P2T - ((t - r0) - w);
-            r = r0 - w;
-        }
-        rt = (r0 - r) - w;
-        q = (int)(fn - 4.0 * floor(fn * 0.25));      /* fn mod 4 in {0,1,2,3} */
-    } else {
+    if (!(ax < 1.6e6)) {                             /* also NaN and infinities */
         *sn = sin(x);
         *cs = cos(x);
         return;
     }
+    /* Straight-line on purpose (selects, no branches): on the GPU different lanes of a wavefront evaluate
+     * different arguments, and a data-dependent branch costs an exec-mask round trip even when not taken.
+     * |x| <= pi/4 is the n = 0 case of the general reduction (r0 = x - 0, w = 0, r = x, rt = +0). */
+    const double fn = (ax <= LQ_PI_4_HI) ? 0.0 : floor(x * LQ_2_OVER_PI + 0.5);
+    double r0 = x - fn * LQ_P1;                      /* exact: fn*P1 has <= 53 bits, Sterbenz */
+    double w = fn * LQ_P1T;
+    double r = r0 - w;
+    {
+        /* x close to a multiple of pi/2: one level deeper (computed always, selected when needed) */
+        const int deep = fabs(r) < fabs(r0) * 0x1p-16;
+        const double t = r0;
+        const double w2 = fn * LQ_P2;
+        const double r0d = t - w2;
+        const double wd = fn * LQ_P2T - ((t - r0d) - w2);
+        const double rd = r0d - wd;
+        r0 = deep ? r0d : r0;
+        w = deep ? wd : w;
+        r = deep ? rd : r;
+    }
+    const double rt = (r0 - r) - w;
+    const int q = (int)(fn - 4.0 * floor(fn * 0.25));   /* fn mod 4 in {0,1,2,3} */
     const double z = r * r;
     /* sin r = r + r z (s3 + z (s5 + ... + z s17)) */
     double ps = 0x1.952c77030ad4ap-49;                          /* 1/17! */
@@ -111,8 +113,8 @@ LQ_HD double lq_cos(double x) { double s, c; lq_sincos(x, &s, &c); return c; }
 LQ_HD double lq_atan2(double y, double x) {
     const double ax = fabs(x), ay = fabs(y);
     const int xneg = copysign(1.0, x) < 0.0;
-    if (ay == 0.0) return xneg ? copysign(LQ_PI_HI, y) : y;
-    if (ax == 0.0) return copysign(LQ_PI_2_HI, y);
+    /* the zero cases are patched in at the end by selects (straight-line code, see lq_sincos); the general
+     * path may then see 0/0, whose NaN is discarded */
     const int swap = ay > ax;
     const double mx = swap ? ay : ax, mn = swap ? ax : ay;
     const double t = mn / mx;
@@ -132,9 +134,12 @@ LQ_HD double lq_atan2(double y, double x) {
     p = fma(p, w, -0x1.5555555555555p-2);
     const double corr = z * w * p;                               /* atan z - z */
     double a = big ? LQ_PI_4_HI + (z + (corr + LQ_PI_4_LO)) : z + corr;
-    if (swap) a = LQ_PI_2_HI - (a - LQ_PI_2_LO);
-    if (xneg) a = LQ_PI_HI - (a - LQ_PI_LO);
-    return copysign(a, y);
+    a = swap ? LQ_PI_2_HI - (a - LQ_PI_2_LO) : a;
+    a = xneg ? LQ_PI_HI - (a - LQ_PI_LO) : a;
+    double res = copysign(a, y);
+    res = (ax == 0.0) ? copysign(LQ_PI_2_HI, y) : res;
+    res = (ay == 0.0) ? (xneg ? copysign(LQ_PI_HI, y) : y) : res;
+    return res;
 }
 
 /* ln 2 = LN2_HI + LN2_LO, LN2_HI with 32 significant bits so that k*LN2_HI is exact for |k| < 2^20 */
