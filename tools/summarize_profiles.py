@@ -24,6 +24,15 @@ def per_kernel(path, name_part):
     return len(rows), sum(vals), sum(durs)
 
 
+def steady_state_ns(path, name_part, last):
+    """Average duration of the last `last` launches of a kernel (the bench's windowed loop at ~10k nodes; the
+    launches before them belong to the tree-growth phase, where the node table is smaller)."""
+    rows = [r for r in csv.DictReader(open(path)) if name_part in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    rows = rows[-last:]
+    return sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows) / float(len(rows)), len(rows)
+
+
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = os.path.join(ROOT, "gpurun_out")
@@ -41,6 +50,11 @@ def main():
         "hbm_bytes_per_launch": (2.0 * fetch_kib / n_f + write_kib / n_w) * 1024.0,
         "avg_launch_ns_fetch_pass": dur_f / n_f, "avg_launch_ns_write_pass": dur_w / n_w,
     }
+    ss, cnt = steady_state_ns(os.path.join(src, "prof_r1_fetch", "bench_counter_collection.csv"), kern, 250)
+    summary["steady_state_avg_launch_ns"] = ss
+    summary["steady_state_launches"] = cnt
+    summary["steady_state_note"] = ("last %d launches of the process = bench.py's windowed loop at 9.5k-10.5k nodes (the same launches "
+                                    "bench.py brackets with HIP events; an event bracket adds the dispatch gap, ~3 us)" % cnt)
     with open(os.path.join(out, "%s_nn_traffic.json" % rnd), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps(summary, indent=1))
