@@ -147,6 +147,12 @@ int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int capacity, 
                         lqrrt_engine** out);
 int lqrrt_engine_destroy(lqrrt_engine* e);
 
+/* Replaces the model parameters, hull points, obstacle table and occupancy grid of an existing engine (same
+ * model); the tree is kept, queued samples are regenerated from the first uncommitted row of the stream.
+ * This is what the ROS node does between plans when a new map arrives: module globals of the behaviour
+ * files + Constraints.set_feasibility_function (lqrrt_node.py:65, 260-263, 719-745). */
+int lqrrt_engine_set_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys, void* stream);
+
 /* Changing horizon_iters re-lays out the edge pools: call lqrrt_tree_reset afterwards. */
 int lqrrt_engine_set_resolution(lqrrt_engine* e, const lqrrt_resolution* r);
 

@@ -47,3 +47,19 @@ class Constraints:
             raise ValueError("The feasibility plugin is for a %d-state/%d-effort system." % (system.nstates, system.ncontrols))
         self.is_feasible = is_feasible
         self.system = system
+
+    # -- batched evaluation (build-only additions; the reference calls is_feasible once per state) ------
+    def feasible_batch(self, X, U=None):
+        """is_feasible for every row of X (and U, zeros when omitted) in one device launch."""
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        return self.system._engine().feasible_batch(X, None if U is None else np.atleast_2d(np.asarray(U, dtype=np.float64)))
+
+    def first_infeasible(self, X, U=None):
+        """
+        Index of the first infeasible row of X, or -1: the plan re-evaluation of the ROS node
+        (lqrrt_node.py:806-824 walks the next seconds of the current plan, velocities zeroed by the
+        caller, and reacts to the first state that now collides with the map).
+        """
+        ok = self.feasible_batch(X, U)
+        bad = np.nonzero(~np.asarray(ok, dtype=bool))[0]
+        return int(bad[0]) if len(bad) else -1

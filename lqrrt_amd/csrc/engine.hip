@@ -454,30 +454,9 @@ static int build_box_grid(lqrrt_engine* e, const lqrrt_system_desc* sys) {
     return 0;
 }
 
-extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int capacity, int max_wave,
-                                   lqrrt_engine** out) {
-    if (!sys || !out) return fail(LQRRT_E_ARG, "null argument");
-    *out = nullptr;
-    int n, m, nw;
-    if (!model_dims(sys->model, &n, &m, &nw)) return fail(LQRRT_E_ARG, "unknown model %d", sys->model);
-    if (sys->nstates != n || sys->ncontrols != m)
-        return fail(LQRRT_E_ARG, "model %d expects nstates=%d ncontrols=%d, got %d/%d", sys->model, n, m,
-                    sys->nstates, sys->ncontrols);
-    if (capacity < 2 || max_wave < 1 || max_wave > 4096)
-        return fail(LQRRT_E_ARG, "capacity must be >= 2 and 1 <= max_wave <= 4096");
-    if (sys->n_params < 0 || sys->n_params > LQRRT_MAX_PARAMS) return fail(LQRRT_E_ARG, "bad n_params");
-    if (lqrrt_device_count() <= device || device < 0)
-        return fail(LQRRT_E_NODEVICE, "HIP device %d not available (found %d)", device, lqrrt_device_count());
-    HIPCHK(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
-    if (prop.warpSize != 64) return fail(LQRRT_E_NODEVICE, "wavefront size %d != 64 (gfx950 expected)", prop.warpSize);
-
-    lqrrt_engine* e = new lqrrt_engine();
-    e->device = device; e->model = sys->model; e->n = n; e->m = m; e->nw = nw;
-    e->cap = ((capacity + 63) / 64) * 64; e->maxW = max_wave; e->H = 1;
-    memset(&e->P, 0, sizeof e->P);
-    memcpy(e->P.p, sys->params, sizeof(double) * sys->n_params);
+// Problem geometry on the device: hull points, obstacle table (+ exact collision thresholds / box grid) and
+// the optional occupancy grid.  Used at creation and by lqrrt_engine_set_geometry.
+static int upload_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys) {
     int rc = 0;
     auto up = [&](double** dst, const double* src, size_t cnt) -> int {
         TRY(dalloc(dst, cnt));
@@ -486,10 +465,6 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     };
     e->geo.V = sys->n_vertices; e->geo.O = sys->n_obstacles;
     e->geo.stride = sys->obs_stride > 0 ? sys->obs_stride : 3; e->geo.pad = 0;
-    if ((sys->n_vertices > 0 && !sys->vps) || (sys->n_obstacles > 0 && !sys->obs)) {
-        delete e;
-        return fail(LQRRT_E_ARG, "vps/obs pointer missing");
-    }
     rc = up(&e->d_vps, sys->vps, (size_t)2 * sys->n_vertices);
     if (!rc) rc = up(&e->d_obs, sys->obs, (size_t)sys->n_obstacles * e->geo.stride);
     e->geo.vps = e->d_vps; e->geo.obs = e->d_obs; e->geo.oc = nullptr;
@@ -522,6 +497,47 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     }
     e->geo.cell_start = nullptr; e->geo.cell_items = nullptr;
     if (!rc && e->geo.stride == 6 && sys->n_obstacles > 0) rc = build_box_grid(e, sys);
+    return rc;
+}
+
+static void free_geometry(lqrrt_engine* e) {
+    void** ptrs[] = {(void**)&e->d_vps, (void**)&e->d_obs, (void**)&e->d_oc, (void**)&e->d_og, (void**)&e->d_cell_start, (void**)&e->d_cell_items};
+    for (void** p : ptrs) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+}
+
+extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int capacity, int max_wave,
+                                   lqrrt_engine** out) {
+    if (!sys || !out) return fail(LQRRT_E_ARG, "null argument");
+    *out = nullptr;
+    int n, m, nw;
+    if (!model_dims(sys->model, &n, &m, &nw)) return fail(LQRRT_E_ARG, "unknown model %d", sys->model);
+    if (sys->nstates != n || sys->ncontrols != m)
+        return fail(LQRRT_E_ARG, "model %d expects nstates=%d ncontrols=%d, got %d/%d", sys->model, n, m,
+                    sys->nstates, sys->ncontrols);
+    if (capacity < 2 || max_wave < 1 || max_wave > 4096)
+        return fail(LQRRT_E_ARG, "capacity must be >= 2 and 1 <= max_wave <= 4096");
+    if (sys->n_params < 0 || sys->n_params > LQRRT_MAX_PARAMS) return fail(LQRRT_E_ARG, "bad n_params");
+    if (lqrrt_device_count() <= device || device < 0)
+        return fail(LQRRT_E_NODEVICE, "HIP device %d not available (found %d)", device, lqrrt_device_count());
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (prop.warpSize != 64) return fail(LQRRT_E_NODEVICE, "wavefront size %d != 64 (gfx950 expected)", prop.warpSize);
+
+    lqrrt_engine* e = new lqrrt_engine();
+    e->device = device; e->model = sys->model; e->n = n; e->m = m; e->nw = nw;
+    e->cap = ((capacity + 63) / 64) * 64; e->maxW = max_wave; e->H = 1;
+    memset(&e->P, 0, sizeof e->P);
+    memcpy(e->P.p, sys->params, sizeof(double) * sys->n_params);
+    int rc = 0;
+    if ((sys->n_vertices > 0 && !sys->vps) || (sys->n_obstacles > 0 && !sys->obs)) {
+        delete e;
+        return fail(LQRRT_E_ARG, "vps/obs pointer missing");
+    }
+    rc = upload_geometry(e, sys);
     e->tv.cap = e->cap;
     if (!rc) rc = dalloc(&e->tv.state, (size_t)n * e->cap);
     if (!rc) rc = dalloc(&e->tv.trig, (size_t)(2 * nw + 1) * e->cap);
@@ -621,13 +637,9 @@ extern "C" int lqrrt_engine_set_resolution(lqrrt_engine* e, const lqrrt_resoluti
 
 extern "C" int lqrrt_engine_horizon_iters(lqrrt_engine* e) { return e ? e->h_iters : LQRRT_E_ARG; }
 
-extern "C" int lqrrt_engine_set_sampler(lqrrt_engine* e, const lqrrt_sampler_desc* s) {
-    if (!e || !s) return fail(LQRRT_E_ARG, "null argument");
-    if (s->tries_limit < 1) return fail(LQRRT_E_ARG, "tries_limit must be >= 1");
-    e->smp = *s;
-    e->has_sampler = true;
-    e->explicit_samples = false;
-    // same invalidation as a goal change
+// Queued (not yet committed) samples depend on the goal, the sampler settings and the feasibility of the world:
+// drop them and rewind the generator to the first uncommitted candidate row.
+static void invalidate_samples(lqrrt_engine* e) {
     e->pool.clear(); e->pool_rows_end.clear();
     e->pool_base = e->cursor;
     MT g = e->mt_base;
@@ -635,6 +647,31 @@ extern "C" int lqrrt_engine_set_sampler(lqrrt_engine* e, const lqrrt_sampler_des
     e->mt_base = g; e->base_row = e->committed_row;
     e->mt_gen = g; e->gen_row = e->committed_row;
     e->tries_carry = 0; e->d_pool_count = 0;
+}
+
+extern "C" int lqrrt_engine_set_sampler(lqrrt_engine* e, const lqrrt_sampler_desc* s) {
+    if (!e || !s) return fail(LQRRT_E_ARG, "null argument");
+    if (s->tries_limit < 1) return fail(LQRRT_E_ARG, "tries_limit must be >= 1");
+    e->smp = *s;
+    e->has_sampler = true;
+    e->explicit_samples = false;
+    invalidate_samples(e);
+    return 0;
+}
+
+extern "C" int lqrrt_engine_set_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys, void* stream) {
+    if (!e || !sys) return fail(LQRRT_E_ARG, "null argument");
+    if (sys->model != e->model || sys->nstates != e->n || sys->ncontrols != e->m)
+        return fail(LQRRT_E_ARG, "set_geometry cannot change the model (engine: model %d, %d states)", e->model, e->n);
+    if (sys->n_params < 0 || sys->n_params > LQRRT_MAX_PARAMS) return fail(LQRRT_E_ARG, "bad n_params");
+    if ((sys->n_vertices > 0 && !sys->vps) || (sys->n_obstacles > 0 && !sys->obs)) return fail(LQRRT_E_ARG, "vps/obs pointer missing");
+    TRY(use_device(e));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));       // nothing in flight may still read the old tables
+    free_geometry(e);
+    memset(&e->P, 0, sizeof e->P);
+    memcpy(e->P.p, sys->params, sizeof(double) * sys->n_params);
+    TRY(upload_geometry(e, sys));
+    if (!e->explicit_samples) invalidate_samples(e);          // queued samples were filtered against the old world
     return 0;
 }
 

@@ -32,10 +32,23 @@ class Engine(object):
         h = C.c_void_p()
         nat.check(nat.lib().lqrrt_engine_create(C.byref(desc), device, self.capacity, self.max_wave, C.byref(h)))
         self.h = h
+        self._geometry_revision = getattr(system, "revision", 0)
         if system.S is not None:
             S = nat.as_f64(system.S, (self.n, self.n))
             nat.check(nat.lib().lqrrt_engine_set_dense_S(self.h, nat.ptr(S)))
         self.horizon_iters = None
+
+    def sync_geometry(self):
+        """Re-uploads parameters, hull points, obstacles and occupancy grid if the system object changed since
+        this engine last saw it (system.revision; e.g. set_occupancy_grid between two plans)."""
+        rev = getattr(self.system, "revision", 0)
+        if rev != self._geometry_revision:
+            desc, keep = self.system.desc()
+            nat.check(nat.lib().lqrrt_engine_set_geometry(self.h, C.byref(desc), nat.current_stream()))
+            self._keep = keep
+            self._geometry_revision = rev
+            return True
+        return False
 
     def close(self):
         if getattr(self, "h", None):

@@ -96,6 +96,7 @@ class Planner:
                 self._engine.close()
             self._engine = Engine(self.system, capacity=capacity, max_wave=self.wave_size, device=self.device)
             self._engine_key = key
+        self._engine.sync_geometry()        # the world may have changed since the last plan (new map, new obstacles)
         return self._engine
 
     def update_plan(self, x0, sample_space, goal_bias=0,

@@ -103,6 +103,7 @@ class NativeSystem(object):
         self.obs = np.zeros((0, 3))
         self.obs_stride = 3
         self.ogrid = None         # optional occupancy grid: dict(grid=int8 [rows][cols], origin=(x,y), cpm, threshold)
+        self.revision = 0         # bumped whenever the world changes; engines re-upload on their next use
         self._ops = None
         self._ops_dt = None
 
@@ -138,8 +139,9 @@ class NativeSystem(object):
         """
         Switches the collision model of a planar vehicle to the ROS node's occupancy-grid test
         (demos/lqrrt_ros/nodes/lqrrt_node.py:719-745; grid as in nav_msgs/OccupancyGrid: -1 unknown, 0..100).
-        Optionally replaces the hull points (e.g. behaviors/params.py's 0.1 m lattice).  Engines already
-        created keep the old model.
+        Optionally replaces the hull points (e.g. behaviors/params.py's 0.1 m lattice).  Engines that already
+        exist (a Planner's, the one behind the plugin handles) pick the new map up on their next use, which is
+        how the node swaps maps between plans (lqrrt_node.py:65, 1120-1140).
         """
         if self.model not in (nat.MODEL_BOAT_ADVANCED, nat.MODEL_BOAT_INTERMEDIATE, nat.MODEL_CAR, nat.MODEL_ROS_BOAT):
             raise ValueError("occupancy-grid feasibility is defined for the hull-sweeping vehicles")
@@ -152,7 +154,18 @@ class NativeSystem(object):
                           cpm=float(cpm) if cpm is not None else 1.0 / float(resolution), threshold=float(threshold))
         if vps is not None:
             self.vps = np.ascontiguousarray(vps, dtype=np.float64).reshape(2, -1)
-        self._ops = None
+        self.revision += 1
+
+    def clear_occupancy_grid(self):
+        """Back to the obstacle-table collision model."""
+        self.ogrid = None
+        self.revision += 1
+
+    def set_obstacles(self, obs):
+        """Replaces the obstacle table ([x, y, r] rows; boxes [lo(3), hi(3)] for the double integrator)."""
+        obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, self.obs_stride)
+        self.obs = obs
+        self.revision += 1
 
     def Smatrix(self):
         return np.eye(self.nstates) if self.S is None else np.asarray(self.S, dtype=np.float64)
@@ -162,6 +175,7 @@ class NativeSystem(object):
         from .engine import Engine
         if self._ops is None:
             self._ops = Engine(self, capacity=64, max_wave=64)
+        self._ops.sync_geometry()
         if dt is not None and dt != self._ops_dt:
             self._ops.set_resolution(dt=dt, FPR=0.0, horizon_iters=1, error_tol=np.zeros(self.nstates),
                                      goal=None, goal_buffer=None)

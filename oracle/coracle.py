@@ -94,6 +94,10 @@ class COracle(object):
         key = np.ascontiguousarray(st[1], dtype=np.uint32)
         lib().orc_set_mt19937(self.h, _p(key), int(st[2]))
 
+    def set_mt19937(self, key, pos):
+        key = np.ascontiguousarray(key, dtype=np.uint32)
+        lib().orc_set_mt19937(self.h, _p(key), int(pos))
+
     def reset(self, x0):
         x0 = _f(x0)
         lib().orc_reset(self.h, _p(x0))

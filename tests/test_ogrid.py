@@ -93,3 +93,73 @@ def test_hip_ogrid_tree_bit_exact_vs_coracle(golden_dir):
     np.testing.assert_array_equal(eng.states(), o.states())
     np.testing.assert_array_equal(eng.edge_lengths(), o.edge_lengths())
     assert (eng.edge_lengths() < 20).mean() > 0.05          # the grid actually cut edges
+
+
+@pytest.mark.gpu
+def test_map_swap_between_plans_matches_fresh_oracle(golden_dir):
+    """A new map arrives between two plans (lqrrt_node.py:65, 719-745): the existing engine must plan through
+    the NEW map exactly like the sequential oracle built on it, and the plugin handle must see it too."""
+    import coracle
+    import lqrrt_amd
+    from lqrrt_amd.engine import Engine
+    g = _fixture(golden_dir)
+    s = lqrrt_amd.systems.BoatIntermediate(0)
+    cpm, origin = float(g["cpm"]), g["origin"]
+
+    def cleared(grid):
+        grid = np.array(grid)
+        for px, py in ((s.x0[0], s.x0[1]), (s.goal[0], s.goal[1])):
+            c, r = int(cpm * (px - origin[0])), int(cpm * (py - origin[1]))
+            grid[max(r - 40, 0):r + 40, max(c - 40, 0):c + 40] = 0
+        return grid
+
+    map_a = cleared(g["grid"])
+    map_b = cleared(np.roll(np.array(g["grid"]), 37, axis=1)[::-1])       # a different world
+    s.set_occupancy_grid(map_a, origin, cpm=cpm, threshold=float(g["threshold"]))
+    nodes, wave, budget = 600, 128, 6000
+    eng = Engine(s, capacity=nodes + wave + 8, max_wave=wave)
+    kw = s.plan_kwargs
+    eng.set_resolution(kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer))
+    space = np.array(s.sample_space, dtype=np.float64)
+    eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), np.array(s.goal_bias, dtype=np.float64), 10)
+    st = np.random.RandomState(5).get_state()
+    eng.set_mt19937(st[1], st[2])
+    eng.tree_reset(s.x0)
+    eng.extend(wave, max_attempts=budget // 2, node_limit=nodes)            # first plan, map A (leaves queued samples behind)
+    probe = g["x"][:256]
+    ok_a = s._engine(0.1).feasible_batch(probe)
+
+    s.set_occupancy_grid(map_b, origin, cpm=cpm, threshold=float(g["threshold"]))
+    assert eng.sync_geometry() and not eng.sync_geometry()
+    ok_b = s._engine(0.1).feasible_batch(probe)
+    assert (ok_a != ok_b).any()
+    key, pos = eng.get_mt19937()                                             # the stream continues where plan 1 stopped
+    eng.tree_reset(s.x0)
+    stats = eng.extend(wave, max_attempts=budget, node_limit=nodes)
+
+    o = coracle.make(s, nodes + wave + 8, seed=5)                            # fresh oracle on map B ...
+    o.set_mt19937(key, pos)                                                  # ... fed the same continued stream
+    o.extend(max_iters=budget, max_nodes=nodes)
+    assert eng.size == o.size and eng.size > 100
+    np.testing.assert_array_equal(eng.parents(), o.parents())
+    np.testing.assert_array_equal(eng.states(), o.states())
+    assert stats.attempts == o.iterations
+    okc = np.array([o.feasible(x, np.zeros(3)) for x in probe])
+    np.testing.assert_array_equal(ok_b, okc)
+
+
+@pytest.mark.gpu
+def test_first_infeasible_plan_reevaluation(golden_dir):
+    """Constraints.first_infeasible = the node's walk along the current plan (lqrrt_node.py:806-824)."""
+    import lqrrt_amd
+    g = _fixture(golden_dir)
+    s = _native_boat(g)
+    c = lqrrt_amd.Constraints(6, 3, s.goal_buffer, s.is_feasible)
+    X = np.array(g["x"][:400])
+    ok = np.array(g["ok"][:400], dtype=bool)
+    want = int(np.nonzero(~ok)[0][0]) if (~ok).any() else -1
+    assert c.first_infeasible(X) == want
+    np.testing.assert_array_equal(c.feasible_batch(X), ok)
+    free = X[ok]
+    assert c.first_infeasible(free) == -1
+    assert c.first_infeasible(free[:0].reshape(0, 6)) == -1
