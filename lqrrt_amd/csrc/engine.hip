@@ -107,6 +107,7 @@ struct lqrrt_engine {
     double* d_obs = nullptr;
     double* d_oc = nullptr;       // derived circle table [O][4]
     signed char* d_og = nullptr;  // occupancy grid
+    unsigned char* d_ogc = nullptr;   // its 8x8 max-pooled companion
     int* d_cell_start = nullptr;  // box obstacles: uniform grid (CSR) over the boxes' bounding volume
     int* d_cell_items = nullptr;
     double* d_S = nullptr;        // dense system S (n x n) or null = identity
@@ -223,7 +224,7 @@ static bool model_dims(int model, int* n, int* m, int* nw) {
 }
 
 static size_t geo_lds_bytes(const lqrrt_engine* e) {
-    if (e->geo.og) return 0;
+    if (e->geo.og) return e->geo.og_lds ? sizeof(double) * (size_t)2 * e->geo.V : 0;
     return e->geo.oc ? sizeof(double) * ((size_t)2 * e->geo.V + (size_t)4 * e->geo.O) : 0;
 }
 
@@ -379,7 +380,7 @@ extern "C" int lqrrt_device_count(void) {
 }
 
 static void free_all(lqrrt_engine* e) {
-    void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_og, e->d_cell_start, e->d_cell_items, e->d_S, e->tv.state, e->tv.trig, e->tv.K, e->tv.pID, e->tv.elen,
+    void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_og, e->d_ogc, e->d_cell_start, e->d_cell_items, e->d_S, e->tv.state, e->tv.trig, e->tv.K, e->tv.pID, e->tv.elen,
                     e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost,
                     e->d_pidx, e->d_par_done, e->d_par_want, e->d_list,
                     e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_cand, e->d_flags};
@@ -485,7 +486,7 @@ static int upload_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys) {
         rc = up(&e->d_oc, oc.data(), (size_t)4 * sys->n_obstacles);
         e->geo.oc = e->d_oc;
     }
-    e->geo.og = nullptr;
+    e->geo.og = nullptr; e->geo.ogc = nullptr; e->geo.og_lds = 0;
     if (!rc && sys->ogrid) {
         if (sys->og_rows < 1 || sys->og_cols < 1 || !(sys->og_cpm > 0)) rc = fail(LQRRT_E_ARG, "bad occupancy grid");
         if (!rc) rc = dalloc(&e->d_og, (size_t)sys->og_rows * sys->og_cols);
@@ -494,6 +495,24 @@ static int upload_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys) {
         e->geo.og = e->d_og; e->geo.og_rows = sys->og_rows; e->geo.og_cols = sys->og_cols;
         e->geo.og_ox = sys->og_origin[0]; e->geo.og_oy = sys->og_origin[1];
         e->geo.og_cpm = sys->og_cpm; e->geo.og_thr = sys->og_threshold;
+        // coarse map for the conservative cull in grid_hits: block (R, C) = any occupied cell in its 8x8 cells,
+        // "occupied" exactly as the sweep reads it: not (value < threshold)
+        const int cr = (sys->og_rows + (1 << OG_COARSE_SHIFT) - 1) >> OG_COARSE_SHIFT;
+        const int cc = (sys->og_cols + (1 << OG_COARSE_SHIFT) - 1) >> OG_COARSE_SHIFT;
+        std::vector<unsigned char> coarse((size_t)cr * cc, 0);
+        for (int r = 0; r < sys->og_rows; ++r)
+            for (int c = 0; c < sys->og_cols; ++c)
+                if (!((double)sys->ogrid[(size_t)r * sys->og_cols + c] < sys->og_threshold))
+                    coarse[(size_t)(r >> OG_COARSE_SHIFT) * cc + (c >> OG_COARSE_SHIFT)] = 1;
+        if (!rc) rc = dalloc(&e->d_ogc, coarse.size());
+        if (!rc && hipMemcpy(e->d_ogc, coarse.data(), coarse.size(), hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(LQRRT_E_HIP, "ogrid upload failed");
+        e->geo.ogc = e->d_ogc; e->geo.ogc_rows = cr; e->geo.ogc_cols = cc;
+        double hull_r = 0.0;
+        for (int v = 0; v < sys->n_vertices; ++v)
+            hull_r = std::max(hull_r, std::sqrt(sys->vps[v] * sys->vps[v] + sys->vps[sys->n_vertices + v] * sys->vps[sys->n_vertices + v]));
+        e->geo.og_reach = hull_r * (1.0 + 1e-9) + 1e-9;
+        e->geo.og_lds = ((size_t)2 * sys->n_vertices * sizeof(double) <= (size_t)48 * 1024) ? 1 : 0;
     }
     e->geo.cell_start = nullptr; e->geo.cell_items = nullptr;
     if (!rc && e->geo.stride == 6 && sys->n_obstacles > 0) rc = build_box_grid(e, sys);
@@ -501,7 +520,7 @@ static int upload_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys) {
 }
 
 static void free_geometry(lqrrt_engine* e) {
-    void** ptrs[] = {(void**)&e->d_vps, (void**)&e->d_obs, (void**)&e->d_oc, (void**)&e->d_og, (void**)&e->d_cell_start, (void**)&e->d_cell_items};
+    void** ptrs[] = {(void**)&e->d_vps, (void**)&e->d_obs, (void**)&e->d_oc, (void**)&e->d_og, (void**)&e->d_ogc, (void**)&e->d_cell_start, (void**)&e->d_cell_items};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;

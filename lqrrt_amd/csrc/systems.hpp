@@ -49,7 +49,12 @@ struct Geo {
     const signed char* og;
     double og_ox, og_oy, og_cpm, og_thr;
     int og_rows, og_cols;
+    // coarse occupancy (1 = some cell of the 8x8 block is occupied) and the vehicle's reach, for a conservative cull
+    const unsigned char* ogc;
+    int ogc_rows, ogc_cols, og_lds;      // og_lds: the hull points fit in LDS next to the edge history
+    double og_reach;
 };
+constexpr int OG_COARSE_SHIFT = 3;
 
 struct GeoL {            // LDS-resident copy used inside a workgroup
     const double* vps;   // [2][V]
@@ -57,14 +62,21 @@ struct GeoL {            // LDS-resident copy used inside a workgroup
     int V, O;
 };
 
-__device__ __forceinline__ size_t geo_lds_doubles(const Geo& g) { return g.oc ? (size_t)2 * g.V + (size_t)4 * g.O : 0; }
+__device__ __forceinline__ size_t geo_lds_doubles(const Geo& g) {
+    if (g.og) return g.og_lds ? (size_t)2 * g.V : 0;
+    return g.oc ? (size_t)2 * g.V + (size_t)4 * g.O : 0;
+}
 
 // Cooperative copy HBM -> LDS by the calling workgroup (caller synchronises afterwards).
 __device__ __forceinline__ GeoL stage_geo(const Geo& g, double* lds, int tid, int nthreads) {
     GeoL L;
     L.V = g.V; L.O = g.O;
     L.vps = lds; L.oc = lds + 2 * g.V;
-    if (g.og) { L.vps = g.vps; return L; }     // occupancy-grid model: hull points are read from HBM/L2
+    if (g.og) {                                // occupancy-grid model: only the hull points are staged
+        if (g.og_lds) { for (int i = tid; i < 2 * g.V; i += nthreads) lds[i] = g.vps[i]; }
+        else L.vps = g.vps;
+        return L;
+    }
     if (g.oc) {
         for (int i = tid; i < 2 * g.V; i += nthreads) lds[i] = g.vps[i];
         for (int i = tid; i < 4 * g.O; i += nthreads) lds[2 * g.V + i] = g.oc[i];
@@ -123,11 +135,31 @@ __device__ __forceinline__ double numpy_row_sum(const double* a) {
 // (int64)(cpm*(p - origin)) (truncation), ogrid[iy][ix] with NumPy's index rules -- an index in
 // [-dim, -1] wraps around, anything else outside raises IndexError there = infeasible here -- and a hit
 // is any value >= threshold.  Lanes split the hull points.
-__device__ __forceinline__ bool grid_hits(const Geo& g, double px, double py, double c, double s, int lane) {
+__device__ __forceinline__ bool grid_hits(const Geo& g, const GeoL& gl, double px, double py, double c, double s, int lane) {
+    // Conservative cull: every hull point lies within og_reach of the centre, so its cell lies in the cell
+    // rectangle of [p - reach, p + reach] (+-1 cell for rounding).  If that rectangle is strictly inside the map
+    // and no 8x8 block it touches holds an occupied cell, no vertex can hit anything: same answer as the sweep,
+    // a handful of byte loads instead of V dependent lookups.  Anything else falls through to the exact sweep.
+    {
+        const double x0 = g.og_cpm * ((px - g.og_reach) - g.og_ox), x1 = g.og_cpm * ((px + g.og_reach) - g.og_ox);
+        const double y0 = g.og_cpm * ((py - g.og_reach) - g.og_oy), y1 = g.og_cpm * ((py + g.og_reach) - g.og_oy);
+        if (x0 >= 2.0 && y0 >= 2.0 && x1 < (double)(g.og_cols - 2) && y1 < (double)(g.og_rows - 2)) {
+            const int cx0 = ((int)x0 - 1) >> OG_COARSE_SHIFT, cx1 = ((int)x1 + 1) >> OG_COARSE_SHIFT;
+            const int cy0 = ((int)y0 - 1) >> OG_COARSE_SHIFT, cy1 = ((int)y1 + 1) >> OG_COARSE_SHIFT;
+            const int nx = cx1 - cx0 + 1, cells = nx * (cy1 - cy0 + 1);
+            bool occ = false;
+            for (int q = lane; q < cells; q += 64) {
+                const int r = q / nx, cc = q - r * nx;
+                occ |= g.ogc[(size_t)(cy0 + r) * g.ogc_cols + (cx0 + cc)] != 0;
+            }
+            if (__any(occ) == 0) return false;
+        }
+    }
     bool hit = false;
     const double ms = -s;
+#pragma unroll 4
     for (int v = lane; v < g.V; v += 64) {
-        const double bx = g.vps[v], by = g.vps[g.V + v];
+        const double bx = gl.vps[v], by = gl.vps[g.V + v];
         const double vx = px + (c * bx + ms * by);
         const double vy = py + (s * bx + c * by);
         long long ix = (long long)(g.og_cpm * (vx - g.og_ox));
@@ -333,7 +365,7 @@ struct BoatAdvanced : BoatCommon {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             if (x[3 + i] > P[46 + i] || x[3 + i] < P[49 + i]) return false;
-        if (g.og) return !grid_hits(g, x[0], x[1], trig[0], trig[1], lane);
+        if (g.og) return !grid_hits(g, gl, x[0], x[1], trig[0], trig[1], lane);
         return !hull_hits(gl, x[0], x[1], trig[0], trig[1], false, lane);
     }
 };
@@ -368,7 +400,7 @@ struct BoatIntermediate : BoatCommon {
         carlike(x, P[13], P[14], xn);
     }
     __device__ static bool feasible(const double*, const Geo& g, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
-        if (g.og) return !grid_hits(g, x[0], x[1], trig[0], trig[1], lane);
+        if (g.og) return !grid_hits(g, gl, x[0], x[1], trig[0], trig[1], lane);
         return !hull_hits(gl, x[0], x[1], trig[0], trig[1], false, lane);
     }
 };
@@ -495,7 +527,7 @@ struct RosBoat : BoatCommon {
         if ((int)P[42] && xn[3] < 0.0) xn[3] = fabs(x[3]);
     }
     __device__ static bool feasible(const double*, const Geo& g, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
-        if (g.og) return !grid_hits(g, x[0], x[1], trig[0], trig[1], lane);   // lqrrt_node.py:719-745
+        if (g.og) return !grid_hits(g, gl, x[0], x[1], trig[0], trig[1], lane);   // lqrrt_node.py:719-745
         if (g.O == 0) return true;                                            // no map yet: anywhere is valid (:726-727)
         return !hull_hits(gl, x[0], x[1], trig[0], trig[1], false, lane);
     }
@@ -527,7 +559,7 @@ struct Car {
         xn[4] = clipd(fabs(xn[3] / P[8]), 0.0, 1.0) * xn[4];            // demo_car.py:70
     }
     __device__ static bool feasible(const double*, const Geo& g, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
-        if (g.og) return !grid_hits(g, x[0], x[1], trig[0], trig[1], lane);   // (the ROS node has no 2p vertex)
+        if (g.og) return !grid_hits(g, gl, x[0], x[1], trig[0], trig[1], lane);   // (the ROS node has no 2p vertex)
         return !hull_hits(gl, x[0], x[1], trig[0], trig[1], true, lane);
     }
 };

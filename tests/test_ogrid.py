@@ -163,3 +163,22 @@ def test_first_infeasible_plan_reevaluation(golden_dir):
     free = X[ok]
     assert c.first_infeasible(free) == -1
     assert c.first_infeasible(free[:0].reshape(0, 6)) == -1
+
+
+@pytest.mark.gpu
+def test_tree_chain_example_runs():
+    """examples/tree_chain_gpu.py: chained update_plan(specific_time=...) with maps changing in between
+    (lqrrt_node.py:389-500).  Wall-clock budgeted, so only structural properties are asserted."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("tree_chain_gpu", os.path.join(root, "examples", "tree_chain_gpu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    log = mod.run(moves=3, basic_duration=0.15, verbose=False)
+    assert len(log) >= 1
+    for i, e in enumerate(log):
+        assert e["nodes"] > 200 and e["attempts"] >= e["nodes"] - 1       # the budget buys a real tree
+        assert 0.1 <= e["seconds"] < 5.0
+        if i > 0 and log[i - 1]["collision_ahead_s"] is None:
+            np.testing.assert_allclose(e["start"], log[i - 1]["seed"])       # chained: starts where the last plan said
