@@ -512,6 +512,14 @@ static int upload_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys) {
         for (int v = 0; v < sys->n_vertices; ++v)
             hull_r = std::max(hull_r, std::sqrt(sys->vps[v] * sys->vps[v] + sys->vps[sys->n_vertices + v] * sys->vps[sys->n_vertices + v]));
         e->geo.og_reach = hull_r * (1.0 + 1e-9) + 1e-9;
+        double bb[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int v = 0; v < sys->n_vertices; ++v) {
+            const double bx = sys->vps[v], by = sys->vps[sys->n_vertices + v];
+            if (v == 0) { bb[0] = bb[1] = bx; bb[2] = bb[3] = by; }
+            bb[0] = std::min(bb[0], bx); bb[1] = std::max(bb[1], bx);
+            bb[2] = std::min(bb[2], by); bb[3] = std::max(bb[3], by);
+        }
+        for (int k = 0; k < 4; ++k) e->geo.og_bb[k] = bb[k];
         e->geo.og_lds = ((size_t)2 * sys->n_vertices * sizeof(double) <= (size_t)48 * 1024) ? 1 : 0;
     }
     e->geo.cell_start = nullptr; e->geo.cell_items = nullptr;

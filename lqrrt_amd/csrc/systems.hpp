@@ -53,6 +53,7 @@ struct Geo {
     const unsigned char* ogc;
     int ogc_rows, ogc_cols, og_lds;      // og_lds: the hull points fit in LDS next to the edge history
     double og_reach;
+    double og_bb[4];                     // body-frame bounding box of the hull points: xmin, xmax, ymin, ymax (inflated)
 };
 constexpr int OG_COARSE_SHIFT = 3;
 
@@ -153,6 +154,26 @@ __device__ __forceinline__ bool grid_hits(const Geo& g, const GeoL& gl, double p
                 occ |= g.ogc[(size_t)(cy0 + r) * g.ogc_cols + (cx0 + cc)] != 0;
             }
             if (__any(occ) == 0) return false;
+            // Second stage, same argument one level down: the cells of the axis-aligned box around the ROTATED
+            // hull rectangle (its four corners, +-1 cell).  Passes for a vehicle that runs along an obstacle
+            // without touching it, where the coarse blocks cannot tell.
+            const double ax0 = c * g.og_bb[0], ax1 = c * g.og_bb[1], bx0 = s * g.og_bb[0], bx1 = s * g.og_bb[1];
+            const double ay0 = s * g.og_bb[2], ay1 = s * g.og_bb[3], by0 = c * g.og_bb[2], by1 = c * g.og_bb[3];
+            // world offsets of a body point (u, v): (c u - s v, s u + c v); extremes are attained at corners
+            const double wx_lo = fmin(ax0, ax1) - fmax(ay0, ay1), wx_hi = fmax(ax0, ax1) - fmin(ay0, ay1);
+            const double wy_lo = fmin(bx0, bx1) + fmin(by0, by1), wy_hi = fmax(bx0, bx1) + fmax(by0, by1);
+            const double m = 1e-9 * (1.0 + g.og_reach);
+            const int fx0 = (int)(g.og_cpm * ((px + wx_lo - m) - g.og_ox)) - 1, fx1 = (int)(g.og_cpm * ((px + wx_hi + m) - g.og_ox)) + 1;
+            const int fy0 = (int)(g.og_cpm * ((py + wy_lo - m) - g.og_oy)) - 1, fy1 = (int)(g.og_cpm * ((py + wy_hi + m) - g.og_oy)) + 1;
+            const int fnx = fx1 - fx0 + 1, fcells = fnx * (fy1 - fy0 + 1);
+            if (fcells <= 1024) {            // (inside the map: the reach box is, and this box lies within it)
+                bool focc = false;
+                for (int q = lane; q < fcells; q += 64) {
+                    const int r = q / fnx, cc = q - r * fnx;
+                    focc |= !((double)g.og[(size_t)(fy0 + r) * g.og_cols + (fx0 + cc)] < g.og_thr);
+                }
+                if (__any(focc) == 0) return false;
+            }
         }
     }
     bool hit = false;
