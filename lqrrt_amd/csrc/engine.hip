@@ -134,6 +134,8 @@ struct lqrrt_engine {
     double* d_rec = nullptr;
     double* d_pcost = nullptr;
     int* d_pidx = nullptr;
+    double* d_M = nullptr;              // in-wave cost matrix [W][W] of small waves (see SteerFuse)
+    bool wave_matrix = false;           // this wave runs in matrix mode
     int *d_par_done = nullptr, *d_par_want = nullptr, *d_list = nullptr;
     unsigned char *d_changed = nullptr, *d_stale = nullptr, *d_need = nullptr;
     int* d_summary = nullptr;     // [4]: device-side copy of the listed count (index 0)
@@ -144,6 +146,7 @@ struct lqrrt_engine {
     int seq = 0;                  // sequence number of the last k_decide
     bool wave_complete = false;   // the last speculate covered the whole wave (single-GPU path)
     static constexpr int MAXCH = 1024;
+    static constexpr int MATRIX_MAX_W = 256;
 
     // sample stream
     MT mt_gen, mt_base;
@@ -301,7 +304,7 @@ static void prof_end(lqrrt_engine* e, hipStream_t st, EvPair* ev, int kind, doub
 // kernel launch wrappers
 
 static int tri_chunk() {
-    static const int c = getenv("LQRRT_TRI_CHUNK") ? atoi(getenv("LQRRT_TRI_CHUNK")) : 16;
+    static const int c = getenv("LQRRT_TRI_CHUNK") ? atoi(getenv("LQRRT_TRI_CHUNK")) : 32;
     return c;
 }
 
@@ -319,7 +322,7 @@ static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
 // NN over a node table for W samples at xs (device, [W][n]); writes id/cost and/or records.
 static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int W, const double* Sd,
                      bool tri, int* out_id, double* out_cost, double* rec, hipStream_t st,
-                     bool profile, int* n_chunks_out = nullptr, int wave_lo = -1) {
+                     bool profile, int* n_chunks_out = nullptr, int wave_lo = -1, bool defer_reduce = false) {
     if (W <= 0) return 0;
     int chunk, n_chunks;
     if (tri) { chunk = tri_chunk(); n_chunks = (nv.count + chunk - 1) / chunk; }   // in-wave pass: the reduction is fused into k_decide
@@ -341,7 +344,7 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     }
 #undef NN_LAUNCH
     if (profile) prof_end(e, st, &ev, 0, (double)W * (double)nv.count * (8.0 * e->n + 1.0));
-    if (tri) { HIPCHK(hipGetLastError()); return 0; }
+    if (tri || defer_reduce) { HIPCHK(hipGetLastError()); return 0; }     // deferred: the steer launch reduces (SteerFuse)
 #define RED_LAUNCH(DENSE)                                                                                 \
     DISPATCH(e, hipLaunchKernelGGL((k_nn_reduce<S, DENSE>), dim3(W), dim3(64), 0, st, e->d_pcost, e->d_pidx, W, n_chunks, nv, \
                                    xs, S_use, out_id, out_cost, rec, e->L.R, e->L.off_cost, e->L.off_parent,               \
@@ -355,13 +358,22 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
 }
 
 static int launch_steer(lqrrt_engine* e, const double* xs, const int* list, int lo, int count,
-                        const int* par, hipStream_t st, const int* list_count = nullptr) {
+                        const int* par, hipStream_t st, const int* list_count = nullptr, const SteerFuse* fuse = nullptr) {
     if (count <= 0) return 0;
     const size_t lds = (size_t)e->H * (e->n + e->m) * sizeof(double) + geo_lds_bytes(e);
+    SteerFuse f;
+    memset(&f, 0, sizeof f);
+    if (fuse) f = *fuse;
+    f.Sd = e->d_S;
     EvPair ev;
     prof_begin(e, st, &ev, 1);
-    DISPATCH(e, hipLaunchKernelGGL((k_steer<S>), dim3(count), dim3(64), lds, st, e->P, e->geo, e->res, e->tv,
-                                    e->d_rec, e->L, xs, list, lo, par, list_count));
+    if (e->d_S) {
+        DISPATCH(e, hipLaunchKernelGGL((k_steer<S, true>), dim3(count), dim3(64), lds, st, e->P, e->geo, e->res, e->tv,
+                                        e->d_rec, e->L, xs, list, lo, par, list_count, f));
+    } else {
+        DISPATCH(e, hipLaunchKernelGGL((k_steer<S, false>), dim3(count), dim3(64), lds, st, e->P, e->geo, e->res, e->tv,
+                                        e->d_rec, e->L, xs, list, lo, par, list_count, f));
+    }
     prof_end(e, st, &ev, 1, 0.0);
     HIPCHK(hipGetLastError());
     return 0;
@@ -381,7 +393,7 @@ extern "C" int lqrrt_device_count(void) {
 
 static void free_all(lqrrt_engine* e) {
     void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_og, e->d_ogc, e->d_cell_start, e->d_cell_items, e->d_S, e->tv.state, e->tv.trig, e->tv.K, e->tv.pID, e->tv.elen,
-                    e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost,
+                    e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_M,
                     e->d_pidx, e->d_par_done, e->d_par_want, e->d_list,
                     e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_cand, e->d_flags};
     for (void* p : ptrs)
@@ -575,6 +587,7 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     const size_t pw = (size_t)lqrrt_engine::MAXCH * e->maxW;
     if (!rc) rc = dalloc(&e->d_pcost, pw);
     if (!rc) rc = dalloc(&e->d_pidx, pw);
+    if (!rc) rc = dalloc(&e->d_M, (size_t)lqrrt_engine::MATRIX_MAX_W * lqrrt_engine::MATRIX_MAX_W);
     if (!rc) rc = dalloc(&e->d_par_done, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_par_want, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_list, (size_t)e->maxW);
@@ -1116,12 +1129,25 @@ extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void
     const double* xs = wave_samples(e);
     const int cnt = hi - lo;
     const bool whole = (lo == 0 && hi == W);
+    static const int matrix_max = getenv("LQRRT_MATRIX_MAX_W") ? std::min(atoi(getenv("LQRRT_MATRIX_MAX_W")), (int)lqrrt_engine::MATRIX_MAX_W)
+                                                                : (int)lqrrt_engine::MATRIX_MAX_W;
+    e->wave_matrix = W <= matrix_max;
     if (cnt > 0) {
         // snapshot NN for the slice: records lo..hi-1 get (cost, parent); the reduce also initialises the
         // slice's wave bookkeeping (parent-in-use, changed, stale)
-        TRY(launch_nn(e, tree_view(e, true), xs + (size_t)lo * e->n, cnt, nullptr, false, nullptr, nullptr,
-                      e->d_rec + (size_t)lo * e->L.R, st, true, nullptr, lo));
-        TRY(launch_steer(e, xs, nullptr, lo, cnt, e->d_par_done, st));
+        // snapshot NN for the slice; its reduction is the prologue of the steer launch, which also initialises the
+        // slice's wave bookkeeping (parent-in-use, changed, stale) and, for a small wave, writes each record's row
+        // of the in-wave cost matrix
+        const NodeView nv = tree_view(e, true);
+        int n_chunks = 0;
+        TRY(launch_nn(e, nv, xs + (size_t)lo * e->n, cnt, nullptr, false, nullptr, nullptr,
+                      e->d_rec + (size_t)lo * e->L.R, st, true, &n_chunks, lo, true));
+        SteerFuse f;
+        memset(&f, 0, sizeof f);
+        f.pcost = e->d_pcost; f.pidx = e->d_pidx; f.n_chunks = n_chunks; f.nv = nv;
+        f.changed = e->d_changed; f.stale = e->d_stale; f.par_out = e->d_par_done;
+        f.M = (e->wave_matrix && whole) ? e->d_M : nullptr; f.W = W;
+        TRY(launch_steer(e, xs, nullptr, lo, cnt, e->d_par_done, st, nullptr, &f));
     }
     HIPCHK(hipGetLastError());
     e->wave_complete = whole;
@@ -1147,7 +1173,7 @@ static int pick_wave(const lqrrt_engine* e, int wave_cap) {
 }
 
 static void tune_wave(lqrrt_engine* e, int W, const lqrrt_extend_stats& ws, int wave_cap) {
-    static const double k_cut = getenv("LQRRT_CTL_CUT") ? atof(getenv("LQRRT_CTL_CUT")) : 4.0;
+    static const double k_cut = getenv("LQRRT_CTL_CUT") ? atof(getenv("LQRRT_CTL_CUT")) : 2.0;
     static const double k_min = getenv("LQRRT_CTL_MIN") ? atof(getenv("LQRRT_CTL_MIN")) : 128.0;
     static const int k_hi = getenv("LQRRT_CTL_HI") ? atoi(getenv("LQRRT_CTL_HI")) : 10;
     static const int k_lo = getenv("LQRRT_CTL_LO") ? atoi(getenv("LQRRT_CTL_LO")) : 5;
@@ -1203,35 +1229,46 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
         HIPCHK(hipMemsetAsync(e->d_changed, 0, W, st));
         HIPCHK(hipMemsetAsync(e->d_stale, 0, W, st));
     }
+    // Small waves keep an in-wave cost matrix that the steer launches maintain row by row (SteerFuse), so a repair
+    // round is decide + re-steer; larger waves scan the wave records with k_nn_scan<TRI> every round.
+    const bool mat = e->wave_matrix;
+    if (mat && !e->wave_complete) {
+        if (e->d_S) { DISPATCH(e, hipLaunchKernelGGL((k_wave_rows<S, true>), dim3(W), dim3(64), 0, st, e->d_rec, e->L, xs, e->d_S, e->d_M, W)); }
+        else { DISPATCH(e, hipLaunchKernelGGL((k_wave_rows<S, false>), dim3(W), dim3(64), 0, st, e->d_rec, e->L, xs, nullptr, e->d_M, W)); }
+    }
     e->wave_complete = false;
+    SteerFuse rf;
+    memset(&rf, 0, sizeof rf);
+    rf.M = mat ? e->d_M : nullptr; rf.W = W;
 
     const int guard = 4 * W + 8;
     int rounds = 0;
     while (true) {
-        int n_chunks = 1;
-        if (W > 1) {
-            TRY(launch_nn(e, record_view(e, W), xs, W, nullptr, true, nullptr, nullptr, nullptr, st, false, &n_chunks));
-        } else {
-            HIPCHK(hipMemsetAsync(e->d_pidx, 0xff, sizeof(int), st));        // no in-wave candidate
-            HIPCHK(hipMemsetAsync(e->d_pcost, 0x7f, sizeof(double), st));    // large finite cost
-        }
         // one thread per sample (rounded up to whole wavefronts): a small wave does not pay 16-wavefront barriers
         const int dthreads = std::min(1024, ((W + 63) / 64) * 64);
-        hipLaunchKernelGGL(k_decide, dim3(1), dim3(dthreads), 0, st, e->d_rec, e->L, W, e->d_pcost, e->d_pidx, n_chunks, tri_chunk(),
-                           e->d_par_done, e->d_par_want, e->d_changed, e->d_stale, e->d_need, e->d_list, e->h_summary_dev,
-                           e->h_summary_dev + 4, e->d_summary, ++e->seq);
+        if (mat) {
+            hipLaunchKernelGGL(k_decide, dim3(1), dim3(dthreads), 0, st, e->d_rec, e->L, W, e->d_M, (const int*)nullptr, W, 1,
+                               e->d_par_done, e->d_par_want, e->d_changed, e->d_stale, e->d_need, e->d_list, e->h_summary_dev,
+                               e->h_summary_dev + 4, e->d_summary, ++e->seq);
+        } else {
+            int n_chunks = 1;
+            TRY(launch_nn(e, record_view(e, W), xs, W, nullptr, true, nullptr, nullptr, nullptr, st, false, &n_chunks));
+            hipLaunchKernelGGL(k_decide, dim3(1), dim3(dthreads), 0, st, e->d_rec, e->L, W, e->d_pcost, e->d_pidx, n_chunks, tri_chunk(),
+                               e->d_par_done, e->d_par_want, e->d_changed, e->d_stale, e->d_need, e->d_list, e->h_summary_dev,
+                               e->h_summary_dev + 4, e->d_summary, ++e->seq);
+        }
         HIPCHK(hipGetLastError());
         // The re-steer of whatever k_decide lists is enqueued right behind it, before the host has seen the
         // count (the kernel reads it from device memory), so the GPU never idles on a host round trip; the
         // host catches up on the summary while the steer runs.
         const int pre = std::min(W, 64);
-        TRY(launch_steer(e, xs, e->d_list, 0, pre, e->d_par_done, st, e->d_summary));
+        TRY(launch_steer(e, xs, e->d_list, 0, pre, e->d_par_done, st, e->d_summary, &rf));
         TRY(wait_summary(e, st));
         const int n_list = e->h_summary[0], n_defer = e->h_summary[1];
         if (getenv("LQRRT_TRACE")) fprintf(stderr, "[wave N=%d W=%d] round %d: list=%d defer=%d horizon=%d\n", e->N, W, rounds, n_list, n_defer, e->h_summary[2]);
         if (n_list == 0 && n_defer == 0) break;
         if (n_list == 0) return fail(LQRRT_E_STATE, "exact-mode repair made no progress (deferred=%d)", n_defer);
-        if (n_list > pre) TRY(launch_steer(e, xs, e->d_list, pre, n_list - pre, e->d_par_done, st, e->d_summary));
+        if (n_list > pre) TRY(launch_steer(e, xs, e->d_list, pre, n_list - pre, e->d_par_done, st, e->d_summary, &rf));
         ws.fix_rounds++;
         ws.resteers += n_list;
         if (++rounds > guard) return fail(LQRRT_E_STATE, "exact-mode repair did not converge");

@@ -398,11 +398,25 @@ template <class S> struct is_packed<S, std::enable_if_t<S::PACKED>> : std::true_
 // branch stays a scalar branch.
 __device__ __forceinline__ bool uniform_true(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
 
-template <class S>
+// Optional stages fused into a steer launch (both off for the plain batched operator):
+//  * reduce prologue (speculative launch of a wave): the wavefront first reduces its sample's partial minima of
+//    the tree scan -- what k_nn_reduce does -- so the wave needs no separate reduce launch;
+//  * row epilogue (small waves): after the rollout the wavefront evaluates the cost of ITS new end state for
+//    every later sample of the wave and stores row t of the in-wave cost matrix M[t][u]; k_decide then takes
+//    column minima and the per-round in-wave scan launch disappears.
+struct SteerFuse {
+    const double* pcost; const int* pidx; int n_chunks;    // n_chunks > 0: reduce prologue, partials of local sample blockIdx.x
+    NodeView nv; const double* Sd;
+    unsigned char* changed; unsigned char* stale; int* par_out;   // wave bookkeeping initialised by the prologue
+    double* M; int W;                                        // M != null: row epilogue, leading dimension W
+};
+
+template <class S, bool DENSE>
 __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView tv, double* __restrict__ rec,
                                               RecLayout L, const double* __restrict__ xs,
                                               const int* __restrict__ list, int lo,
-                                              const int* __restrict__ par, const int* __restrict__ list_count) {
+                                              const int* __restrict__ par, const int* __restrict__ list_count,
+                                              SteerFuse f) {
     // list mode with a device-side count: the launch is enqueued before the host knows how many samples
     // k_decide listed, so surplus workgroups simply leave (and a converged round costs one empty launch)
     if (list_count && (int)blockIdx.x + lo >= list_count[0]) return;
@@ -420,13 +434,48 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
     const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
     __syncthreads();
     const int t = list ? list[blockIdx.x + (list_count ? lo : 0)] : lo + (int)blockIdx.x;
-    const int pref = par[t];
     double* my = rec + (size_t)t * L.R;
 
     double x[S::N], K[S::M * S::N], trig[2 * S::NW + 1], xt[S::N], ttrig[2 * S::NW + 1];
 #pragma unroll
     for (int d = 0; d < S::N; ++d) xt[d] = xs[(size_t)t * S::N + d];
     trig_of<S>(xt, ttrig);
+    int pref;
+    if (f.n_chunks > 0) {
+        // nearest node of this sample from the scan's partial minima (see k_nn_reduce for the rules)
+        double b = INFINITY;
+        int bi = -1;
+        const double* pc = f.pcost + (size_t)blockIdx.x * f.n_chunks;
+        const int* pi = f.pidx + (size_t)blockIdx.x * f.n_chunks;
+        for (int c = lane; c < f.n_chunks; c += 64) {
+            const double v = pc[c];
+            const int vi = pi[c];
+            if (vi >= 0 && (bi < 0 || v < b)) { b = v; bi = vi; }
+        }
+        lexmin_wave(b, bi);
+        const bool fallback = bi < 0 && f.nv.ignore != nullptr;
+        if (fallback) {
+            for (int i = lane; i < f.nv.count; i += 64) {
+                double xi[S::N], ti[2 * S::NW + 1], e[S::N];
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) xi[d] = f.nv.x[(long long)i * f.nv.sn + d * f.nv.sd];
+#pragma unroll
+                for (int j = 0; j < 2 * S::NW; ++j) ti[j] = f.nv.trig[(long long)i * f.nv.tn + j * f.nv.td];
+                erf_cached<S>(xt, ttrig, xi, ti, e);
+                const double c = quad_cost<S, DENSE>(e, f.Sd);
+                if (bi < 0 || c < b) { b = c; bi = i; }
+            }
+            lexmin_wave(b, bi);
+        }
+        if (lane == 0) {
+            my[L.off_cost] = fallback ? INFINITY : b;
+            my[L.off_parent] = (double)bi;
+            f.par_out[t] = bi; f.changed[t] = 0; f.stale[t] = 0;
+        }
+        pref = bi;
+    } else {
+        pref = par[t];
+    }
     if (pref >= 0) {
 #pragma unroll
         for (int d = 0; d < S::N; ++d) x[d] = tv.state[(size_t)d * tv.cap + pref];
@@ -523,6 +572,50 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         // flags: bit 0 = end state in the goal region, bit 1 = stopped by error growth,
         //        bits 8.. = number of completed steps (for the horizon_iters replay on the host)
         my[L.off_flags] = (double)(flags | (grew ? 2 : 0) | (steps << 8));
+    }
+    if (f.M) {
+        // row t of the in-wave cost matrix: cost of this record's end state for every later sample u (the
+        // arithmetic of k_nn_scan<TRI>: erf about the sample, quad_cost); +inf when the record adds no node
+        for (int u = t + 1 + lane; u < f.W; u += 64) {
+            double xu[S::N], tu[2 * S::NW + 1], e[S::N];
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) xu[d] = xs[(size_t)u * S::N + d];
+            trig_of<S>(xu, tu);
+            double c = INFINITY;
+            if (cnt > 0) {
+                erf_cached<S>(xu, tu, x, trig, e);
+                c = quad_cost<S, DENSE>(e, f.Sd);
+            }
+            f.M[(size_t)t * f.W + u] = c;
+        }
+    }
+}
+
+// Rows of the in-wave cost matrix straight from the records (sharded waves: records of other ranks arrive by
+// all-gather without their rows).  One wavefront per record.
+template <class S, bool DENSE>
+__global__ __launch_bounds__(64) void k_wave_rows(const double* __restrict__ rec, RecLayout L, const double* __restrict__ xs,
+                                                  const double* __restrict__ Sd, double* __restrict__ M, int W) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= W) return;
+    const double* my = rec + (size_t)t * L.R;
+    const bool valid = my[L.off_len] > 0.0;
+    double x[S::N], trig[2 * S::NW + 1];
+#pragma unroll
+    for (int d = 0; d < S::N; ++d) x[d] = my[L.off_xend + d];
+#pragma unroll
+    for (int j = 0; j < 2 * S::NW; ++j) trig[j] = my[L.off_trig + j];
+    for (int u = t + 1 + lane; u < W; u += 64) {
+        double xu[S::N], tu[2 * S::NW + 1], e[S::N];
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) xu[d] = xs[(size_t)u * S::N + d];
+        trig_of<S>(xu, tu);
+        double c = INFINITY;
+        if (valid) {
+            erf_cached<S>(xu, tu, x, trig, e);
+            c = quad_cost<S, DENSE>(e, Sd);
+        }
+        M[(size_t)t * W + u] = c;
     }
 }
 
@@ -631,11 +724,20 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ rec,
         if (t <= hz) {
             double wc = INFINITY;
             int s = -1;
-            const int nc = min(n_chunks, t / chunk + 1);     // chunks that hold samples < t
+            if (pidx) {
+                const int nc = min(n_chunks, t / chunk + 1);     // chunks that hold samples < t
 #pragma unroll 4
-            for (int c = 0; c < nc; ++c) {                   // ascending chunks + strict '<' = lowest id on ties
-                const double v = pcost[(size_t)c * W + t];
-                if (v < wc) { wc = v; s = pidx[(size_t)c * W + t]; }
+                for (int c = 0; c < nc; ++c) {                   // ascending chunks + strict '<' = lowest id on ties
+                    const double v = pcost[(size_t)c * W + t];
+                    if (v < wc) { wc = v; s = pidx[(size_t)c * W + t]; }
+                }
+            } else {
+                // matrix mode: pcost = M[s][t] written by the steer epilogues (+inf where s adds no node)
+#pragma unroll 8
+                for (int c = 0; c < t; ++c) {
+                    const double v = pcost[(size_t)c * W + t];
+                    if (v < wc) { wc = v; s = c; }
+                }
             }
             const double csnap = rec[(size_t)t * L.R + L.off_cost];
             const int psnap = (int)rec[(size_t)t * L.R + L.off_parent];
