@@ -16,7 +16,7 @@ for a, b, k in ev:
     busy[k] += b - a; cnt[k] += 1
     if prev is not None: gap[k] += max(0, a - prev)
     prev = b
-waves = max(1, cnt.get('k_nn_reduce', 1))
+waves = max(1, cnt.get('k_nn_scan', 1))        # one tree scan per wave
 print("window %.1f ms, %d dispatches, %d waves, %.1f us/wave" % (tot / 1e6, len(ev), waves, tot / 1e3 / waves))
 for k, v in busy.most_common():
     print("%-18s n/wave %5.2f  busy %5.1f%%  avg %6.1f us  gap-before avg %5.1f us (%4.1f%%)" % (
