@@ -153,6 +153,17 @@ int lqrrt_engine_destroy(lqrrt_engine* e);
  * files + Constraints.set_feasibility_function (lqrrt_node.py:65, 260-263, 719-745). */
 int lqrrt_engine_set_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys, void* stream);
 
+/* Wave semantics.  EXACT (default): the result is the tree the reference's sequential loop
+ * builds -- samples are speculated against the wave-start snapshot, validated against the nodes accepted earlier
+ * in the wave and re-steered on conflict; the wave size is chosen adaptively.  SYNCHRONOUS: all samples of a
+ * wave see the wave-start snapshot (nodes and ignore set), accepted edges are committed in sample order and
+ * the goal bookkeeping of the wave's hits follows in that order; waves have exactly the size asked for
+ * (lqrrt_engine_extend's `wave`), size 1 is the reference's loop.  Its parity target is the restatement of
+ * this rule in oracle/lqrrt_oracle.c (orc_extend_sync). */
+#define LQRRT_WAVE_EXACT        0
+#define LQRRT_WAVE_SYNCHRONOUS  1
+int lqrrt_engine_set_wave_mode(lqrrt_engine* e, int mode);
+
 /* Changing horizon_iters re-lays out the edge pools: call lqrrt_tree_reset afterwards. */
 int lqrrt_engine_set_resolution(lqrrt_engine* e, const lqrrt_resolution* r);
 

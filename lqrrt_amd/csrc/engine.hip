@@ -171,6 +171,7 @@ struct lqrrt_engine {
 
     // adaptive wave size (exactness does not depend on W, only speed does)
     double ctl_w = 0.0;
+    bool sync_mode = false;             // synchronous wave semantics (LQRRT_WAVE_SYNCHRONOUS) instead of exact
 
     // counters
     lqrrt_extend_stats tot{};
@@ -715,6 +716,13 @@ extern "C" int lqrrt_engine_set_geometry(lqrrt_engine* e, const lqrrt_system_des
     return 0;
 }
 
+extern "C" int lqrrt_engine_set_wave_mode(lqrrt_engine* e, int mode) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    if (mode != LQRRT_WAVE_EXACT && mode != LQRRT_WAVE_SYNCHRONOUS) return fail(LQRRT_E_ARG, "unknown wave mode %d", mode);
+    e->sync_mode = mode == LQRRT_WAVE_SYNCHRONOUS;
+    return 0;
+}
+
 extern "C" int lqrrt_engine_set_mt19937(lqrrt_engine* e, const uint32_t* key624, int pos) {
     if (!e || !key624) return fail(LQRRT_E_ARG, "null argument");
     if (pos < 0 || pos > 624) return fail(LQRRT_E_ARG, "bad MT19937 position");
@@ -1131,7 +1139,7 @@ extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void
     const bool whole = (lo == 0 && hi == W);
     static const int matrix_max = getenv("LQRRT_MATRIX_MAX_W") ? std::min(atoi(getenv("LQRRT_MATRIX_MAX_W")), (int)lqrrt_engine::MATRIX_MAX_W)
                                                                 : (int)lqrrt_engine::MATRIX_MAX_W;
-    e->wave_matrix = W <= matrix_max;
+    e->wave_matrix = W <= matrix_max && !e->sync_mode;
     if (cnt > 0) {
         // snapshot NN for the slice: records lo..hi-1 get (cost, parent); the reduce also initialises the
         // slice's wave bookkeeping (parent-in-use, changed, stale)
@@ -1229,6 +1237,14 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
         HIPCHK(hipMemsetAsync(e->d_changed, 0, W, st));
         HIPCHK(hipMemsetAsync(e->d_stale, 0, W, st));
     }
+    if (e->sync_mode) {
+        // every sample stands as speculated against the wave-start snapshot: publish the summary and commit
+        e->wave_complete = false;
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(std::min(1024, ((W + 63) / 64) * 64)), 0, st, e->d_rec, e->L, W, e->d_par_done,
+                           e->h_summary_dev, e->h_summary_dev + 4, ++e->seq);
+        HIPCHK(hipGetLastError());
+        TRY(wait_summary(e, st));
+    }
     // Small waves keep an in-wave cost matrix that the steer launches maintain row by row (SteerFuse), so a repair
     // round is decide + re-steer; larger waves scan the wave records with k_nn_scan<TRI> every round.
     const bool mat = e->wave_matrix;
@@ -1243,7 +1259,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
 
     const int guard = 4 * W + 8;
     int rounds = 0;
-    while (true) {
+    while (!e->sync_mode) {
         // one thread per sample (rounded up to whole wavefronts): a small wave does not pay 16-wavefront barriers
         const int dthreads = std::min(1024, ((W + 63) / 64) * 64);
         if (mat) {
@@ -1280,6 +1296,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     const int* par = e->h_summary + 4 + 2 * W;
     int C = 0, acc = 0;
     bool hit = false;
+    std::vector<int> sync_hits;
     const int64_t room = node_limit + 1 - (int64_t)e->N;   // nodes that may still be added (size > max_nodes stops)
     for (int t = 0; t < W; ++t) {
         if ((int64_t)C >= max_commit) break;
@@ -1288,7 +1305,11 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
         C = t + 1;
         if (len[t] > 0) {
             ++acc;
-            if (flg[t] & 1) { hit = true; break; }
+            if (flg[t] & 1) {
+                hit = true;
+                if (!e->sync_mode) break;        // exact mode: the ignore set changes here, the wave ends
+                sync_hits.push_back(acc - 1);   // synchronous mode: remember the node (offset from base), go on
+            }
         }
     }
     for (int t = C; t < W; ++t) e->h_rank[t] = acc;
@@ -1324,17 +1345,20 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     }
     e->N += acc;
     if (hit) {
-        const int id = e->N - 1;                     // the goal hit is the last committed node
-        int64_t steps = 0;
-        for (int v = id; v != -1; v = e->h_pid[v]) {
-            steps += e->h_elen[v];
-            // ignores = union of succeeded paths, planner.py:270 (only consulted when pruning, :239)
-            if (pruning) e->h_ign[v >> 6] |= (1ull << (v & 63));
+        if (!e->sync_mode) sync_hits.assign(1, acc - 1);      // exact mode: the goal hit is the last committed node
+        for (int off : sync_hits) {                          // in commit order
+            const int id = base + off;
+            int64_t steps = 0;
+            for (int v = id; v != -1; v = e->h_pid[v]) {
+                steps += e->h_elen[v];
+                // ignores = union of succeeded paths, planner.py:270 (only consulted when pruning, :239)
+                if (pruning) e->h_ign[v >> 6] |= (1ull << (v & 63));
+            }
+            e->goal_hits++;
+            ws.goal_hits++;
+            if (e->best_end < 0 || steps < e->best_steps) { e->best_end = id; e->best_steps = steps; }  // planner.py:276 (T < self.T)
         }
         e->ign_dirty = pruning != 0;
-        e->goal_hits++;
-        ws.goal_hits = 1;
-        if (e->best_end < 0 || steps < e->best_steps) { e->best_end = id; e->best_steps = steps; }  // planner.py:276 (T < self.T)
     }
     if (getenv("LQRRT_TRACE")) fprintf(stderr, "[wave N=%d W=%d] commit C=%d acc=%d hit=%d rounds=%d\n", base, W, C, acc, (int)hit, rounds);
     // advance the stream
@@ -1346,7 +1370,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     e->tot.attempts += C; e->tot.accepted += acc; e->tot.waves += 1; e->tot.fix_rounds += ws.fix_rounds;
     e->tot.resteers += ws.resteers; e->tot.goal_hits += ws.goal_hits; e->tot.tree_size = e->N;
     e->tot.candidates = e->committed_row;
-    tune_wave(e, W, ws, e->maxW);
+    if (!e->sync_mode) tune_wave(e, W, ws, e->maxW);
     if (out) *out = ws;
     return 0;
 }
@@ -1363,7 +1387,7 @@ extern "C" int lqrrt_engine_extend(lqrrt_engine* e, int wave, int64_t max_attemp
         if (max_attempts >= 0 && acc.attempts >= max_attempts) { acc.stop_reason = LQRRT_STOP_ATTEMPTS; break; }
         if (node_limit >= 0 && (int64_t)e->N > node_limit) { acc.stop_reason = LQRRT_STOP_NODES; break; }
         if (until_size > 0 && e->N >= until_size) { acc.stop_reason = LQRRT_STOP_TARGET; break; }
-        int W = pick_wave(e, wave);
+        int W = e->sync_mode ? std::min(wave, e->maxW) : pick_wave(e, wave);     // synchronous waves have the size asked for
         int64_t cap_attempts = max_attempts >= 0 ? max_attempts - acc.attempts : (int64_t)W;
         if ((int64_t)W > cap_attempts) W = (int)cap_attempts;
         if (e->explicit_samples) {

@@ -790,6 +790,25 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ rec,
     }
 }
 
+// Synchronous wave mode: nothing to validate, the host only needs the per-sample summary (same layout and the same
+// publication protocol as k_decide's converged round).
+__global__ __launch_bounds__(1024) void k_publish(const double* __restrict__ rec, RecLayout L, int W, const int* __restrict__ par_done,
+                                                  int* __restrict__ ctrl, int* __restrict__ summary, int seq) {
+    for (int t = threadIdx.x; t < W; t += blockDim.x) {
+        summary[t] = (int)rec[(size_t)t * L.R + L.off_len];
+        summary[W + t] = (int)rec[(size_t)t * L.R + L.off_flags];
+        summary[2 * W + t] = par_done[t];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ctrl[0] = 0; ctrl[1] = 0; ctrl[2] = W - 1;
+        __threadfence_system();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&ctrl[3], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // Append the first C samples' accepted records to the tree (tree.py:77-96).  rank[t] = number of
 // accepted samples before t (computed on the host from the summary, uploaded).  One wavefront
 // per sample.  In-wave parents resolve to base + rank[parent sample].

@@ -38,6 +38,15 @@ class Engine(object):
             nat.check(nat.lib().lqrrt_engine_set_dense_S(self.h, nat.ptr(S)))
         self.horizon_iters = None
 
+    def set_wave_mode(self, mode):
+        """'exact' (default: the reference's sequential result) or 'synchronous' (all samples of a wave see the
+        wave-start snapshot; fixed wave size; parity target oracle/lqrrt_oracle.c orc_extend_sync)."""
+        modes = {"exact": 0, "synchronous": 1}
+        if mode not in modes:
+            raise ValueError("wave mode must be 'exact' or 'synchronous'")
+        nat.check(nat.lib().lqrrt_engine_set_wave_mode(self.h, modes[mode]))
+        self.wave_mode = mode
+
     def sync_geometry(self):
         """Re-uploads parameters, hull points, obstacles and occupancy grid if the system object changed since
         this engine last saw it (system.revision; e.g. set_occupancy_grid between two plans)."""

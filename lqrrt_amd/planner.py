@@ -11,12 +11,15 @@ get_state, get_effort), ValueError conventions and return values.
 
 What is different: the per-iteration loop body (planner.py:233-290: sample, cost-to-go
 nearest neighbour, LQR-policy steer with feasibility sweep, tree append, goal test) is
-executed by the HIP engine in *waves* of up to `wave_size` samples.  In exact mode (the only
-mode) a wave's result is identical to running its samples one after another: every sample is
+executed by the HIP engine in *waves* of up to `wave_size` samples.  In exact mode (the
+default) a wave's result is identical to running its samples one after another: every sample is
 first evaluated against the tree as it stood at the start of the wave, then the engine
 re-checks each sample against the nodes accepted earlier in the same wave and re-steers the
 few whose true parent was born inside the wave, iterating to the fix-point
-(csrc/engine.hip).  dynamics / lqr / erf / is_feasible must therefore be the plugin handles
+(csrc/engine.hip).  wave_mode='synchronous' drops that validation: all samples of a wave (exactly
+`wave_size` of them) see the tree as of the start of the wave -- not the reference's tree any more, but
+the one oracle/lqrrt_oracle.c's orc_extend_sync defines, and several times faster.
+dynamics / lqr / erf / is_feasible must be the plugin handles
 of a native system (lqrrt_amd.systems); arbitrary Python callables raise ValueError.
 """
 from __future__ import division
@@ -57,6 +60,8 @@ class Planner:
 
     wave_size: (new, optional) upper bound on the samples evaluated per wave.
 
+    wave_mode: (new, optional) 'exact' (default, the reference's sequential result) or 'synchronous'.
+
     device: (new, optional) HIP device ordinal.
 
     """
@@ -66,10 +71,13 @@ class Planner:
                  error_tol=0.05, erf=np.subtract,
                  min_time=0.5, max_time=1, max_nodes=1E5,
                  goal0=None, sys_time=time.time, printing=True,
-                 wave_size=1024, device=0):
+                 wave_size=1024, device=0, wave_mode='exact'):
 
         self.device = device
         self.wave_size = int(wave_size)
+        if wave_mode not in ('exact', 'synchronous'):
+            raise ValueError("wave_mode must be 'exact' or 'synchronous'")
+        self.wave_mode = wave_mode
         self._engine = None
         self._engine_key = None
 
@@ -97,6 +105,7 @@ class Planner:
             self._engine = Engine(self.system, capacity=capacity, max_wave=self.wave_size, device=self.device)
             self._engine_key = key
         self._engine.sync_geometry()        # the world may have changed since the last plan (new map, new obstacles)
+        self._engine.set_wave_mode(self.wave_mode)
         return self._engine
 
     def update_plan(self, x0, sample_space, goal_bias=0,

@@ -26,6 +26,7 @@ def lib():
         for name in ("orc_iterations", "orc_candidates", "orc_hits", "orc_best_steps"):
             getattr(L, name).restype = C.c_longlong
         L.orc_extend.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p]
+        L.orc_extend_sync.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p]
         L.orc_enable_trace.argtypes = [C.c_void_p, C.c_longlong]
         L.orc_get_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
         L.orc_set_resolution.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int] + [C.c_void_p] * 4
@@ -108,6 +109,11 @@ class COracle(object):
     def extend(self, max_iters=-1, max_nodes=-1, pruning=True, stop_on_goal=False):
         return lib().orc_extend(self.h, int(max_iters), int(max_nodes), 1 if pruning else 0, 1 if stop_on_goal else 0,
                                 _p(self.S) if self.S is not None else None)
+
+    def extend_sync(self, wave, max_iters=-1, max_nodes=-1, pruning=True, stop_on_goal=False):
+        """Synchronous wave mode (every sample of a wave searches the wave-start snapshot); wave=1 == extend."""
+        return lib().orc_extend_sync(self.h, int(wave), int(max_iters), int(max_nodes), 1 if pruning else 0,
+                                     1 if stop_on_goal else 0, _p(self.S) if self.S is not None else None)
 
     @property
     def size(self):

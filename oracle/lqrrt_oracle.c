@@ -441,13 +441,18 @@ static void sample(orc* o, double* x) {
 }
 
 /* nearest by cost-to-go about the sample, planner.py:239-247 + 340-350 (identity or dense S) */
+static int nearest_upto(const orc* o, const double* xs, const double* Sd, int pruning, int count);
 static int nearest(const orc* o, const double* xs, const double* Sd, int pruning) {
+    return nearest_upto(o, xs, Sd, pruning, o->N);
+}
+/* nearest among the first `count` nodes (the synchronous wave mode searches the wave-start snapshot) */
+static int nearest_upto(const orc* o, const double* xs, const double* Sd, int pruning, int count) {
     const int n = o->n;
     double gt[4], e[MAXN], prod[MAXN];
     trig_of(o, xs, gt);
     double best = INFINITY, best_all = INFINITY;
     int bi = -1, bai = -1;
-    for (int i = 0; i < o->N; ++i) {
+    for (int i = 0; i < count; ++i) {
         erf_cached(o, xs, gt, o->state + (size_t)i * n, o->trig + (size_t)i * 4, e);
         if (!Sd) for (int k = 0; k < n; ++k) prod[k] = e[k] * e[k];
         else for (int k = 0; k < n; ++k) {
@@ -558,6 +563,65 @@ int orc_extend(orc* o, long long max_iters, long long max_nodes, int pruning, in
         }
     }
     free(ex); free(eu);
+    return reason;
+}
+
+/*
+ * Synchronous wave mode (build-only semantics): the attempts are taken `wave` at a time; every
+ * sample of a wave searches the tree AS IT WAS WHEN THE WAVE STARTED (nodes and ignore set), the accepted
+ * edges are then committed in sample order and the goal bookkeeping of the wave's hits (planner.py:260-283) is
+ * applied in that order after the wave.  wave = 1 is the reference's loop.  A wave is shortened by max_iters
+ * and stops adding nodes once size > max_nodes; stop_on_goal ends the run after the wave that hit the goal.
+ */
+int orc_extend_sync(orc* o, int wave, long long max_iters, long long max_nodes, int pruning, int stop_on_goal, const double* Sd) {
+    const int n = o->n, m = o->m, H = o->H;
+    double xs[MAXN];
+    double* ex = (double*)malloc(sizeof(double) * (size_t)(H + 1) * n);
+    double* eu = (double*)malloc(sizeof(double) * (size_t)(H + 1) * m);
+    int* hits = (int*)malloc(sizeof(int) * (size_t)(wave > 0 ? wave : 1));
+    long long done = 0;
+    int reason = 1;
+    for (;;) {
+        if (max_iters >= 0 && done >= max_iters) { reason = 1; break; }
+        if (max_nodes >= 0 && o->N > max_nodes) { reason = 2; break; }
+        int W = wave;
+        if (max_iters >= 0 && (long long)W > max_iters - done) W = (int)(max_iters - done);
+        if (o->N + W + 1 >= o->cap) { reason = 2; break; }
+        const int N0 = o->N;
+        int n_hits = 0;
+        for (int k = 0; k < W; ++k) {
+            if (max_nodes >= 0 && o->N > max_nodes) break;        /* the wave is cut where the node limit is passed */
+            sample(o, xs);
+            const int near = nearest_upto(o, xs, Sd, pruning, N0);
+            const int len = steer(o, near, xs, ex, eu);
+            if (o->trace_near && o->iterations < o->trace_cap) { o->trace_near[o->iterations] = near; o->trace_len[o->iterations] = len; }
+            o->iterations++;
+            ++done;
+            if (len > 0) {
+                const int id = o->N;
+                const double* xe = ex + (size_t)(len - 1) * n;
+                memcpy(o->state + (size_t)id * n, xe, sizeof(double) * n);
+                trig_of(o, xe, o->trig + (size_t)id * 4);
+                gain(o, xe, o->trig + (size_t)id * 4, eu + (size_t)(len - 1) * m, o->K + (size_t)id * m * n);
+                o->pid[id] = near; o->elen[id] = len;
+                memcpy(o->xedge + (size_t)id * H * n, ex, sizeof(double) * len * n);
+                memcpy(o->uedge + (size_t)id * H * m, eu, sizeof(double) * len * m);
+                o->N++;
+                int in = 1;
+                for (int d = 0; d < n; ++d) in = in && (o->glo[d] < xe[d]) && (xe[d] < o->ghi[d]);
+                if (in) hits[n_hits++] = id;
+            }
+        }
+        for (int h = 0; h < n_hits; ++h) {
+            const int id = hits[h];
+            long long steps = 0;
+            for (int v = id; v != -1; v = o->pid[v]) { steps += o->elen[v]; if (pruning) o->ign[v] = 1; }
+            o->hits++;
+            if (o->best_end < 0 || steps < o->best_steps) { o->best_end = id; o->best_steps = steps; }
+        }
+        if (n_hits && stop_on_goal) { reason = 4; break; }
+    }
+    free(ex); free(eu); free(hits);
     return reason;
 }
 

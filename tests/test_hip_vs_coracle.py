@@ -138,3 +138,34 @@ def test_bit_exact_other_seeds_and_modes():
     o = coracle.make(s, 5000 + 512 + 8, seed=2)
     assert o.extend(max_nodes=5000, stop_on_goal=True) == 4
     _compare(eng, stats, o)
+
+
+@pytest.mark.parametrize("name,nodes,wave", [("boat_advanced", 1500, 256), ("boat_advanced", 600, 1), ("car", 1200, 1024),
+                                             ("boat_novice", 500, 64), ("pendulum", 300, 100)])
+def test_synchronous_mode_bit_exact_vs_its_oracle(name, nodes, wave):
+    """SURVEY 8a row 1w, synchronous wave mode: all samples of a wave see the wave-start snapshot, commit in sample
+    order; parity target = orc_extend_sync (oracle/lqrrt_oracle.c).  Wave size 1 is the reference's loop."""
+    import coracle
+    import lqrrt_amd
+    from lqrrt_amd.engine import Engine
+    s = lqrrt_amd.systems.SYSTEMS[name](0)
+    kw = s.plan_kwargs
+    eng = Engine(s, capacity=nodes + 2 * wave + 8, max_wave=wave)
+    eng.set_resolution(kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer))
+    space = np.array(s.sample_space, dtype=np.float64)
+    eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), np.array(s.goal_bias, dtype=np.float64), 10)
+    st = np.random.RandomState(1).get_state()
+    eng.set_mt19937(st[1], st[2])
+    eng.tree_reset(s.x0)
+    eng.set_wave_mode("synchronous")
+    stats = eng.extend(wave, max_attempts=20 * nodes, node_limit=nodes)
+    o = coracle.make(s, nodes + 2 * wave + 8, seed=1)
+    o.extend_sync(wave, max_iters=20 * nodes, max_nodes=nodes)
+    _compare(eng, stats, o)
+    if wave == 1:                                   # degenerates to the sequential algorithm
+        o2 = coracle.make(s, nodes + 2 * wave + 8, seed=1)
+        o2.extend(max_iters=20 * nodes, max_nodes=nodes)
+        np.testing.assert_array_equal(o.parents(), o2.parents())
+        np.testing.assert_array_equal(o.states(), o2.states())
+    with pytest.raises(ValueError):
+        eng.set_wave_mode("relaxed")

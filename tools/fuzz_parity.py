@@ -39,6 +39,7 @@ def draw_case(rng, rng2, names=None):
     c["world"] = int(rng2.choice([1, 1, 1, 2, 3, 8]))      # >1: sample-sharded waves, ranks emulated on one GPU
     if c["world"] > 1:
         c["stop_goal"] = False
+    c["sync"] = bool(rng2.rand() < 0.25)                 # synchronous wave mode vs orc_extend_sync
     c["ogrid"] = False
     if name in ("boat_advanced", "boat_intermediate", "ros_boat") and rng2.rand() < 0.35:
         # a synthetic occupancy map over the sample space (lqrrt_node.py:792-860 feasibility model)
@@ -80,6 +81,8 @@ def run_case(c, verbose=False):
         st = np.random.RandomState(seed).get_state()
         eng.set_mt19937(st[1], st[2])
         eng.tree_reset(s.x0)
+        if c.get("sync"):
+            eng.set_wave_mode("synchronous")
         return eng
 
     world = c.get("world", 1)
@@ -94,7 +97,7 @@ def run_case(c, verbose=False):
         recs = [records_tensor(e) for e in ranks]
         attempts = 0
         while ranks[0].size <= nodes and attempts < budget:
-            W = ranks[0].wave_suggest(wave)
+            W = min(wave, budget - attempts) if c.get("sync") else ranks[0].wave_suggest(wave)
             bounds = [shard_bounds(W, r, world) for r in range(world)]
             for r, e in enumerate(ranks):
                 e.wave_speculate(W, bounds[r][1], bounds[r][2])
@@ -110,7 +113,10 @@ def run_case(c, verbose=False):
         eng, others = ranks[0], ranks[1:]
         stats = eng.counters()
     o = coracle.make(s, nodes + wave + 8, seed=seed, tries=tries, horizon=c["horizon"])
-    o.extend(max_iters=budget, max_nodes=nodes, pruning=c["pruning"], stop_on_goal=c["stop_goal"])
+    if c.get("sync"):
+        o.extend_sync(wave, max_iters=budget, max_nodes=nodes, pruning=c["pruning"], stop_on_goal=c["stop_goal"])
+    else:
+        o.extend(max_iters=budget, max_nodes=nodes, pruning=c["pruning"], stop_on_goal=c["stop_goal"])
     ok = (eng.size == o.size and stats.attempts == o.iterations and stats.candidates == o.candidates
           and np.array_equal(eng.parents(), o.parents()) and np.array_equal(eng.states(), o.states())
           and np.array_equal(eng.edge_lengths(), o.edge_lengths()) and np.array_equal(eng.ignored(), o.ignored())
@@ -143,7 +149,7 @@ def run_case(c, verbose=False):
 
 
 def describe(c):
-    return " ".join("%s=%s" % (k, c[k]) for k in ("name", "nodes", "wave", "seed", "tries", "pruning", "stop_goal", "adaptive", "world", "ogrid")) \
+    return " ".join("%s=%s" % (k, c[k]) for k in ("name", "nodes", "wave", "seed", "tries", "pruning", "stop_goal", "adaptive", "world", "ogrid", "sync")) \
         + (" behavior=%s" % c["system"].behavior if hasattr(c["system"], "behavior") else "")
 
 
