@@ -1280,8 +1280,9 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
         const int pre = std::min(W, 64);
         TRY(launch_steer(e, xs, e->d_list, 0, pre, e->d_par_done, st, e->d_summary, &rf));
         TRY(wait_summary(e, st));
-        const int n_list = e->h_summary[0], n_defer = e->h_summary[1];
-        if (getenv("LQRRT_TRACE")) fprintf(stderr, "[wave N=%d W=%d] round %d: list=%d defer=%d horizon=%d\n", e->N, W, rounds, n_list, n_defer, e->h_summary[2]);
+        const unsigned counts = (unsigned)__atomic_load_n(&e->h_summary[2], __ATOMIC_RELAXED);   // same 64-bit store as the sequence word
+        const int n_list = (int)(counts >> 16), n_defer = (int)(counts & 0xffffu);
+        if (getenv("LQRRT_TRACE")) fprintf(stderr, "[wave N=%d W=%d] round %d: list=%d defer=%d\n", e->N, W, rounds, n_list, n_defer);
         if (n_list == 0 && n_defer == 0) break;
         if (n_list == 0) return fail(LQRRT_E_STATE, "exact-mode repair made no progress (deferred=%d)", n_defer);
         if (n_list > pre) TRY(launch_steer(e, xs, e->d_list, pre, n_list - pre, e->d_par_done, st, e->d_summary, &rf));

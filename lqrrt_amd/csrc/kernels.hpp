@@ -699,7 +699,7 @@ __global__ void k_tree_root(Params P, TreeView tv, const double* __restrict__ x0
 //   redo when want differs from the parent the record was computed with, when that in-wave parent
 //   was itself recomputed last round, or when a redo was deferred.  A redo whose in-wave parent is
 //   also redone this round is deferred (its start state is about to change).
-// ctrl[0]=listed, ctrl[1]=deferred, ctrl[2]=L, ctrl[3]=sequence number (written last);
+// ctrl[0]=L (converged round only), ctrl[2]=listed<<16|deferred and ctrl[3]=sequence number (ONE 64-bit store);
 // summary[0..3W) = len, flags, parent per sample.
 __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ rec, RecLayout L, int W,
                                                  const double* __restrict__ pcost, const int* __restrict__ pidx, int n_chunks, int chunk,
@@ -776,17 +776,26 @@ __global__ __launch_bounds__(1024) void k_decide(const double* __restrict__ rec,
             summary[2 * W + t] = par_done[t];
         }
     }
-    // ctrl/summary live in pinned host memory: publish them with ONE system-scope release so that the
-    // host, which spins on ctrl[3] == seq, never needs a copy or a stream synchronisation.  Every wave first
-    // drains its own stores, the barrier orders them before lane 0, whose release then covers them all.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // ctrl/summary live in pinned host memory; the host spins on ctrl[3] == seq and never needs a copy or a
+    // stream synchronisation.  The round's counts travel WITH the sequence number in one aligned 64-bit store
+    // (low word: listed << 16 | deferred, high word: seq), so an unconverged round needs no fence at all -- a
+    // system-scope release writes back the whole L2.  Only the converged round, whose per-sample summary the
+    // host is about to read, orders that summary before the word: every wave drains its own stores, the barrier
+    // orders them before lane 0, whose release then covers them all.
+    const bool converged = (n_list == 0 && n_defer == 0);
+    if (converged) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         dev_count[0] = n_list;                       // read by the re-steer launch that follows
-        ctrl[0] = n_list; ctrl[1] = n_defer; ctrl[2] = hz;
-        __threadfence_system();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&ctrl[3], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (converged) {
+            ctrl[0] = hz;
+            __threadfence_system();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const unsigned long long word = ((unsigned long long)(unsigned)seq << 32) | (unsigned)((n_list << 16) | n_defer);
+        __hip_atomic_store((unsigned long long*)(ctrl + 2), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -802,10 +811,11 @@ __global__ __launch_bounds__(1024) void k_publish(const double* __restrict__ rec
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        ctrl[0] = 0; ctrl[1] = 0; ctrl[2] = W - 1;
+        ctrl[0] = W - 1;
         __threadfence_system();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&ctrl[3], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long word = (unsigned long long)(unsigned)seq << 32;       // listed = deferred = 0
+        __hip_atomic_store((unsigned long long*)(ctrl + 2), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
