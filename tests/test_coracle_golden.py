@@ -89,3 +89,34 @@ def test_coracle_matches_numpy_oracle_beyond_fixtures():
         assert o.iterations == ref.iterations
         np.testing.assert_allclose(o.states(), ref.tree.state, rtol=0, atol=1e-9)
         np.testing.assert_array_equal(o.ignored(), ref._ignored)
+
+
+def test_synchronous_wave_oracle_properties():
+    """orc_extend_sync: wave size 1 IS the sequential algorithm; larger waves are deterministic,
+    consume the same sample stream, and no sample of a wave takes a node born in that wave as its parent."""
+    s = lqrrt_amd.systems.SYSTEMS["boat_intermediate"](0)
+    a = coracle.make(s, 400, seed=4)
+    a.extend(max_iters=3000, max_nodes=300)
+    b = coracle.make(s, 400, seed=4)
+    b.extend_sync(1, max_iters=3000, max_nodes=300)
+    np.testing.assert_array_equal(a.parents(), b.parents())
+    np.testing.assert_array_equal(a.states(), b.states())
+    assert a.iterations == b.iterations and a.candidates == b.candidates
+    wave = 64
+    c = coracle.make(s, 3000, seed=4)
+    c.enable_trace(4000)
+    c.extend_sync(wave, max_iters=2048, max_nodes=10 ** 6)
+    d = coracle.make(s, 3000, seed=4)
+    d.extend_sync(wave, max_iters=2048, max_nodes=10 ** 6)
+    np.testing.assert_array_equal(c.parents(), d.parents())
+    np.testing.assert_array_equal(c.states(), d.states())
+    assert c.iterations == 2048
+    near, length = c.trace()
+    size_at_wave_start, size = [], 1
+    for k in range(c.iterations):
+        if k % wave == 0:
+            start = size
+        assert near[k] < start                      # parents come from the wave-start snapshot only
+        size += 1 if length[k] > 0 else 0
+    assert size == c.size
+    assert not np.array_equal(c.parents()[:min(c.size, a.size)], a.parents()[:min(c.size, a.size)])   # a different tree
