@@ -1453,3 +1453,11 @@ extern "C" int lqrrt_profile_read(lqrrt_engine* e, double* nn_ms, int64_t* nn_la
     if (steer_launches) *steer_launches = e->steer_launches;
     return 0;
 }
+
+#ifdef STEER_TIMING
+// debug build only (tools/ablate_steer.py): phase timestamps of block 0 of the last steer launch, 100 MHz ticks
+extern "C" int lqrrt_debug_steer_ts(unsigned long long* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lq::g_steer_ts), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    return 0;
+}
+#endif

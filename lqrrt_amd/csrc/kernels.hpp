@@ -411,6 +411,13 @@ struct SteerFuse {
     double* M; int W;                                        // M != null: row epilogue, leading dimension W
 };
 
+#ifdef STEER_TIMING
+__device__ unsigned long long g_steer_ts[8];
+#define STEER_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_steer_ts[i] = wall_clock64(); } while (0)
+#else
+#define STEER_TS(i) do {} while (0)
+#endif
+
 template <class S, bool DENSE>
 __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView tv, double* __restrict__ rec,
                                               RecLayout L, const double* __restrict__ xs,
@@ -420,19 +427,13 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
     // list mode with a device-side count: the launch is enqueued before the host knows how many samples
     // k_decide listed, so surplus workgroups simply leave (and a converged round costs one empty launch)
     if (list_count && (int)blockIdx.x + lo >= list_count[0]) return;
+    STEER_TS(0);
     extern __shared__ double hist[];
     double* hx = hist;
     double* hu = hist + (size_t)r.H * S::N;
     const int lane = threadIdx.x;
-    // Model constants and tolerances are read every step: keep them in LDS (broadcast reads into VGPRs)
-    // rather than in SGPRs, where ~100 live doubles spill through v_writelane/v_readlane and every
-    // reload is a dependent scalar-cache round trip on the critical path of the rollout.
     __shared__ double Pl[MAXP];
     __shared__ double tol_l[MAXN], glo_l[MAXN], ghi_l[MAXN];
-    for (int i = lane; i < MAXP; i += 64) Pl[i] = P.p[i];
-    if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
-    const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
-    __syncthreads();
     const int t = list ? list[blockIdx.x + (list_count ? lo : 0)] : lo + (int)blockIdx.x;
     double* my = rec + (size_t)t * L.R;
 
@@ -493,8 +494,18 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         for (int j = 0; j < S::M * S::N; ++j) K[j] = pr[L.off_K + j];
     }
 
+    STEER_TS(1);
+    // Model constants and tolerances are read every step: keep them in LDS (broadcast reads into VGPRs)
+    // rather than in SGPRs, where ~100 live doubles spill through v_writelane/v_readlane and every
+    // reload is a dependent scalar-cache round trip on the critical path of the rollout.  Staged AFTER the
+    // sample / parent loads were issued, so the two chains of memory latency overlap.
+    for (int i = lane; i < MAXP; i += 64) Pl[i] = P.p[i];
+    if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
+    const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
+    __syncthreads();
+    STEER_TS(2);
     int cnt = 0, steps = 0;
-    bool grew = false;
+    bool grew = false, truncated = false;
     double last[S::N];
 #pragma unroll
     for (int d = 0; d < S::N; ++d) last[d] = INFINITY;           // planner.py:377
@@ -517,6 +528,7 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         }
         if (!uniform_true(S::feasible(Pl, g, gl, xn, u, trn, lane))) {   // planner.py:393-396
             cnt = (int)(r.FPR * (double)cnt);
+            truncated = true;
             break;
         }
         ++steps;                                                 // planner.py:414
@@ -546,17 +558,23 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         for (int j = 0; j < 2 * S::NW; ++j) trig[j] = trn[j];
         S::gain(Pl, x, trig, u, K);                             // planner.py:436
     }
+    STEER_TS(3);
     __syncthreads();
 
     int flags = 0;
     if (cnt > 0) {
-        double ul[S::M];
+        // A rollout that was not cut back by the FPR rule leaves exactly the new node in registers: x / trig are the
+        // last recorded state and K = lqr(x, u_last) was refreshed right after recording it (planner.py:436 computes
+        // what :257 asks for again).  Only a truncated edge has to go back to the history.
+        if (truncated) {
+            double ul[S::M];
 #pragma unroll
-        for (int d = 0; d < S::N; ++d) x[d] = hx[(cnt - 1) * S::N + d];
+            for (int d = 0; d < S::N; ++d) x[d] = hx[(cnt - 1) * S::N + d];
 #pragma unroll
-        for (int j = 0; j < S::M; ++j) ul[j] = hu[(cnt - 1) * S::M + j];
-        trig_of<S>(x, trig);
-        S::gain(Pl, x, trig, ul, K);                            // planner.py:257: lqr(xnew, u_last)
+            for (int j = 0; j < S::M; ++j) ul[j] = hu[(cnt - 1) * S::M + j];
+            trig_of<S>(x, trig);
+            S::gain(Pl, x, trig, ul, K);                        // planner.py:257: lqr(xnew, u_last)
+        }
         bool in = true;                                          // planner.py:442-447 (strict)
 #pragma unroll
         for (int d = 0; d < S::N; ++d) in = in && (glo_l[d] < x[d]) && (x[d] < ghi_l[d]);
@@ -573,6 +591,7 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         //        bits 8.. = number of completed steps (for the horizon_iters replay on the host)
         my[L.off_flags] = (double)(flags | (grew ? 2 : 0) | (steps << 8));
     }
+    STEER_TS(4);
     if (f.M) {
         // row t of the in-wave cost matrix: cost of this record's end state for every later sample u (the
         // arithmetic of k_nn_scan<TRI>: erf about the sample, quad_cost); +inf when the record adds no node
@@ -589,6 +608,7 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
             f.M[(size_t)t * f.W + u] = c;
         }
     }
+    STEER_TS(5);
 }
 
 // Rows of the in-wave cost matrix straight from the records (sharded waves: records of other ranks arrive by
