@@ -111,10 +111,24 @@ class NativeError(RuntimeError):
         self.code = code
 
 
+def _try_build():
+    """The library is built in-tree by __graft_entry__.build(); if it is absent and the toolchain is here, build it
+    now (a minute of hipcc).  Never a CPU path: without the library every call raises."""
+    root = os.path.dirname(_HERE)
+    entry = os.path.join(root, "__graft_entry__.py")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if os.path.exists(entry) and os.path.exists(hipcc):
+        import subprocess
+        import sys
+        subprocess.call([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import __graft_entry__ as g; g.build()" % root])
+
+
 def lib():
-    """Loads liblqrrt_hip.so (once).  Raises if it has not been built."""
+    """Loads liblqrrt_hip.so (once).  Raises if it has not been built and cannot be."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            _try_build()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 "lqrrt_amd: %s is missing -- build the HIP extension first "
