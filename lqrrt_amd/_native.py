@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblqrrt_hip.so")
+LIB_PATH = os.environ.get("LQRRT_LIB") or os.path.join(_HERE, "liblqrrt_hip.so")     # LQRRT_LIB: an experimental build (tools/)
 
 MAX_STATES, MAX_CONTROLS, MAX_PARAMS = 12, 6, 96
 
