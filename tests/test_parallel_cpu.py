@@ -95,13 +95,17 @@ def test_sharded_wave_two_ranks_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    port = 29500 + (os.getpid() % 500)
+    import socket
+    with socket.socket() as sk:                       # a port nobody holds right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [out.get(timeout=60) for _ in procs]
+    # generous: a spawned interpreter has to import torch, which takes minutes in a cold container
+    res = [out.get(timeout=600) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     res.sort()
     assert res[0][1:] == res[1][1:], "replicas diverged: %r" % (res,)

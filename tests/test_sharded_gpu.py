@@ -68,7 +68,11 @@ def test_sharded_wave_class_world_of_one_nccl():
     import torch
     import torch.distributed as dist
     from lqrrt_amd.parallel import ShardedWave
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
     try:
         _, ref = _make("boat_intermediate", 900, 128)
