@@ -10,7 +10,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 400 python $R/bench.py > $O/bench_plain.json 2> $O/bench_plain.err < /dev/null
-CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu"
+CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu --no-extras"
 rm -rf $O/prof_r1 $O/prof_r1_fetch $O/prof_r1_write
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r1 -o bench -- $CMD > $O/bench_under_rocprof.json 2> $O/prof_r1.log < /dev/null
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_r1_fetch -o bench -- $CMD > /dev/null 2> $O/prof_r1_fetch.log < /dev/null

@@ -43,18 +43,18 @@ def main():
     n_f, fetch_kib, dur_f = per_kernel(os.path.join(src, "prof_r1_fetch", "bench_counter_collection.csv"), kern)
     n_w, write_kib, dur_w = per_kernel(os.path.join(src, "prof_r1_write", "bench_counter_collection.csv"), kern)
     summary = {
-        "kernel": kern, "command": "python bench.py --steps 20 --warmup 3 --no-cpu (whole process: tree growth + warm-up + timed steps)",
+        "kernel": kern, "command": "python bench.py --steps 20 --warmup 3 --no-cpu --no-extras (whole process: tree growth + warm-up + timed steps)",
         "launches": n_f,
         "FETCH_SIZE_KiB_per_launch": fetch_kib / n_f, "WRITE_SIZE_KiB_per_launch": write_kib / n_w,
         "fetch_correction": 2.0,
         "hbm_bytes_per_launch": (2.0 * fetch_kib / n_f + write_kib / n_w) * 1024.0,
         "avg_launch_ns_fetch_pass": dur_f / n_f, "avg_launch_ns_write_pass": dur_w / n_w,
     }
-    ss, cnt = steady_state_ns(os.path.join(src, "prof_r1_fetch", "bench_counter_collection.csv"), kern, 250)
+    ss, cnt = steady_state_ns(os.path.join(src, "prof_r1_fetch", "bench_counter_collection.csv"), kern, 180)
     summary["steady_state_avg_launch_ns"] = ss
     summary["steady_state_launches"] = cnt
     summary["steady_state_note"] = ("last %d launches of the process = bench.py's windowed loop at 9.5k-10.5k nodes (the same launches "
-                                    "bench.py brackets with HIP events; an event bracket adds the dispatch gap, ~3 us)" % cnt)
+                                    "bench.py times with dispatch-attached HIP events)" % cnt)
     with open(os.path.join(out, "%s_nn_traffic.json" % rnd), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps(summary, indent=1))
