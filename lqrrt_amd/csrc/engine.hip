@@ -709,7 +709,8 @@ extern "C" int lqrrt_engine_set_geometry(lqrrt_engine* e, const lqrrt_system_des
     if (sys->n_params < 0 || sys->n_params > LQRRT_MAX_PARAMS) return fail(LQRRT_E_ARG, "bad n_params");
     if ((sys->n_vertices > 0 && !sys->vps) || (sys->n_obstacles > 0 && !sys->obs)) return fail(LQRRT_E_ARG, "vps/obs pointer missing");
     TRY(use_device(e));
-    HIPCHK(hipStreamSynchronize((hipStream_t)stream));       // nothing in flight may still read the old tables
+    (void)stream;
+    HIPCHK(hipDeviceSynchronize());                          // nothing in flight, on any stream, may still read the old tables
     free_geometry(e);
     memset(&e->P, 0, sizeof e->P);
     memcpy(e->P.p, sys->params, sizeof(double) * sys->n_params);
