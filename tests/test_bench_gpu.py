@@ -1,0 +1,44 @@
+"""bench.py keeps its contract: one JSON line (the last line of stdout) with the driver's fields, the roofline and,
+when asked for, the CPU baseline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(extra, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1"] + extra,
+                         capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    return json.loads(lines[-1])                     # the JSON line is the LAST line of stdout
+
+
+def test_bench_line_fields():
+    d = _run(["--cpu-seconds", "2"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 1e4                                          # north_star's floor, by a wide margin in practice
+    assert abs(d["ms_per_step"] * d["value"] / 1e3 - d["config"]["attempts_per_step"]) < 1e-6 * d["config"]["attempts_per_step"] + 1
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["launches"] > 0 and r["avg_launch_us"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["sample"]
+    assert d["synchronous_mode"]["value"] > d["value"]             # the optional mode is an extra, never the metric
+
+
+def test_bench_sharded_code_path_world_of_one():
+    d = _run(["--no-cpu", "--no-extras"], env={"LQRRT_FORCE_SHARDED": "1"})
+    assert d["value"] > 1e4 and "cpu_baseline" not in d
