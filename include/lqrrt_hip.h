@@ -311,7 +311,8 @@ int lqrrt_engine_counters(lqrrt_engine* e, lqrrt_extend_stats* out);
 
 /* Timing of the dominant kernel (NN scan) accumulated with HIP events on `stream` (attached to each
  * dispatch as its start/stop events) when enabled: total ms, launches, algorithmic bytes (sum of W*N*(8n+1)).
- * on = 0 off, 1 NN scan launches only, 2 NN scan and steer launches (enabling resets the sums). */
+ * on = 0 off, 1 NN scan launches only, 2 NN scan and steer launches (enabling resets the sums);
+ * add 16 * (k - 1) to time only every k-th NN scan launch (sums and launch counts then refer to those). */
 int lqrrt_profile_enable(lqrrt_engine* e, int on);
 int lqrrt_profile_read(lqrrt_engine* e, double* nn_ms, int64_t* nn_launches, double* nn_bytes,
                        double* steer_ms, int64_t* steer_launches);

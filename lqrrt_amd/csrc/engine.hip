@@ -179,6 +179,7 @@ struct lqrrt_engine {
 
     // profiling
     int prof = 0;                       // 0 off, 1 NN scan only, 2 NN scan + steer
+    int prof_every = 1, prof_tick = 0;  // time every prof_every-th NN scan launch (the events cost ~1 us of host time each)
     std::vector<hipEvent_t> ev_free;    // recycled events (creating one per launch costs more than the record)
     std::vector<EvPair> evs;
     double nn_ms = 0, nn_bytes = 0, steer_ms = 0;
@@ -293,6 +294,7 @@ static void prof_flush(lqrrt_engine* e) {
 static void prof_begin(lqrrt_engine* e, hipStream_t, EvPair* ev, int kind) {
     ev->a = ev->b = nullptr;
     if (e->prof < 1 + kind) return;
+    if (kind == 0 && e->prof_every > 1 && (e->prof_tick++ % e->prof_every) != 0) return;
     if (e->evs.size() >= 2048) prof_flush(e);      // bounded pool; these events completed long ago
     ev->a = prof_event(e);
     ev->b = prof_event(e);
@@ -1437,6 +1439,10 @@ extern "C" int lqrrt_engine_counters(lqrrt_engine* e, lqrrt_extend_stats* out) {
 extern "C" int lqrrt_profile_enable(lqrrt_engine* e, int on) {
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     prof_flush(e);
+    // on = level + 16 * (sampling interval - 1): e.g. 1 + 16*3 times every 4th NN scan launch
+    e->prof_every = on > 0 ? (on >> 4) + 1 : 1;
+    e->prof_tick = 0;
+    on = on > 0 ? (on & 15) : on;
     e->prof = on < 0 ? 0 : (on > 2 ? 2 : on);
     e->nn_ms = e->nn_bytes = e->steer_ms = 0;
     e->nn_launches = e->steer_launches = 0;

@@ -331,9 +331,9 @@ class Engine(object):
         nat.check(nat.lib().lqrrt_engine_counters(self.h, C.byref(st)))
         return st
 
-    def profile_enable(self, on=True, steer=True):
-        """HIP-event timing of the NN scan launches (and of the steer launches when `steer`)."""
-        nat.check(nat.lib().lqrrt_profile_enable(self.h, (2 if steer else 1) if on else 0))
+    def profile_enable(self, on=True, steer=True, every=1):
+        """HIP-event timing of the NN scan launches (every `every`-th one) and of the steer launches when `steer`."""
+        nat.check(nat.lib().lqrrt_profile_enable(self.h, ((2 if steer else 1) + 16 * (max(1, int(every)) - 1)) if on else 0))
 
     def profile_read(self):
         a, b, c, d, f = C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_int64()
