@@ -18,7 +18,8 @@ import lqrrt_amd
 
 CASES = [("boat_advanced", "200"), ("boat_intermediate", "300"), ("boat_novice", "300"), ("car", "500"),
          ("pendulum", "150"), ("car", "2000"), ("car", "firstgoal"), ("boat_novice", "firstgoal"),
-         ("boat_intermediate", "adaptive"), ("car", "adaptive")]
+         ("boat_intermediate", "adaptive"), ("car", "adaptive"),
+         ("car", "nopruning"), ("boat_novice", "nopruning"), ("car", "tries1"), ("boat_intermediate", "tries1")]
 
 
 @pytest.mark.parametrize("name,tag", CASES)
@@ -28,10 +29,12 @@ def test_coracle_trajectory(golden_dir, name, tag):
         pytest.skip("fixture missing")
     g = np.load(path)
     s = lqrrt_amd.systems.SYSTEMS[name](0)
-    o = coracle.make(s, int(g["max_nodes"]), seed=1, horizon=(0.1, 3) if tag == "adaptive" else None)
+    pruning = bool(g["pruning"]) if "pruning" in g.files else True
+    tries = int(g["tries"]) if "tries" in g.files else 10
+    o = coracle.make(s, int(g["max_nodes"]), seed=1, tries=tries, horizon=(0.1, 3) if tag == "adaptive" else None)
     o.enable_trace(int(g["iterations"]) + 16)
     first_goal = float(g["min_time"]) == 0.0
-    reason = o.extend(max_nodes=int(g["max_nodes"]), stop_on_goal=first_goal)
+    reason = o.extend(max_nodes=int(g["max_nodes"]), pruning=pruning, stop_on_goal=first_goal)
     assert reason == (4 if first_goal else 2)
     assert o.iterations == int(g["iterations"])
     assert o.candidates == int(g["n_candidates"])

@@ -147,7 +147,7 @@ def gen_ops(name):
 
 # --------------------------------------------------------------------------- trajectory level
 
-def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None, horizon=None):
+def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None, horizon=None, pruning=True, tries=10):
     ns = rl.load_demo(name, OBS_SEED)
     planner = rl.make_planner(name, ns, max_nodes, min_time=min_time)
     if horizon is not None:
@@ -174,7 +174,7 @@ def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None, horizon=N
 
     np.random.seed(PLAN_SEED)
     t0 = time.time()
-    ret = planner.update_plan(rl.x0_of(name, ns), ns["sample_space"], goal_bias=ns["goal_bias"], xrand_gen=10)
+    ret = planner.update_plan(rl.x0_of(name, ns), ns["sample_space"], goal_bias=ns["goal_bias"], xrand_gen=tries, pruning=pruning)
     wall = time.time() - t0
 
     # how many (n+1)-double sampler candidates were consumed from the legacy global stream
@@ -204,6 +204,7 @@ def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None, horizon=N
         plan_T=np.float64(planner.T), pid_hash=np.array(pid_hash(tree.pID)),
         state_sum=np.float64(tree.state.sum()), ref_wall_s=np.float64(wall),
         tie_iterations=np.int64(np.sum(ties)), horizon_iters_final=np.int64(planner.horizon_iters),
+        pruning=np.bool_(pruning), tries=np.int64(tries),
     )
     # a few complete edges (first, a middle one, the last) to pin x_seq/u_seq contents
     for tagid, ID in (("a", 1), ("b", tree.size // 2), ("c", tree.size - 1)):
@@ -379,6 +380,13 @@ def main():
         run_traj("car", 2000, keep_xrand=64)
         run_traj("car", 2000, keep_xrand=64, tag="firstgoal", min_time=0)
         run_traj("boat_novice", 1000, keep_xrand=64, tag="firstgoal", min_time=0)
+    if "modes" in what or "traj" in what:
+        # update_plan's other switches on the reference itself: pruning=False (argmin instead of the ignore-aware
+        # argsort, planner.py:239-247) and xrand_gen=1 (a single sampler try, :188-211)
+        run_traj("car", 600, keep_xrand=64, tag="nopruning", pruning=False)
+        run_traj("boat_novice", 400, keep_xrand=64, tag="nopruning", pruning=False)
+        run_traj("car", 600, keep_xrand=64, tag="tries1", tries=1)
+        run_traj("boat_intermediate", 300, keep_xrand=64, tag="tries1", tries=1)
     if "adaptive" in what or "traj" in what:
         run_traj("boat_intermediate", 400, keep_xrand=64, tag="adaptive", horizon=(0.1, 3))
         run_traj("car", 400, keep_xrand=64, tag="adaptive", horizon=(0.1, 3))
