@@ -19,7 +19,8 @@ import lqrrt_amd
 CASES = [("boat_advanced", "200"), ("boat_intermediate", "300"), ("boat_novice", "300"), ("car", "500"),
          ("pendulum", "150"), ("car", "2000"), ("car", "firstgoal"), ("boat_novice", "firstgoal"),
          ("boat_intermediate", "adaptive"), ("car", "adaptive"),
-         ("car", "nopruning"), ("boat_novice", "nopruning"), ("car", "tries1"), ("boat_intermediate", "tries1")]
+         ("car", "nopruning"), ("boat_novice", "nopruning"), ("car", "tries1"), ("boat_intermediate", "tries1"),
+         ("car", "guide"), ("boat_intermediate", "guide")]
 
 
 @pytest.mark.parametrize("name,tag", CASES)

@@ -111,7 +111,8 @@ def test_costs_to_go_golden(sys_ops):
 TRAJ = [("boat_intermediate", "300", 256), ("boat_novice", "300", 256), ("car", "500", 256), ("pendulum", "150", 64),
         ("car", "2000", 1024), ("car", "firstgoal", 128), ("boat_novice", "firstgoal", 128),
         ("boat_intermediate", "adaptive", 256), ("car", "adaptive", 64),
-        ("car", "nopruning", 256), ("boat_novice", "nopruning", 512), ("car", "tries1", 128), ("boat_intermediate", "tries1", 256)]
+        ("car", "nopruning", 256), ("boat_novice", "nopruning", 512), ("car", "tries1", 128), ("boat_intermediate", "tries1", 256),
+        ("car", "guide", 64), ("boat_intermediate", "guide", 16)]
 
 
 @pytest.mark.parametrize("tag,wave,min_prefix", [("200", 64, 201), ("200", 1024, 201), ("3000", 1024, 150), ("10k", 1024, 150)])
@@ -147,7 +148,8 @@ def test_trajectory_golden(golden_dir, name, tag, wave):
     pruning = bool(g["pruning"]) if "pruning" in g.files else True            # the "modes" fixtures carry their switches
     tries = int(g["tries"]) if "tries" in g.files else 10
     np.random.seed(1)
-    ret = p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=tries, pruning=pruning)
+    guide = g["guide"] if "guide" in g.files and len(g["guide"]) else None    # fallback-plan fixtures (planner.py:311-328)
+    ret = p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=tries, pruning=pruning, guide=guide)
     assert ret == bool(g["returned"])
     if tag == "adaptive":
         assert p.horizon_iters == int(g["horizon_iters_final"])

@@ -96,7 +96,8 @@ def test_costs_to_go(sys_and_ops):
 TRAJ = [("boat_advanced", "200"), ("boat_intermediate", "300"), ("boat_novice", "300"), ("car", "500"),
         ("pendulum", "150"), ("car", "2000"), ("car", "firstgoal"), ("boat_novice", "firstgoal"),
         ("boat_intermediate", "adaptive"), ("car", "adaptive"),
-        ("car", "nopruning"), ("boat_novice", "nopruning"), ("car", "tries1"), ("boat_intermediate", "tries1")]
+        ("car", "nopruning"), ("boat_novice", "nopruning"), ("car", "tries1"), ("boat_intermediate", "tries1"),
+        ("car", "guide"), ("boat_intermediate", "guide")]
 
 
 @pytest.mark.parametrize("name,tag", TRAJ)
@@ -109,7 +110,8 @@ def test_trajectory(golden_dir, name, tag):
     np.random.seed(1)
     pruning = bool(g["pruning"]) if "pruning" in g.files else True            # the "modes" fixtures carry their switches
     tries = int(g["tries"]) if "tries" in g.files else 10
-    ret = p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=tries, pruning=pruning, trace=True)
+    guide = g["guide"] if "guide" in g.files and len(g["guide"]) else None    # fallback-plan fixtures (planner.py:311-328)
+    ret = p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=tries, pruning=pruning, guide=guide, trace=True)
     assert ret == bool(g["returned"])
     assert p.iterations == int(g["iterations"])
     assert p.sampler.candidates == int(g["n_candidates"])

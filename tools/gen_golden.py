@@ -147,7 +147,8 @@ def gen_ops(name):
 
 # --------------------------------------------------------------------------- trajectory level
 
-def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None, horizon=None, pruning=True, tries=10):
+def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None, horizon=None, pruning=True, tries=10, guide=None,
+             finish_on_goal=False):
     ns = rl.load_demo(name, OBS_SEED)
     planner = rl.make_planner(name, ns, max_nodes, min_time=min_time)
     if horizon is not None:
@@ -174,7 +175,8 @@ def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None, horizon=N
 
     np.random.seed(PLAN_SEED)
     t0 = time.time()
-    ret = planner.update_plan(rl.x0_of(name, ns), ns["sample_space"], goal_bias=ns["goal_bias"], xrand_gen=tries, pruning=pruning)
+    ret = planner.update_plan(rl.x0_of(name, ns), ns["sample_space"], goal_bias=ns["goal_bias"], xrand_gen=tries, pruning=pruning,
+                              guide=guide, finish_on_goal=finish_on_goal)
     wall = time.time() - t0
 
     # how many (n+1)-double sampler candidates were consumed from the legacy global stream
@@ -204,7 +206,8 @@ def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None, horizon=N
         plan_T=np.float64(planner.T), pid_hash=np.array(pid_hash(tree.pID)),
         state_sum=np.float64(tree.state.sum()), ref_wall_s=np.float64(wall),
         tie_iterations=np.int64(np.sum(ties)), horizon_iters_final=np.int64(planner.horizon_iters),
-        pruning=np.bool_(pruning), tries=np.int64(tries),
+        pruning=np.bool_(pruning), tries=np.int64(tries), finish_on_goal=np.bool_(finish_on_goal),
+        guide=np.array(guide if guide is not None else [], dtype=np.float64),
     )
     # a few complete edges (first, a middle one, the last) to pin x_seq/u_seq contents
     for tagid, ID in (("a", 1), ("b", tree.size // 2), ("c", tree.size - 1)):
@@ -387,6 +390,12 @@ def main():
         run_traj("boat_novice", 400, keep_xrand=64, tag="nopruning", pruning=False)
         run_traj("car", 600, keep_xrand=64, tag="tries1", tries=1)
         run_traj("boat_intermediate", 300, keep_xrand=64, tag="tries1", tries=1)
+    if "plans" in what or "traj" in what:
+        # plan extraction off the main line: the guide fallback when the goal was not reached (planner.py:311-328)
+        run_traj("car", 60, keep_xrand=64, tag="guide", guide=[35.0, 35.0, 0.0, 0.0, 0.0])
+        run_traj("boat_intermediate", 50, keep_xrand=64, tag="guide", guide=[30.0, 10.0, 0.5, 0.0, 0.0, 0.0])
+        # (finish_on_goal cannot be pinned this way: with the frozen clock the reference's force-arrive steer, whose
+        #  only other exit is np.allclose to the goal, never returns -- its real exit is the wall-clock timeout)
     if "adaptive" in what or "traj" in what:
         run_traj("boat_intermediate", 400, keep_xrand=64, tag="adaptive", horizon=(0.1, 3))
         run_traj("car", 400, keep_xrand=64, tag="adaptive", horizon=(0.1, 3))
