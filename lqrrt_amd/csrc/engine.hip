@@ -1467,4 +1467,8 @@ extern "C" int lqrrt_debug_steer_ts(unsigned long long* out8) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lq::g_steer_ts), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
     return 0;
 }
+extern "C" int lqrrt_debug_step_acc(unsigned long long* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lq::g_step_acc), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    return 0;
+}
 #endif

@@ -414,8 +414,13 @@ struct SteerFuse {
 #ifdef STEER_TIMING
 __device__ unsigned long long g_steer_ts[8];
 #define STEER_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_steer_ts[i] = wall_clock64(); } while (0)
+__device__ unsigned long long g_step_acc[8];        // per-phase ticks of the rollout loop of block 0, + step count
+#define STEP_TS(v) const unsigned long long v = wall_clock64()
+#define STEP_ACC(i, a, b) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_step_acc[i] += (b) - (a); } while (0)
 #else
 #define STEER_TS(i) do {} while (0)
+#define STEP_TS(v) do {} while (0)
+#define STEP_ACC(i, a, b) do {} while (0)
 #endif
 
 template <class S, bool DENSE>
@@ -511,6 +516,7 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
     for (int d = 0; d < S::N; ++d) last[d] = INFINITY;           // planner.py:377
     while (true) {
         double e[S::N], u[S::M], uc[S::M], xn[S::N], trn[2 * S::NW + 1];
+        STEP_TS(ts0);
         if constexpr (is_packed<S>::value) {
             // same arithmetic, elementary functions packed across lanes (systems.hpp packed_heading)
             S::step_packed(Pl, xt, ttrig, x, trig, K, r.dt, lane, e, u, xn, trn);
@@ -526,7 +532,11 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
             S::step(Pl, x, trig, uc, r.dt, xn);                 // planner.py:390 (dynamics gets copies)
             trig_of<S>(xn, trn);
         }
-        if (!uniform_true(S::feasible(Pl, g, gl, xn, u, trn, lane))) {   // planner.py:393-396
+        STEP_TS(ts1);
+        const bool feas_ok = uniform_true(S::feasible(Pl, g, gl, xn, u, trn, lane));
+        STEP_TS(ts2);
+        STEP_ACC(0, ts0, ts1); STEP_ACC(1, ts1, ts2);
+        if (!feas_ok) {                                                  // planner.py:393-396
             cnt = (int)(r.FPR * (double)cnt);
             truncated = true;
             break;
@@ -557,6 +567,8 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
 #pragma unroll
         for (int j = 0; j < 2 * S::NW; ++j) trig[j] = trn[j];
         S::gain(Pl, x, trig, u, K);                             // planner.py:436
+        STEP_TS(ts3);
+        STEP_ACC(2, ts2, ts3); STEP_ACC(3, ts0, ts0 + 1);
     }
     STEER_TS(3);
     __syncthreads();
