@@ -511,6 +511,9 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
     STEER_TS(2);
     int cnt = 0, steps = 0;
     bool grew = false, truncated = false;
+    double tolr[S::N];                                           // loop-invariant: keep the tolerances out of the per-step LDS traffic
+#pragma unroll
+    for (int d = 0; d < S::N; ++d) tolr[d] = tol_l[d];
     double last[S::N];
 #pragma unroll
     for (int d = 0; d < S::N; ++d) last[d] = INFINITY;           // planner.py:377
@@ -552,11 +555,11 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         }
         bool conv = true;
 #pragma unroll
-        for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= tol_l[d]);
+        for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= tolr[d]);
         if (steps > r.H || uniform_true(conv)) break;            // planner.py:428
         // record (planner.py:432-433): lane d keeps component d
-        if (lane == 0) {                                         // wave-uniform values: one lane writes the LDS history
-#pragma unroll
+        {                                                        // wave-uniform values: every lane stores the same bits to the same
+#pragma unroll                                                   // LDS address (no exec-mask round trip for a lane-0 branch)
             for (int d = 0; d < S::N; ++d) hx[cnt * S::N + d] = xn[d];
 #pragma unroll
             for (int j = 0; j < S::M; ++j) hu[cnt * S::M + j] = u[j];
