@@ -45,7 +45,7 @@ def run(moves=6, basic_duration=0.3, seed=0, verbose=True):
 
     constraints = lqrrt.Constraints(nstates=6, ncontrols=3, goal_buffer=boat.goal_buffer, is_feasible=boat.is_feasible)
     planner = lqrrt.Planner(boat.dynamics, boat.lqr, constraints, erf=boat.erf, error_tol=boat.error_tol,
-                            min_time=basic_duration, max_time=basic_duration, max_nodes=1E5, goal0=goal,
+                            min_time=basic_duration, max_time=basic_duration, max_nodes=4E5, goal0=goal,
                             printing=False, **boat.plan_kwargs)
 
     state = np.zeros(6)
