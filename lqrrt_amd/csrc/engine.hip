@@ -112,6 +112,7 @@ struct lqrrt_engine {
     int* d_cell_start = nullptr;  // box obstacles: uniform grid (CSR) over the boxes' bounding volume
     int* d_cell_items = nullptr;
     double* d_S = nullptr;        // dense system S (n x n) or null = identity
+    int smode = 1;                // form of d_S for the scans: S_DENSE, S_DIAG or S_BAND2 (kernels.hpp quad_cost)
 
     // tree
     TreeView tv{};
@@ -342,11 +343,21 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
 #define NN_LAUNCH(DENSE, TRI)                                                                            \
     DISPATCH(e, hipExtLaunchKernelGGL((k_nn_scan<S, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, W, S_use, chunk, \
                                       e->d_pcost, e->d_pidx, ps_c, ps_t))
-    if (S_use) {
-        if (tri) { NN_LAUNCH(true, true); } else { NN_LAUNCH(true, false); }
+    // structured forms of the engine's own S are instantiated only for the systems that have them
+    const int sm = !S_use ? S_IDENT : (Sd ? S_DENSE : e->smode);
+#define NN_ONE(SYS, DENSE, TRI)                                                                            \
+    hipExtLaunchKernelGGL((k_nn_scan<SYS, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, W, S_use, chunk, \
+                          e->d_pcost, e->d_pidx, ps_c, ps_t)
+    if (sm == S_BAND2 && e->model == LQRRT_MODEL_DOUBLE_INTEGRATOR) {
+        if (tri) NN_ONE(DoubleIntegratorT<6>, S_BAND2, true); else NN_ONE(DoubleIntegratorT<6>, S_BAND2, false);
+    } else if (sm == S_DIAG && e->model == LQRRT_MODEL_ROS_BOAT) {
+        if (tri) NN_ONE(RosBoat, S_DIAG, true); else NN_ONE(RosBoat, S_DIAG, false);
+    } else if (S_use) {
+        if (tri) { NN_LAUNCH(S_DENSE, true); } else { NN_LAUNCH(S_DENSE, false); }
     } else {
-        if (tri) { NN_LAUNCH(false, true); } else { NN_LAUNCH(false, false); }
+        if (tri) { NN_LAUNCH(S_IDENT, true); } else { NN_LAUNCH(S_IDENT, false); }
     }
+#undef NN_ONE
 #undef NN_LAUNCH
     if (profile) prof_end(e, st, &ev, 0, (double)W * (double)nv.count * (8.0 * e->n + 1.0));
     if (tri || defer_reduce) { HIPCHK(hipGetLastError()); return 0; }     // deferred: the steer launch reduces (SteerFuse)
@@ -641,6 +652,17 @@ extern "C" int lqrrt_engine_set_dense_S(lqrrt_engine* e, const double* S_host) {
     if (S_host) {
         TRY(dalloc(&e->d_S, (size_t)e->n * e->n));
         HIPCHK(hipMemcpy(e->d_S, S_host, sizeof(double) * e->n * e->n, hipMemcpyHostToDevice));
+        // classify S so that the scans can leave its zero terms out (quad_cost)
+        const int n = e->n, h = n / 2;
+        bool diag = true, band2 = (n % 2 == 0);
+        for (int j = 0; j < n; ++j)
+            for (int k = 0; k < n; ++k) {
+                const bool nz = S_host[j * n + k] != 0.0;
+                if (nz && j != k) diag = false;
+                if (nz && band2 && (j % h) != (k % h)) band2 = false;
+            }
+        e->smode = diag ? S_DIAG : (band2 ? S_BAND2 : S_DENSE);
+        if (getenv("LQRRT_S_DENSE")) e->smode = S_DENSE;
     }
     return 0;
 }

@@ -106,12 +106,30 @@ __device__ __forceinline__ void erf_cached(const double* xg, const double* gtrig
 
 // (v-x)' S (v-x) in the reference's evaluation order (planner.py:350):
 // np.sum(np.tensordot(diffs, S, axes=1) * diffs, axis=1)
-template <class S, bool DENSE>
+// DENSE is the form of S: 0 identity, 1 dense, 2 diagonal, 3 "two bands" (S_jk != 0 only for j = k mod N/2 and
+// j = k mod N/2 + N/2: the DARE solution of a double integrator with diagonal Q, R).  2 and 3 evaluate exactly the
+// dense loop with its zero terms left out -- the same partial sums in the same order, so the same bits except for
+// the sign of an exact zero, which no comparison can see (costs are only ever compared).  The host classifies S
+// (lqrrt_engine_set_dense_S); only the tree / in-wave scans are specialised, everything else stays dense.
+constexpr int S_IDENT = 0, S_DENSE = 1, S_DIAG = 2, S_BAND2 = 3;
+template <class S, int DENSE>
 __device__ __forceinline__ double quad_cost(const double* e, const double* Sd) {
     double prod[S::N];
-    if constexpr (!DENSE) {
+    if constexpr (DENSE == S_IDENT) {
 #pragma unroll
         for (int k = 0; k < S::N; ++k) prod[k] = e[k] * e[k];
+    } else if constexpr (DENSE == S_DIAG) {
+#pragma unroll
+        for (int k = 0; k < S::N; ++k) prod[k] = (e[k] * Sd[k * S::N + k]) * e[k];
+    } else if constexpr (DENSE == S_BAND2) {
+        constexpr int h = S::N / 2;
+#pragma unroll
+        for (int k = 0; k < S::N; ++k) {
+            const int k0 = k % h;
+            double t = e[k0] * Sd[k0 * S::N + k];
+            t += e[k0 + h] * Sd[(k0 + h) * S::N + k];
+            prod[k] = t * e[k];
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < S::N; ++k) {
@@ -131,7 +149,7 @@ __device__ __forceinline__ double quad_cost(const double* e, const double* Sd) {
 // Output: partial minima over the eligible nodes (not ignored / accepted in-wave record) at
 // [chunk * ps_c + sample * ps_t]: the tree scan writes sample-major (ps_c = 1) so that k_nn_reduce reads a
 // sample's partials contiguously; the in-wave scan writes chunk-major (ps_t = 1), the order k_decide wants.
-template <class S, bool DENSE, bool TRI>
+template <class S, int DENSE, bool TRI>
 __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __restrict__ xs, int W,
                                                 const double* __restrict__ Sd, int chunk,
                                                 double* __restrict__ pcost, int* __restrict__ pidx,
@@ -244,7 +262,7 @@ __device__ __forceinline__ void lexmin_wave(double& c, int& i) {
     }
 }
 
-template <class S, bool DENSE>
+template <class S, int DENSE>
 __global__ __launch_bounds__(64) void k_nn_reduce(const double* __restrict__ pcost, const int* __restrict__ pidx,
                                                   int W, int n_chunks, NodeView nv, const double* __restrict__ xs,
                                                   const double* __restrict__ Sd,
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(64) void k_nn_reduce(const double* __restrict__ pco
 }
 
 // Full cost vector of one sample (planner.py:340-350); thread per node.
-template <class S, bool DENSE>
+template <class S, int DENSE>
 __global__ void k_costs(NodeView nv, const double* __restrict__ xq, const double* __restrict__ Sd,
                         double* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -423,7 +441,7 @@ __device__ unsigned long long g_step_acc[8];        // per-phase ticks of the ro
 #define STEP_ACC(i, a, b) do {} while (0)
 #endif
 
-template <class S, bool DENSE>
+template <class S, int DENSE>
 __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView tv, double* __restrict__ rec,
                                               RecLayout L, const double* __restrict__ xs,
                                               const int* __restrict__ list, int lo,
@@ -628,7 +646,7 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
 
 // Rows of the in-wave cost matrix straight from the records (sharded waves: records of other ranks arrive by
 // all-gather without their rows).  One wavefront per record.
-template <class S, bool DENSE>
+template <class S, int DENSE>
 __global__ __launch_bounds__(64) void k_wave_rows(const double* __restrict__ rec, RecLayout L, const double* __restrict__ xs,
                                                   const double* __restrict__ Sd, double* __restrict__ M, int W) {
     const int t = blockIdx.x, lane = threadIdx.x;
