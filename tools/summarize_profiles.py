@@ -39,7 +39,7 @@ def main():
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     shutil.copy(os.path.join(src, "prof_r1", "bench_kernel_stats.csv"), os.path.join(out, "%s_kernel_stats.csv" % rnd))
-    kern = "k_nn_scan<lq::BoatAdvanced, false, false>"
+    kern = "k_nn_scan<lq::BoatAdvanced, 0, false>"
     n_f, fetch_kib, dur_f = per_kernel(os.path.join(src, "prof_r1_fetch", "bench_counter_collection.csv"), kern)
     n_w, write_kib, dur_w = per_kernel(os.path.join(src, "prof_r1_write", "bench_counter_collection.csv"), kern)
     summary = {
