@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -1229,9 +1230,12 @@ static void tune_wave(lqrrt_engine* e, int W, const lqrrt_extend_stats& ws, int 
 // the sequence word costs ~2 us; a hipMemcpyAsync + hipStreamSynchronize round trip costs ~25 us.
 static int wait_summary(lqrrt_engine* e, hipStream_t st) {
     volatile int* flag = e->h_summary + 3;
+    const auto t_start = std::chrono::steady_clock::now();
     for (long spin = 0;; ++spin) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == e->seq) return 0;
         if ((spin & 0xfffff) == 0xfffff) {                     // every ~1M polls: make sure the stream is still alive
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 120.0)
+                return fail(LQRRT_E_HIP, "no wave summary after 120 s (sequence %d): device hung?", e->seq);
             hipError_t q = hipStreamQuery(st);
             if (q != hipSuccess && q != hipErrorNotReady)
                 return fail(LQRRT_E_HIP, "stream failed while waiting for the wave summary: %s", hipGetErrorString(q));
