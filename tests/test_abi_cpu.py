@@ -121,3 +121,15 @@ def test_dare_matches_scipy():
         K_ref = np.linalg.solve(R + B.T @ S_ref @ B, B.T @ S_ref @ A)
         np.testing.assert_allclose(S, S_ref, rtol=1e-10, atol=1e-10)
         np.testing.assert_allclose(K, K_ref, rtol=1e-10, atol=1e-10)
+
+
+def test_integration_stub_matches_binding():
+    """INTEGRATION.md shows the ctypes struct a maintainer would write; it must list the fields of the real binding
+    (lqrrt_amd/_native.py SystemDesc == include/lqrrt_hip.h lqrrt_system_desc) in order."""
+    import re
+    from lqrrt_amd import _native as nat
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"class _SystemDesc\(C\.Structure\):.*?_fields_ = \[(.*?)\]\n", text, re.S)
+    assert m, "stub not found"
+    names = re.findall(r'\("(\w+)"', m.group(1))
+    assert names == [f[0] for f in nat.SystemDesc._fields_]
