@@ -408,3 +408,30 @@ def test_replanning_and_control_surface():
     assert p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10, specific_time=0.2) is True
     assert 0.2 <= time.time() - t0 < 20.0 and p.plan_reached_goal
     assert p.tree.size > 300             # the budget buys a much larger tree than the reference's ~20 nodes (loose: shared boxes)
+
+
+def test_planner_synchronous_wave_mode():
+    """Planner(wave_mode='synchronous'): same API, the tree of the synchronous rule (oracle orc_extend_sync), and the
+    ValueError convention for a bad mode."""
+    import coracle
+    import lqrrt_amd as lqrrt
+    s = _system("car")
+    with pytest.raises(ValueError):
+        _planner(s, 300, wave_mode="relaxed")
+    wave = 64
+    p = _planner(s, 600, wave_size=wave, wave_mode="synchronous")
+    np.random.seed(3)
+    assert p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10) is False      # frozen clock: ends on max_nodes
+    assert p.tree.size > 600 and hasattr(p, "node_seq") and np.all(np.isfinite(p.get_state(0.3 * p.T)))
+    # the planner asks the engine for 4 waves per native call, always whole waves of `wave` samples: the oracle
+    # reproduces the tree when it is driven in the same whole waves
+    o = coracle.make(s, 600 + 2 * wave + 64, seed=3)
+    o.extend_sync(wave, max_iters=p.stats["attempts"], max_nodes=600)
+    n = min(o.size, p.tree.size)
+    np.testing.assert_array_equal(np.array(p.tree.pID, dtype=np.int32)[:n], o.parents()[:n])
+    np.testing.assert_array_equal(p.tree.state[:n], o.states()[:n])
+    # and the exact mode on the same seed gives a different (the reference's) tree
+    q = _planner(s, 600, wave_size=wave)
+    np.random.seed(3)
+    q.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10)
+    assert not np.array_equal(np.array(q.tree.pID)[:n], np.array(p.tree.pID)[:n])
