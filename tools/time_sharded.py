@@ -9,7 +9,10 @@ import torch.distributed as dist
 import bench
 from lqrrt_amd.parallel import ShardedWave, shard_bounds
 
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", RANK="0", WORLD_SIZE="1")
+import socket
+with socket.socket() as _sk:
+    _sk.bind(("127.0.0.1", 0)); _port = _sk.getsockname()[1]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port), RANK="0", WORLD_SIZE="1")
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 boat, eng = bench.build_problem(10000, 1024, 0)
 eng.extend(1024, until_size=9500)
