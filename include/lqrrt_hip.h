@@ -187,6 +187,30 @@ int lqrrt_engine_get_mt19937(lqrrt_engine* e, uint32_t* key624, int* pos);
 int lqrrt_tree_reset(lqrrt_engine* e, const double* x0_host, void* stream);
 int lqrrt_tree_size(lqrrt_engine* e);
 
+/* Puts an existing tree on the device: the reference's Tree features state / lqr[.][1] / pID / x_seq / u_seq
+ * (tree.py:50-96) as flat host arrays.  Replaces whatever tree the engine holds; lqrrt_engine_set_resolution must
+ * have been called (the edge pools are laid out for its horizon_iters).  Uses: teacher-forced parity (the reference's
+ * own tree resident while lqrrt_nn_argmin / lqrrt_steer_batch are compared decision by decision with
+ * planner.py:236-257), and warm-starting a replan from a tree kept by the caller (lqrrt_node.py:389-500).
+ *   states   [count][n]       tree.state
+ *   K        [count][m][n]    tree.lqr[i][1]   (node S is never read on the path, planner.py:373)
+ *   pID      [count]          pID[0] = -1, 0 <= pID[i] < i   (tree.py:83-84 raises ValueError otherwise)
+ *   edge_len [count]          len(tree.x_seq[i]), 1..horizon_iters; NULL = every edge is the single state of its node
+ *   xedge    [sum(edge_len)][n], uedge [sum(edge_len)][m]: the edges back to back in node order; NULL = xedge rows
+ *            are the node's own state, uedge rows zero
+ *   ignored  [count] 0/1      membership in planner.py:173,270's `ignores`; NULL = none
+ * Goal bookkeeping (lqrrt_plan_best) starts empty; the sample stream and counters are not touched. */
+int lqrrt_tree_load(lqrrt_engine* e, int count, const double* states_host, const double* K_host, const int32_t* pID_host,
+                    const int32_t* edge_len_host, const double* xedge_host, const double* uedge_host,
+                    const uint8_t* ignored_host, void* stream);
+
+/* Forgets every node with id >= size (nodes are only ever appended, so the first `size` nodes are exactly the tree
+ * as it stood when it had that size).  Ignore bits of the dropped nodes are cleared, those of kept nodes stay. */
+int lqrrt_tree_truncate(lqrrt_engine* e, int size);
+
+/* Overwrites the ignore bits of nodes [first, first+count) (planner.py:270 `ignores`). */
+int lqrrt_tree_set_ignored(lqrrt_engine* e, int first, int count, const uint8_t* flags_host);
+
 /* Remember / restore the current tree size, ignore set and goal bookkeeping.  Nodes are only
  * ever appended, so rewinding is O(1); used by bench.py to keep the tree inside the size
  * window the metric is quoted at. (build-only; the reference rebuilds its tree per call) */
@@ -201,6 +225,9 @@ int lqrrt_tree_get_edge_lengths(lqrrt_engine* e, int first, int count, int32_t* 
 /* edge of one node: x [len][n], u [len][m]; returns len (root: 1, tree.py:69-70) */
 int lqrrt_tree_get_edge(lqrrt_engine* e, int id, double* x_host, double* u_host);
 int lqrrt_tree_get_ignored(lqrrt_engine* e, int first, int count, uint8_t* out_host);
+/* edges of nodes [first, first+count) in one copy: x [count][H][n], u [count][H][m] (H = horizon_iters; rows beyond a
+ * node's edge length are unspecified) */
+int lqrrt_tree_get_edges(lqrrt_engine* e, int first, int count, double* x_host, double* u_host);
 
 /* ---------------------------------------------------------------- operators ---------- */
 

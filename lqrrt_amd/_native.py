@@ -71,6 +71,10 @@ SIGNATURES = {
     "lqrrt_engine_get_mt19937": (_I, [_P, _P, C.POINTER(_I)]),
     "lqrrt_tree_reset": (_I, [_P, _P, _P]),
     "lqrrt_tree_size": (_I, [_P]),
+    "lqrrt_tree_load": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "lqrrt_tree_truncate": (_I, [_P, _I]),
+    "lqrrt_tree_set_ignored": (_I, [_P, _I, _I, _P]),
+    "lqrrt_tree_get_edges": (_I, [_P, _I, _I, _P, _P]),
     "lqrrt_tree_mark": (_I, [_P]),
     "lqrrt_tree_rewind": (_I, [_P]),
     "lqrrt_tree_get_states": (_I, [_P, _I, _I, _P]),
@@ -174,12 +178,13 @@ def ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def current_stream():
-    """hipStream_t of torch's current stream when torch is importable, else the null stream."""
+def current_stream(device=None):
+    """hipStream_t of torch's current stream ON `device` (the engine's device, not torch's current one) when torch is
+    importable, else the null stream."""
     try:
         import torch
         if torch.cuda.is_available():
-            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     except Exception:
         pass
     return C.c_void_p(0)

@@ -310,6 +310,11 @@ static void prof_end(lqrrt_engine* e, hipStream_t, EvPair* ev, int kind, double 
 // --------------------------------------------------------------------------------------------
 // kernel launch wrappers
 
+static bool trace_on() {
+    static const bool on = getenv("LQRRT_TRACE") != nullptr;     // read once: getenv walks the environment
+    return on;
+}
+
 static int tri_chunk() {
     static const int c = getenv("LQRRT_TRI_CHUNK") ? atoi(getenv("LQRRT_TRI_CHUNK")) : 32;
     return c;
@@ -801,6 +806,8 @@ extern "C" int lqrrt_tree_reset(lqrrt_engine* e, const double* x0_host, void* st
 
 extern "C" int lqrrt_tree_size(lqrrt_engine* e) { return e ? e->N : LQRRT_E_ARG; }
 
+static int flush_ignore(lqrrt_engine* e, hipStream_t st, bool sync_first);
+
 static int range_ok(lqrrt_engine* e, int first, int count) {
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     if (first < 0 || count < 0 || first + count > e->N)
@@ -862,6 +869,116 @@ extern "C" int lqrrt_tree_get_ignored(lqrrt_engine* e, int first, int count, uin
     return 0;
 }
 
+extern "C" int lqrrt_tree_get_edges(lqrrt_engine* e, int first, int count, double* x_host, double* u_host) {
+    TRY(range_ok(e, first, count));
+    if (!count) return 0;
+    TRY(use_device(e));
+    if (x_host) HIPCHK(hipMemcpy(x_host, e->tv.xedge + (size_t)first * e->H * e->n, sizeof(double) * (size_t)count * e->H * e->n, hipMemcpyDeviceToHost));
+    if (u_host) HIPCHK(hipMemcpy(u_host, e->tv.uedge + (size_t)first * e->H * e->m, sizeof(double) * (size_t)count * e->H * e->m, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// trig table of loaded nodes: the same lq_sincos the steer kernel applies to a new end state (trig_of)
+template <class S>
+__global__ void k_tree_trig(TreeView tv, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    if constexpr (S::NW > 0) {
+        double x[S::N], trig[2 * S::NW + 1];
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) x[d] = tv.state[(size_t)d * tv.cap + i];
+        trig_of<S>(x, trig);
+#pragma unroll
+        for (int j = 0; j < 2 * S::NW; ++j) tv.trig[(size_t)j * tv.cap + i] = trig[j];
+    }
+}
+
+extern "C" int lqrrt_tree_load(lqrrt_engine* e, int count, const double* states, const double* K, const int32_t* pID,
+                               const int32_t* edge_len, const double* xedge, const double* uedge, const uint8_t* ignored,
+                               void* stream) {
+    if (!e || !states || !K || !pID) return fail(LQRRT_E_ARG, "null argument");
+    if (!e->has_res) return fail(LQRRT_E_STATE, "set_resolution first (the edge pools depend on horizon_iters)");
+    if (count < 1) return fail(LQRRT_E_ARG, "a tree has at least its seed node");
+    if (count > e->cap) return fail(LQRRT_E_CAPACITY, "tree of %d nodes exceeds the engine capacity %d", count, e->cap);
+    if (pID[0] != -1) return fail(LQRRT_E_ARG, "the seed node must have parent -1");
+    for (int i = 1; i < count; ++i)
+        if (pID[i] < 0 || pID[i] >= i) return fail(LQRRT_E_ARG, "The given parent ID, %d, doesn't exist.", pID[i]);   // tree.py:83-84
+    if (edge_len)
+        for (int i = 0; i < count; ++i)
+            if (edge_len[i] < 1 || edge_len[i] > e->H)
+                return fail(LQRRT_E_ARG, "edge of node %d has %d steps (horizon_iters is %d)", i, edge_len[i], e->H);
+    TRY(use_device(e));
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipStreamSynchronize(st));                       // nothing of the old tree may still be in flight
+    const int n = e->n, m = e->m, H = e->H;
+    std::vector<double> soa((size_t)count);
+    for (int d = 0; d < n; ++d) {
+        for (int i = 0; i < count; ++i) soa[i] = states[(size_t)i * n + d];
+        HIPCHK(hipMemcpy(e->tv.state + (size_t)d * e->cap, soa.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(e->tv.K, K, sizeof(double) * (size_t)count * m * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->tv.pID, pID, sizeof(int) * count, hipMemcpyHostToDevice));
+    e->h_pid.assign(pID, pID + count);
+    if (edge_len) e->h_elen.assign(edge_len, edge_len + count); else e->h_elen.assign(count, 1);
+    HIPCHK(hipMemcpy(e->tv.elen, e->h_elen.data(), sizeof(int) * count, hipMemcpyHostToDevice));
+    {   // edges into the fixed-stride pools
+        std::vector<double> xe((size_t)count * H * n, 0.0), ue((size_t)count * H * m, 0.0);
+        size_t row = 0;
+        for (int i = 0; i < count; ++i) {
+            const int len = e->h_elen[i];
+            for (int k = 0; k < len; ++k, ++row) {
+                const double* xs = xedge ? xedge + row * n : states + (size_t)i * n;
+                for (int d = 0; d < n; ++d) xe[((size_t)i * H + k) * n + d] = xs[d];
+                if (uedge) for (int j = 0; j < m; ++j) ue[((size_t)i * H + k) * m + j] = uedge[row * m + j];
+            }
+        }
+        HIPCHK(hipMemcpy(e->tv.xedge, xe.data(), sizeof(double) * xe.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->tv.uedge, ue.data(), sizeof(double) * ue.size(), hipMemcpyHostToDevice));
+    }
+    DISPATCH(e, hipLaunchKernelGGL((k_tree_trig<S>), dim3((count + 255) / 256), dim3(256), 0, st, e->tv, count));
+    HIPCHK(hipGetLastError());
+    std::fill(e->h_ign.begin(), e->h_ign.end(), 0ull);
+    if (ignored)
+        for (int i = 0; i < count; ++i)
+            if (ignored[i]) e->h_ign[i >> 6] |= 1ull << (i & 63);
+    e->ign_hi = std::max(e->ign_hi, std::max(e->N, count));
+    e->ign_dirty = true;
+    e->N = count;
+    TRY(flush_ignore(e, st, false));
+    HIPCHK(hipStreamSynchronize(st));
+    e->goal_hits = 0; e->best_end = -1; e->best_steps = -1;
+    e->tot.tree_size = count;
+    e->ctl_w = 0.0;
+    return 0;
+}
+
+extern "C" int lqrrt_tree_truncate(lqrrt_engine* e, int size) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    if (size < 1 || size > e->N) return fail(LQRRT_E_ARG, "cannot truncate a tree of %d nodes to %d", e->N, size);
+    if (size == e->N) return 0;
+    e->ign_hi = std::max(e->ign_hi, e->N);
+    for (int i = size; i < e->N; ++i) e->h_ign[i >> 6] &= ~(1ull << (i & 63));
+    e->ign_dirty = true;
+    e->N = size;
+    e->h_pid.resize(size); e->h_elen.resize(size);
+    if (e->best_end >= size) { e->best_end = -1; e->best_steps = -1; e->goal_hits = 0; }
+    e->tot.tree_size = size;
+    return 0;
+}
+
+extern "C" int lqrrt_tree_set_ignored(lqrrt_engine* e, int first, int count, const uint8_t* flags) {
+    TRY(range_ok(e, first, count));
+    if (count && !flags) return fail(LQRRT_E_ARG, "null argument");
+    for (int i = 0; i < count; ++i) {
+        const int id = first + i;
+        if (flags[i]) e->h_ign[id >> 6] |= 1ull << (id & 63);
+        else e->h_ign[id >> 6] &= ~(1ull << (id & 63));
+    }
+    e->ign_hi = std::max(e->ign_hi, e->N);
+    e->ign_dirty = true;
+    return 0;
+}
+
 extern "C" int lqrrt_tree_mark(lqrrt_engine* e) {
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     if (e->N < 1) return fail(LQRRT_E_STATE, "no tree: call lqrrt_tree_reset");
@@ -882,7 +999,7 @@ extern "C" int lqrrt_tree_rewind(lqrrt_engine* e) {
     return 0;
 }
 
-static int flush_ignore(lqrrt_engine* e, hipStream_t st, bool sync_first = false) {
+static int flush_ignore(lqrrt_engine* e, hipStream_t st, bool sync_first) {
     if (!e->ign_dirty) return 0;
     // only the words that cover nodes which exist (or existed since the last upload) can differ
     const size_t words = std::min((size_t)e->cap / 64 + 1, (size_t)std::max(e->ign_hi, e->N) / 64 + 1);
@@ -1161,7 +1278,7 @@ extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void
     TRY(use_device(e));
     hipStream_t st = (hipStream_t)stream;
     TRY(ensure_samples(e, e->cursor + W, st));
-    TRY(flush_ignore(e, st));
+    TRY(flush_ignore(e, st, false));
     const double* xs = wave_samples(e);
     const int cnt = hi - lo;
     const bool whole = (lo == 0 && hi == W);
@@ -1313,7 +1430,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
         TRY(wait_summary(e, st));
         const unsigned counts = (unsigned)__atomic_load_n(&e->h_summary[2], __ATOMIC_RELAXED);   // same 64-bit store as the sequence word
         const int n_list = (int)(counts >> 16), n_defer = (int)(counts & 0xffffu);
-        if (getenv("LQRRT_TRACE")) fprintf(stderr, "[wave N=%d W=%d] round %d: list=%d defer=%d\n", e->N, W, rounds, n_list, n_defer);
+        if (trace_on()) fprintf(stderr, "[wave N=%d W=%d] round %d: list=%d defer=%d\n", e->N, W, rounds, n_list, n_defer);
         if (n_list == 0 && n_defer == 0) break;
         if (n_list == 0) return fail(LQRRT_E_STATE, "exact-mode repair made no progress (deferred=%d)", n_defer);
         if (n_list > pre) TRY(launch_steer(e, xs, e->d_list, pre, n_list - pre, e->d_par_done, st, e->d_summary, &rf));
@@ -1392,7 +1509,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
         }
         e->ign_dirty = pruning != 0;
     }
-    if (getenv("LQRRT_TRACE")) fprintf(stderr, "[wave N=%d W=%d] commit C=%d acc=%d hit=%d rounds=%d\n", base, W, C, acc, (int)hit, rounds);
+    if (trace_on()) fprintf(stderr, "[wave N=%d W=%d] commit C=%d acc=%d hit=%d rounds=%d\n", base, W, C, acc, (int)hit, rounds);
     // advance the stream
     const int64_t last = e->cursor + C - 1;
     if (C > 0) e->committed_row = e->pool_rows_end[(size_t)(last - e->pool_base)];

@@ -38,6 +38,10 @@ class Engine(object):
             nat.check(nat.lib().lqrrt_engine_set_dense_S(self.h, nat.ptr(S)))
         self.horizon_iters = None
 
+    def _stream(self):
+        """torch's current HIP stream on THIS engine's device."""
+        return nat.current_stream(self.device)
+
     def set_wave_mode(self, mode):
         """'exact' (default: the reference's sequential result) or 'synchronous' (all samples of a wave see the
         wave-start snapshot; fixed wave size; parity target oracle/lqrrt_oracle.c orc_extend_sync)."""
@@ -53,7 +57,7 @@ class Engine(object):
         rev = getattr(self.system, "revision", 0)
         if rev != self._geometry_revision:
             desc, keep = self.system.desc()
-            nat.check(nat.lib().lqrrt_engine_set_geometry(self.h, C.byref(desc), nat.current_stream()))
+            nat.check(nat.lib().lqrrt_engine_set_geometry(self.h, C.byref(desc), self._stream()))
             self._keep = keep
             self._geometry_revision = rev
             return True
@@ -126,7 +130,49 @@ class Engine(object):
     # -- tree -----------------------------------------------------------------------------------
     def tree_reset(self, x0):
         x0 = nat.as_f64(x0, (self.n,))
-        nat.check(nat.lib().lqrrt_tree_reset(self.h, nat.ptr(x0), nat.current_stream()))
+        nat.check(nat.lib().lqrrt_tree_reset(self.h, nat.ptr(x0), self._stream()))
+
+    def tree_load(self, states, K, pID, edge_len=None, xedge=None, uedge=None, ignored=None):
+        """Puts an existing tree on the device (lqrrt_tree_load): states (N, n), K (N, m, n), pID (N,), optionally the
+        edge lengths (N,) with the packed edges (sum(len), n) / (sum(len), m) and the ignore flags (N,)."""
+        states = nat.as_f64(states)
+        N = len(states)
+        states = nat.as_f64(states, (N, self.n))
+        K = nat.as_f64(K, (N, self.m, self.n))
+        pID = np.ascontiguousarray(pID, dtype=np.int32)
+        if pID.shape != (N,):
+            raise ValueError("expected %d parent IDs" % N)
+        keep = [states, K, pID]
+
+        def opt(a, dtype, shape=None):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=dtype)
+            if shape is not None and a.shape != shape:
+                raise ValueError("expected array of shape %r, got %r" % (shape, a.shape))
+            keep.append(a)
+            return nat.ptr(a)
+        el = opt(edge_len, np.int32, (N,))
+        rows = int(np.sum(edge_len)) if edge_len is not None else N
+        nat.check(nat.lib().lqrrt_tree_load(self.h, N, nat.ptr(states), nat.ptr(K), nat.ptr(pID), el,
+                                            opt(xedge, np.float64, (rows, self.n)), opt(uedge, np.float64, (rows, self.m)),
+                                            opt(ignored, np.uint8, (N,)), self._stream()))
+
+    def tree_truncate(self, size):
+        nat.check(nat.lib().lqrrt_tree_truncate(self.h, int(size)))
+
+    def set_ignored(self, flags, first=0):
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        nat.check(nat.lib().lqrrt_tree_set_ignored(self.h, int(first), len(flags), nat.ptr(flags)))
+
+    def edges(self, first=0, count=None):
+        """(x [count][H][n], u [count][H][m], len [count]) in three copies instead of one per node."""
+        count = self.size - first if count is None else count
+        H = max(self.horizon_iters or 1, 1)
+        x = np.empty((count, H, self.n))
+        u = np.empty((count, H, self.m))
+        nat.check(nat.lib().lqrrt_tree_get_edges(self.h, int(first), int(count), nat.ptr(x), nat.ptr(u)))
+        return x, u, self.edge_lengths(first, count)
 
     def tree_mark(self):
         nat.check(nat.lib().lqrrt_tree_mark(self.h))
@@ -188,7 +234,7 @@ class Engine(object):
         du = self._dev(u, (B, self.m)) if u is not None else None
         ok = torch.empty(B, dtype=torch.uint8, device=dx.device)
         nat.check(nat.lib().lqrrt_feasible_batch(self.h, dx.data_ptr(), du.data_ptr() if du is not None else None,
-                                                 B, ok.data_ptr(), nat.current_stream()))
+                                                 B, ok.data_ptr(), self._stream()))
         return ok.cpu().numpy().astype(bool)
 
     def dynamics_batch(self, x, u):
@@ -196,7 +242,7 @@ class Engine(object):
         B = len(x)
         dx, du = self._dev(x, (B, self.n)), self._dev(u, (B, self.m))
         out = torch.empty_like(dx)
-        nat.check(nat.lib().lqrrt_dynamics_batch(self.h, dx.data_ptr(), du.data_ptr(), B, out.data_ptr(), nat.current_stream()))
+        nat.check(nat.lib().lqrrt_dynamics_batch(self.h, dx.data_ptr(), du.data_ptr(), B, out.data_ptr(), self._stream()))
         return out.cpu().numpy()
 
     def gain_batch(self, x, u=None):
@@ -206,7 +252,7 @@ class Engine(object):
         du = self._dev(u, (B, self.m)) if u is not None else None
         K = torch.empty((B, self.m, self.n), dtype=torch.float64, device=dx.device)
         nat.check(nat.lib().lqrrt_gain_batch(self.h, dx.data_ptr(), du.data_ptr() if du is not None else None,
-                                             B, K.data_ptr(), nat.current_stream()))
+                                             B, K.data_ptr(), self._stream()))
         return K.cpu().numpy()
 
     def erf_batch(self, xg, x):
@@ -214,7 +260,7 @@ class Engine(object):
         B = len(x)
         dg, dx = self._dev(xg, (B, self.n)), self._dev(x, (B, self.n))
         e = torch.empty_like(dx)
-        nat.check(nat.lib().lqrrt_erf_batch(self.h, dg.data_ptr(), dx.data_ptr(), B, e.data_ptr(), nat.current_stream()))
+        nat.check(nat.lib().lqrrt_erf_batch(self.h, dg.data_ptr(), dx.data_ptr(), B, e.data_ptr(), self._stream()))
         return e.cpu().numpy()
 
     def lqr_dare_batch(self, x, u, Q, R, eps=1e-6):
@@ -231,7 +277,7 @@ class Engine(object):
         it = torch.empty(Bn, dtype=torch.int32, device=dev)
         nat.check(nat.lib().lqrrt_lqr_dare_batch(self.h, dx.data_ptr(), du.data_ptr(), Bn, dQ.data_ptr(), dR.data_ptr(),
                                                  float(eps), S.data_ptr(), K.data_ptr(), A.data_ptr(), Bm.data_ptr(),
-                                                 it.data_ptr(), nat.current_stream()))
+                                                 it.data_ptr(), self._stream()))
         return S.cpu().numpy(), K.cpu().numpy(), A.cpu().numpy(), Bm.cpu().numpy(), it.cpu().numpy()
 
     def nn_argmin(self, xs, S=None, use_ignore=True):
@@ -242,7 +288,7 @@ class Engine(object):
         ids = torch.empty(W, dtype=torch.int32, device=dxs.device)
         cost = torch.empty(W, dtype=torch.float64, device=dxs.device)
         nat.check(nat.lib().lqrrt_nn_argmin(self.h, dxs.data_ptr(), W, dS.data_ptr() if dS is not None else None,
-                                            1 if use_ignore else 0, ids.data_ptr(), cost.data_ptr(), nat.current_stream()))
+                                            1 if use_ignore else 0, ids.data_ptr(), cost.data_ptr(), self._stream()))
         return ids.cpu().numpy(), cost.cpu().numpy()
 
     def costs_to_go(self, x, S=None):
@@ -251,7 +297,7 @@ class Engine(object):
         dS = self._dev(S, (self.n, self.n)) if S is not None else None
         cost = torch.empty(self.size, dtype=torch.float64, device=dx.device)
         nat.check(nat.lib().lqrrt_costs_to_go(self.h, dx.data_ptr(), dS.data_ptr() if dS is not None else None,
-                                              cost.data_ptr(), nat.current_stream()))
+                                              cost.data_ptr(), self._stream()))
         return cost.cpu().numpy()
 
     def steer_batch(self, parents, xtar):
@@ -267,7 +313,7 @@ class Engine(object):
         xe = torch.empty((W, self.n), dtype=torch.float64, device=dev)
         Ke = torch.empty((W, self.m, self.n), dtype=torch.float64, device=dev)
         nat.check(nat.lib().lqrrt_steer_batch(self.h, dp.data_ptr(), dx.data_ptr(), W, ln.data_ptr(), xs.data_ptr(),
-                                              us.data_ptr(), xe.data_ptr(), Ke.data_ptr(), nat.current_stream()))
+                                              us.data_ptr(), xe.data_ptr(), Ke.data_ptr(), self._stream()))
         return ln.cpu().numpy(), xs.cpu().numpy(), us.cpu().numpy(), xe.cpu().numpy(), Ke.cpu().numpy()
 
     def steer_force(self, parent, xtar, max_steps, rtol=1e-4, atol=1e-4):
@@ -278,7 +324,7 @@ class Engine(object):
         xs = torch.empty((max_steps, self.n), dtype=torch.float64, device=dev)
         us = torch.empty((max_steps, self.m), dtype=torch.float64, device=dev)
         nat.check(nat.lib().lqrrt_steer_force(self.h, int(parent), dx.data_ptr(), int(max_steps), float(rtol), float(atol),
-                                              ln.data_ptr(), xs.data_ptr(), us.data_ptr(), nat.current_stream()))
+                                              ln.data_ptr(), xs.data_ptr(), us.data_ptr(), self._stream()))
         k = int(ln.cpu()[0])
         return xs[:k].cpu().numpy(), us[:k].cpu().numpy()
 
@@ -306,19 +352,19 @@ class Engine(object):
         return nat.check(nat.lib().lqrrt_wave_suggest(self.h, int(wave_cap)))
 
     def wave_speculate(self, W, lo, hi):
-        nat.check(nat.lib().lqrrt_wave_speculate(self.h, W, lo, hi, nat.current_stream()))
+        nat.check(nat.lib().lqrrt_wave_speculate(self.h, W, lo, hi, self._stream()))
 
     def wave_commit(self, W, max_commit, node_limit, pruning=True):
         st = nat.ExtendStats()
         nat.check(nat.lib().lqrrt_wave_commit(self.h, W, int(max_commit), int(node_limit), 1 if pruning else 0,
-                                              C.byref(st), nat.current_stream()))
+                                              C.byref(st), self._stream()))
         return st
 
     def extend(self, wave, max_attempts=-1, node_limit=-1, until_size=0, pruning=True, stop_on_goal=False):
         st = nat.ExtendStats()
         nat.check(nat.lib().lqrrt_engine_extend(self.h, int(wave), int(max_attempts), int(node_limit), int(until_size),
                                                 1 if pruning else 0, 1 if stop_on_goal else 0, C.byref(st),
-                                                nat.current_stream()))
+                                                self._stream()))
         return st
 
     def plan_best(self):

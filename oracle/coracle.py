@@ -31,6 +31,11 @@ def lib():
         L.orc_get_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
         L.orc_set_resolution.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int] + [C.c_void_p] * 4
         L.orc_set_ogrid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_load_tree.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
+        L.orc_set_ignored.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_nearest_prefix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_costs_prefix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_steer_from.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
         _lib = L
     return _lib
 
@@ -176,6 +181,34 @@ class COracle(object):
         x = _f(x)
         S = None if S is None else _f(S)
         return lib().orc_nearest(self.h, _p(x), _p(S) if S is not None else None, 1 if pruning else 0)
+
+    # teacher forcing: somebody else's tree resident, single decisions replayed (tests/test_teacher_cpu.py)
+    def load_tree(self, states, K, pID, ignored=None):
+        states, K = _f(states), _f(K)
+        pID = np.ascontiguousarray(pID, dtype=np.int32)
+        ign = None if ignored is None else np.ascontiguousarray(ignored, dtype=np.uint8)
+        if lib().orc_load_tree(self.h, len(states), _p(states), _p(K), _p(pID), _p(ign) if ign is not None else None) != 0:
+            raise ValueError("tree does not fit (reset first; capacity %d)" % len(states))
+
+    def set_ignored(self, ignored):
+        ign = np.ascontiguousarray(ignored, dtype=np.uint8)
+        lib().orc_set_ignored(self.h, _p(ign), len(ign))
+
+    def nearest_prefix(self, x, count, pruning=True):
+        x = _f(x)
+        return lib().orc_nearest_prefix(self.h, _p(x), _p(self.S) if self.S is not None else None, 1 if pruning else 0, int(count))
+
+    def costs_prefix(self, x, count):
+        x = _f(x)
+        out = np.empty(int(count))
+        lib().orc_costs_prefix(self.h, _p(x), _p(self.S) if self.S is not None else None, int(count), _p(out))
+        return out
+
+    def steer_from(self, ID, xtar):
+        xtar = _f(xtar)
+        xs, us, K = np.empty((self.H + 1, self.n)), np.empty((self.H + 1, self.m)), np.empty((self.m, self.n))
+        ln = lib().orc_steer_from(self.h, int(ID), _p(xtar), _p(xs), _p(us), _p(K))
+        return ln, xs[:ln].copy(), us[:ln].copy(), K
 
     # single-call operators
     def dynamics(self, x, u):

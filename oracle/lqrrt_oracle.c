@@ -628,6 +628,56 @@ int orc_extend_sync(orc* o, int wave, long long max_iters, long long max_nodes, 
 /* guide search of planner.py:311-318: argmin over ALL nodes with a dense S */
 int orc_nearest(orc* o, const double* x, const double* Sd, int pruning) { return nearest(o, x, Sd, pruning); }
 
+/* ---- teacher forcing (tests/test_teacher_cpu.py): somebody else's tree resident, single decisions replayed ---- */
+
+/* Replaces the tree by `count` given nodes (tree.py features state / lqr[.][1] / pID; edges are not needed by the
+ * decisions replayed here).  orc_reset must have been called (it allocates); ignored may be NULL. */
+int orc_load_tree(orc* o, int count, const double* states, const double* K, const int* pid, const unsigned char* ignored) {
+    if (count < 1 || count > o->cap || !o->state) return -1;
+    const int n = o->n, m = o->m;
+    memcpy(o->state, states, sizeof(double) * (size_t)count * n);
+    memcpy(o->K, K, sizeof(double) * (size_t)count * m * n);
+    memcpy(o->pid, pid, sizeof(int) * count);
+    for (int i = 0; i < count; ++i) {
+        trig_of(o, o->state + (size_t)i * n, o->trig + (size_t)i * 4);
+        o->elen[i] = 1;
+        o->ign[i] = ignored ? ignored[i] : 0;
+    }
+    o->N = count;
+    return 0;
+}
+void orc_set_ignored(orc* o, const unsigned char* ignored, int count) { memcpy(o->ign, ignored, count); }
+/* planner.py:239-247 against the first `count` nodes only (the tree as it stood at an earlier iteration) */
+int orc_nearest_prefix(orc* o, const double* x, const double* Sd, int pruning, int count) {
+    return nearest_upto(o, x, Sd, pruning, count < o->N ? count : o->N);
+}
+/* planner.py:340-350: the whole cost vector against the first `count` nodes */
+void orc_costs_prefix(orc* o, const double* xs, const double* Sd, int count, double* out) {
+    const int n = o->n;
+    double gt[4], e[MAXN], prod[MAXN];
+    trig_of(o, xs, gt);
+    for (int i = 0; i < count; ++i) {
+        erf_cached(o, xs, gt, o->state + (size_t)i * n, o->trig + (size_t)i * 4, e);
+        if (!Sd) for (int k = 0; k < n; ++k) prod[k] = e[k] * e[k];
+        else for (int k = 0; k < n; ++k) {
+            double t = e[0] * Sd[k];
+            for (int j = 1; j < n; ++j) t += e[j] * Sd[j * n + k];
+            prod[k] = t * e[k];
+        }
+        out[i] = row_sum(prod, n);
+    }
+}
+/* planner.py:354-438 from node ID toward xt; xs [H][n], us [H][m]; returns the recorded length; Kend = lqr(x_end, u_last)[1] */
+int orc_steer_from(orc* o, int ID, const double* xt, double* xs, double* us, double* Kend) {
+    const int len = steer(o, ID, xt, xs, us);
+    if (len > 0 && Kend) {
+        double tr[4];
+        trig_of(o, xs + (size_t)(len - 1) * o->n, tr);
+        gain(o, xs + (size_t)(len - 1) * o->n, tr, us + (size_t)(len - 1) * o->m, Kend);
+    }
+    return len;
+}
+
 int orc_size(const orc* o) { return o->N; }
 long long orc_iterations(const orc* o) { return o->iterations; }
 long long orc_candidates(const orc* o) { return o->candidates; }

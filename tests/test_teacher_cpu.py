@@ -1,0 +1,128 @@
+"""
+Teacher-forced parity of the ORACLES against runs of the reference itself (CPU).  See tests/teacher.py for
+the method: the reference's own tree prefix is resident and every one of its decisions -- nearest node
+(planner.py:236-247), steer length and end state (planner.py:250-257) -- is replayed on its own.
+
+What this pins that the free-running comparisons (test_coracle_golden.py, test_oracle_golden.py) cannot:
+  * demo_boat_advanced at 3000 and 10 000 nodes (BASELINE config 4): every one of the 10 375 / 36 936 decisions
+    of the reference's run, not just the prefix before the chaotic divergence point;
+  * the tie audit: the car / pendulum fixtures come from a reference whose np.argsort was made stable
+    (tools/ref_loader.py).  The `*_unpatched` fixtures come from the reference with NOTHING patched; replaying
+    them shows that the lowest-id rule differs from numpy's choice only between nodes of bit-equal cost (relative
+    gap exactly 0.0) and that whichever of them is extended, the edge and the new node are the same.
+
+Tolerances: nearest ids exact (or cost gap exactly 0 on the unpatched runs); steer lengths exact; end states 1e-9.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import coracle
+import lqrrt_amd
+import teacher
+from systems_np import SYSTEMS, make_oracle_planner
+
+
+def _load(golden_dir, name, tag):
+    path = os.path.join(golden_dir, "traj_%s_%s.npz" % (name, tag))
+    if not os.path.exists(path):
+        pytest.skip("fixture missing")
+    g = np.load(path)
+    if "xrand_all" not in g.files:
+        pytest.skip("fixture has no teacher data")
+    return g
+
+
+def replay_c(name, g):
+    s = lqrrt_amd.systems.SYSTEMS[name](0)
+    sch = teacher.Schedule(g, s.goal, s.goal_buffer)
+    o = coracle.make(s, len(sch.state) + 8, seed=1)
+    o.load_tree(sch.state, sch.K, sch.pID)
+    near = np.zeros(sch.iters, dtype=np.int64)
+    ln = np.zeros(sch.iters, dtype=np.int64)
+    xe = np.zeros((sch.iters, s.nstates))
+    cur = None
+    for size, a, b in sch.groups():
+        ign = sch.ignored_at(size)
+        if ign is not cur:
+            o.set_ignored(ign)
+            cur = ign
+        for t in range(a, b):
+            near[t] = o.nearest_prefix(sch.xrand[t], size)
+            ln[t], xs, _, _ = o.steer_from(sch.nearest[t], sch.xrand[t])
+            if ln[t] > 0:
+                xe[t] = xs[-1]
+
+    def gap(t):
+        c = o.costs_prefix(sch.xrand[t], sch.size_before[t])
+        a, b = c[near[t]], c[sch.nearest[t]]
+        return abs(a - b) / max(abs(a), abs(b), 1e-300)
+    return sch, teacher.summarize("c-oracle/%s" % name, sch, near, ln, xe, gap)
+
+
+@pytest.mark.parametrize("name,tag", [("boat_advanced", "3000"), ("boat_advanced", "10k"), ("car", "500"),
+                                       ("car", "2000"), ("pendulum", "150")])
+def test_c_oracle_teacher_forced(golden_dir, name, tag):
+    g = _load(golden_dir, name, tag)
+    sch, r = replay_c(name, g)
+    print(r)
+    assert r["iterations"] == int(g["iterations"])
+    assert r["nearest_miss"] == 0
+    assert r["steer_len_mismatch"] == 0
+    assert r["end_state_compared"] == len(sch.state) - 1          # every node of the reference's tree was reproduced
+    assert r["end_state_max_err"] < 1e-9
+
+
+@pytest.mark.parametrize("name,tag", [("car", "500"), ("car", "2000"), ("pendulum", "150")])
+def test_tie_audit_unpatched_reference(golden_dir, name, tag):
+    """numpy's own argsort vs the lowest-id rule: they may only differ between nodes of bit-equal cost."""
+    g = _load(golden_dir, name, tag + "_unpatched")
+    assert not bool(g["stable_ties"])
+    patched = _load(golden_dir, name, tag)
+    sch, r = replay_c(name, g)
+    print(r)
+    assert r["nearest_miss"] > 0, "the unpatched run is expected to pick other nodes among equal costs somewhere"
+    assert r["nearest_miss_max_rel_gap"] == 0.0                    # ... and only there
+    assert r["steer_len_mismatch"] == 0 and r["end_state_max_err"] < 1e-9
+    # the two runs build the same SET of states with the same edges; only the parent chosen among equals differs
+    assert int(g["iterations"]) == int(patched["iterations"]) and int(g["n_candidates"]) == int(patched["n_candidates"])
+    np.testing.assert_array_equal(g["state"], patched["state"])
+    np.testing.assert_array_equal(g["edge_len"], patched["edge_len"])
+    diff = np.flatnonzero(g["pID"] != patched["pID"])
+    assert len(diff) > 0
+    a, b = g["state"][g["pID"][diff]], patched["state"][patched["pID"][diff]]
+    np.testing.assert_array_equal(a, b)                            # the different parents are the same state
+    # known answers of SURVEY.md 8c (unpatched reference on this box)
+    if (name, tag) == ("car", "500"):
+        assert str(g["pid_hash"]) == "219124599a587d8c" and str(patched["pid_hash"]) == "0c64b54cdd315792"
+
+
+@pytest.mark.parametrize("name,tag", [("car", "500_unpatched"), ("pendulum", "150_unpatched"), ("boat_advanced", "3000")])
+def test_numpy_oracle_teacher_forced(golden_dir, name, tag):
+    """Same replay through the NumPy oracle's _costs_to_go / _steer (the reference's arithmetic, so bit-equal on the
+    generating machine): all decisions of the short runs, a sample of the long one."""
+    from lqrrt_oracle import RefTree
+    g = _load(golden_dir, name, tag)
+    s = SYSTEMS[name](0)
+    sch = teacher.Schedule(g, s.goal, s.goal_buffer)
+    p = make_oracle_planner(s, len(sch.state) + 8)
+    tree = RefTree(sch.state[0], (None, sch.K[0]))
+    tree.lqr = [(None, k) for k in sch.K]
+    p.tree = tree
+    rng = np.random.RandomState(3)
+    picks = np.arange(sch.iters) if sch.iters <= 1000 else np.sort(rng.choice(sch.iters, 300, replace=False))
+    worst = 0.0
+    for t in picks:
+        size = int(sch.size_before[t])
+        tree.state, tree.size = sch.state[:size], size
+        c = p._costs_to_go(np.copy(sch.xrand[t]))
+        ign = sch.ignored_at(size)[:size].astype(bool)
+        mine = int(np.argmin(c if ign.all() else np.where(ign, np.inf, c)))      # lowest id among equal costs
+        ref = int(sch.nearest[t])
+        assert mine == ref or c[mine] == c[ref], (t, mine, ref)
+        xs, us = p._steer(ref, np.copy(sch.xrand[t]))
+        assert len(xs) == int(sch.steer_len[t]), t
+        if len(xs):
+            worst = max(worst, float(np.abs(xs[-1] - sch.state[sch.new_node[t]]).max()))
+    assert worst < 1e-9

@@ -148,20 +148,25 @@ def gen_ops(name):
 # --------------------------------------------------------------------------- trajectory level
 
 def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None, horizon=None, pruning=True, tries=10, guide=None,
-             finish_on_goal=False):
+             finish_on_goal=False, teacher=False, stable_ties=True):
+    """teacher=True additionally stores EVERY iteration's xrand and tie flag (`xrand_all`, `tie_mask`), which is what the
+    teacher-forced parity tests replay decision by decision.  stable_ties=False runs the reference with numpy's own
+    (unspecified) argsort tie order, i.e. with nothing patched at all."""
+    rl.TIES_STABLE = stable_ties
     ns = rl.load_demo(name, OBS_SEED)
     planner = rl.make_planner(name, ns, max_nodes, min_time=min_time)
     if horizon is not None:
         planner.set_resolution(horizon=horizon)            # (min, max) -> adaptive-horizon heuristic
     n = ns["nstates"]
 
-    xrands, nearest, slen, ties = [], [], [], []
+    xrands, nearest, slen, ties, tie_any = [], [], [], [], []
     ctg, steer = planner._costs_to_go, planner._steer
 
     def ctg_spy(x):
         xrands.append(np.copy(x))
         c = ctg(x)
         ties.append(int(np.sum(c == c.min())) > 1)
+        tie_any.append(len(np.unique(c)) < len(c))
         return c
 
     def steer_spy(ID, xtar, force_arrive=False):
@@ -208,7 +213,12 @@ def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None, horizon=N
         tie_iterations=np.int64(np.sum(ties)), horizon_iters_final=np.int64(planner.horizon_iters),
         pruning=np.bool_(pruning), tries=np.int64(tries), finish_on_goal=np.bool_(finish_on_goal),
         guide=np.array(guide if guide is not None else [], dtype=np.float64),
+        stable_ties=np.bool_(stable_ties),
     )
+    if teacher:
+        out["xrand_all"] = np.array(xrands, dtype=np.float64)
+        out["tie_mask"] = np.array(ties, dtype=np.bool_)          # the MINIMUM cost is shared by several nodes
+        out["tie_any_mask"] = np.array(tie_any, dtype=np.bool_)   # some cost value (not nec. the minimum) is repeated
     # a few complete edges (first, a middle one, the last) to pin x_seq/u_seq contents
     for tagid, ID in (("a", 1), ("b", tree.size // 2), ("c", tree.size - 1)):
         out["edge_%s_id" % tagid] = np.int32(ID)
@@ -361,11 +371,28 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--long", action="store_true", help="also run boat_advanced to 10k nodes (~20 min)")
     ap.add_argument("--only", default=None, help="comma list: ops,traj")
+    ap.add_argument("--job", default=None, help="one teacher / tie-audit job: adv10k, adv3000, car500u, car2000u, pend150u, "
+                                                "car500t, car2000t, pend150t (u = unpatched reference, t = teacher data of the patched run)")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     what = set((args.only or "ops,traj").split(","))
+    jobs = {
+        # every iteration's xrand next to nearest / steer_len: input of the teacher-forced parity tests
+        "adv10k": lambda: run_traj("boat_advanced", 10000, keep_xrand=64, tag="10k", teacher=True),
+        "adv3000": lambda: run_traj("boat_advanced", 3000, keep_xrand=64, teacher=True),
+        "car500t": lambda: run_traj("car", 500, teacher=True),
+        "car2000t": lambda: run_traj("car", 2000, keep_xrand=64, teacher=True),
+        "pend150t": lambda: run_traj("pendulum", 150, teacher=True),
+        # the reference with NOTHING patched (numpy's own argsort tie order): the tie audit
+        "car500u": lambda: run_traj("car", 500, keep_xrand=64, tag="500_unpatched", teacher=True, stable_ties=False),
+        "car2000u": lambda: run_traj("car", 2000, keep_xrand=64, tag="2000_unpatched", teacher=True, stable_ties=False),
+        "pend150u": lambda: run_traj("pendulum", 150, keep_xrand=64, tag="150_unpatched", teacher=True, stable_ties=False),
+    }
+    if args.job:
+        jobs[args.job]()
+        return
     if args.long:
-        run_traj("boat_advanced", 10000, keep_xrand=64, tag="10k")
+        jobs["adv10k"]()
         return
     if "ops" in what:
         for name in rl.DEMOS:

@@ -62,8 +62,14 @@ class _StableSortNumpy(object):
         return self._real.argsort(a, *args, **kwargs)
 
 
-def import_reference(stable_ties=True):
-    """Returns the reference `lqrrt` module (Constraints, Planner)."""
+TIES_STABLE = True     # module-wide default for import_reference(); tools/gen_golden.py flips it for the unpatched runs
+
+
+def import_reference(stable_ties=None):
+    """Returns the reference `lqrrt` module (Constraints, Planner).  stable_ties=False leaves the reference's
+    planner module entirely untouched (numpy's own argsort)."""
+    if stable_ties is None:
+        stable_ties = TIES_STABLE
     if not os.path.isdir(REF):
         raise RuntimeError("reference tree not present at %s (build container only)" % REF)
     for p in (os.path.join(REF, "lqrrt"), REF):
