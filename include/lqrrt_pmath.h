@@ -27,7 +27,7 @@
 
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define LQ_HD __host__ __device__ __forceinline__
 #else
 #define LQ_HD static inline

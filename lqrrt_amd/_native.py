@@ -115,24 +115,11 @@ class NativeError(RuntimeError):
         self.code = code
 
 
-def _try_build():
-    """The library is built in-tree by __graft_entry__.build(); if it is absent and the toolchain is here, build it
-    now (a minute of hipcc).  Never a CPU path: without the library every call raises."""
-    root = os.path.dirname(_HERE)
-    entry = os.path.join(root, "__graft_entry__.py")
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if os.path.exists(entry) and os.path.exists(hipcc):
-        import subprocess
-        import sys
-        subprocess.call([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import __graft_entry__ as g; g.build()" % root])
-
-
 def lib():
-    """Loads liblqrrt_hip.so (once).  Raises if it has not been built and cannot be."""
+    """Loads liblqrrt_hip.so (once).  Raises if it has not been built: the library is never compiled implicitly
+    (least of all inside a planning call) and there is no CPU path to fall back to."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            _try_build()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 "lqrrt_amd: %s is missing -- build the HIP extension first "
@@ -166,6 +153,14 @@ def check(rc):
 
 def device_count():
     return lib().lqrrt_device_count()
+
+
+def available():
+    """True when the HIP library is built and a device is visible (compute calls can succeed)."""
+    try:
+        return os.path.exists(LIB_PATH) and device_count() >= 1
+    except (OSError, RuntimeError):
+        return False
 
 
 def require_device():

@@ -37,6 +37,7 @@ class Engine(object):
             S = nat.as_f64(system.S, (self.n, self.n))
             nat.check(nat.lib().lqrrt_engine_set_dense_S(self.h, nat.ptr(S)))
         self.horizon_iters = None
+        self.generation = 0           # bumped whenever the tree is replaced (reset / load): Tree views check it
 
     def _stream(self):
         """torch's current HIP stream on THIS engine's device."""
@@ -131,6 +132,7 @@ class Engine(object):
     def tree_reset(self, x0):
         x0 = nat.as_f64(x0, (self.n,))
         nat.check(nat.lib().lqrrt_tree_reset(self.h, nat.ptr(x0), self._stream()))
+        self.generation += 1
 
     def tree_load(self, states, K, pID, edge_len=None, xedge=None, uedge=None, ignored=None):
         """Puts an existing tree on the device (lqrrt_tree_load): states (N, n), K (N, m, n), pID (N,), optionally the
@@ -157,6 +159,7 @@ class Engine(object):
         nat.check(nat.lib().lqrrt_tree_load(self.h, N, nat.ptr(states), nat.ptr(K), nat.ptr(pID), el,
                                             opt(xedge, np.float64, (rows, self.n)), opt(uedge, np.float64, (rows, self.m)),
                                             opt(ignored, np.uint8, (N,)), self._stream()))
+        self.generation += 1
 
     def tree_truncate(self, size):
         nat.check(nat.lib().lqrrt_tree_truncate(self.h, int(size)))

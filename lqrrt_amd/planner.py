@@ -1,26 +1,22 @@
 """
-Planner -- drop-in for the reference's lqrrt.Planner (lqrrt/planner.py) whose extend path
-runs on an MI355X.
+Planner -- drop-in for the reference's lqrrt.Planner (lqrrt/planner.py) whose extend path runs on an MI355X.
 
-Create an instance of Planner and then call update_plan to generate a plan internal to the
-instance.  To get the state or effort at some time t, use get_state(t) and get_effort(t).
+Same as the reference: constructor / update_plan / set_* / kill_update / unkill signatures, result attributes
+(tree, node_seq, x_seq, u_seq, t_seq, T, plan_reached_goal, get_state, get_effort), which arguments raise
+ValueError and with which message, and update_plan's return value.
 
-What is the same as the reference: constructor / update_plan / set_* / kill_update / unkill
-signatures, result attributes (tree, node_seq, x_seq, u_seq, t_seq, T, plan_reached_goal,
-get_state, get_effort), ValueError conventions and return values.
+Different: the loop body of planner.py:233-290 (sample, cost-to-go nearest neighbour, LQR-policy steer with a
+feasibility sweep per step, tree append, goal test) is executed by the HIP engine (csrc/engine.hip) in WAVES of
+up to `wave_size` samples.  In 'exact' mode, the default, a wave's outcome is the one the samples would have
+produced one after another: all samples are first evaluated against the tree as of the start of the wave, then
+each is re-checked against the nodes accepted earlier in the same wave and the few whose true parent was born
+inside the wave are steered again, to the fix-point.  'synchronous' mode skips that validation (every sample of
+a wave of exactly `wave_size` sees the wave-start tree): not the reference's tree any more but the one
+oracle/lqrrt_oracle.c's orc_extend_sync defines, several times faster.
 
-What is different: the per-iteration loop body (planner.py:233-290: sample, cost-to-go
-nearest neighbour, LQR-policy steer with feasibility sweep, tree append, goal test) is
-executed by the HIP engine in *waves* of up to `wave_size` samples.  In exact mode (the
-default) a wave's result is identical to running its samples one after another: every sample is
-first evaluated against the tree as it stood at the start of the wave, then the engine
-re-checks each sample against the nodes accepted earlier in the same wave and re-steers the
-few whose true parent was born inside the wave, iterating to the fix-point
-(csrc/engine.hip).  wave_mode='synchronous' drops that validation: all samples of a wave (exactly
-`wave_size` of them) see the tree as of the start of the wave -- not the reference's tree any more, but
-the one oracle/lqrrt_oracle.c's orc_extend_sync defines, and several times faster.
-dynamics / lqr / erf / is_feasible must be the plugin handles
-of a native system (lqrrt_amd.systems); arbitrary Python callables raise ValueError.
+dynamics / lqr / erf / is_feasible must be the plugin handles of ONE native system object
+(lqrrt_amd.systems); a GPU cannot call back into Python, so arbitrary callables raise ValueError.
+There is no CPU path: without the HIP library and a device, update_plan raises.
 """
 from __future__ import division
 
@@ -36,34 +32,21 @@ from .systems import plugin_system
 from .tree import Tree
 
 
+def _callable(f):
+    return hasattr(f, '__call__')
+
+
 class Planner:
     """
-    To initialize, provide...
-
-    dynamics, lqr: the `.dynamics` and `.lqr` handles of an lqrrt_amd.systems object
-                   (same call signatures as the reference: xnext = dynamics(x, u, dt),
-                   (S, K) = lqr(x, u)).
-
-    constraints: Instance of the Constraints class (feasibility, goal region).
-
-    horizon: The simulation duration in seconds used to extend the tree.
-
-    dt: The simulation timestep in seconds used to extend the tree.
-
-    FPR: Failed Path Retention factor.
-
-    error_tol: The state error array or scalar defining controller convergence.
-
-    erf: the `.erf` handle of the same system object.
-
-    min_time, max_time, max_nodes, goal0, sys_time, printing: as in the reference.
-
-    wave_size: (new, optional) upper bound on the samples evaluated per wave.
-
-    wave_mode: (new, optional) 'exact' (default, the reference's sequential result) or 'synchronous'.
-
-    device: (new, optional) HIP device ordinal.
-
+    dynamics, lqr, erf: handles of an lqrrt_amd.systems object, called like the reference's plugins
+        (xnext = dynamics(x, u, dt);  (S, K) = lqr(x, u);  e = erf(xgoal, x)).
+    constraints: a Constraints instance (feasibility handle of the same system, goal buffer).
+    horizon: seconds simulated per tree extension, or (min, max) for the adaptive heuristic.
+    dt: simulation step [s].   FPR: failed-path retention factor (planner.py:394-395).
+    error_tol: state error (scalar or per state) below which a steer counts as converged.
+    min_time, max_time, max_nodes, goal0, sys_time, printing: as in the reference (planner.py:61-82).
+    wave_size, wave_mode, device: new and optional -- samples per wave (upper bound), 'exact' | 'synchronous',
+        HIP device ordinal.
     """
 
     def __init__(self, dynamics, lqr, constraints,
@@ -72,34 +55,38 @@ class Planner:
                  min_time=0.5, max_time=1, max_nodes=1E5,
                  goal0=None, sys_time=time.time, printing=True,
                  wave_size=1024, device=0, wave_mode='exact'):
-
-        self.device = device
-        self.wave_size = int(wave_size)
         if wave_mode not in ('exact', 'synchronous'):
             raise ValueError("wave_mode must be 'exact' or 'synchronous'")
-        self.wave_mode = wave_mode
-        self._engine = None
-        self._engine_key = None
-
+        self.device, self.wave_size, self.wave_mode = device, int(wave_size), wave_mode
+        self._engine = self._engine_key = None
+        self.tree = None
         self.set_system(dynamics, lqr, constraints, erf)
-
         self.set_resolution(horizon, dt, FPR, error_tol)
-
         self.set_runtime(min_time, max_time, max_nodes, sys_time)
-
         self.set_goal(goal0)
-
         self.printing = printing
         self.killed = False
         self.stats = None
+        self.warm_up()
 
-#################################################
+    # ------------------------------------------------------------------------------------------ engine
+    def warm_up(self):
+        """Creates the device engine (HBM pools sized by max_nodes, geometry upload) ahead of the first update_plan,
+        so that none of it is charged to a plan's time budget.  Quietly does nothing where there is no GPU or no
+        built library: constructing and configuring a Planner works anywhere, planning does not."""
+        try:
+            if nat.available():
+                self._get_engine()
+        except (nat.NativeError, RuntimeError, OSError):
+            self._engine = self._engine_key = None
 
     def _get_engine(self):
-        """(Re)creates the native engine when the system or the capacity changed."""
+        """The native engine for the current system / capacity / device (recreated when one of them changed)."""
         capacity = int(self.max_nodes) + self.wave_size + 8
         key = (id(self.system), capacity, self.wave_size, self.device)
         if self._engine is None or self._engine_key != key:
+            if self.tree is not None:
+                self.tree._detach()
             if self._engine is not None:
                 self._engine.close()
             self._engine = Engine(self.system, capacity=capacity, max_wave=self.wave_size, device=self.device)
@@ -108,77 +95,66 @@ class Planner:
         self._engine.set_wave_mode(self.wave_mode)
         return self._engine
 
+    # ------------------------------------------------------------------------------------------ planning
     def update_plan(self, x0, sample_space, goal_bias=0,
                     guide=None, xrand_gen=None, pruning=True,
                     finish_on_goal=False, specific_time=None):
         """
-        A new tree is grown from the seed x0 in an attempt to plan a path to the goal
-        (planner.py:104-336).  Arguments and return value as in the reference; xrand_gen may
-        be None or an integer >= 1 (tries allowed for a feasible random sample).
+        Grows a new tree from the seed x0 toward the goal and extracts a plan from it (planner.py:104-336);
+        arguments as in the reference.  xrand_gen: None, an integer >= 1 (tries allowed per feasible random sample)
+        or a function of the planner returning a sample.
 
-        Returns True if it finished fully, or False if it was haulted (killed, tree exceeded
-        max_nodes, or no goal set).
+        Returns True if it ran to completion, False if it was halted (killed, tree larger than max_nodes, no goal).
         """
-        # Safety first!
         x0 = np.array(x0, dtype=np.float64)
         if self.goal is None:
             print("No goal has been set yet!")
             self.get_state = lambda t: x0
             self.get_effort = lambda t: np.zeros(self.ncontrols)
             return False
+        min_time, max_time = (self.min_time, self.max_time) if specific_time is None else (specific_time, specific_time)
 
-        if specific_time is None:
-            min_time = self.min_time
-            max_time = self.max_time
+        user_sampler = not (xrand_gen is None or type(xrand_gen) is int)
+        if user_sampler:
+            # planner.py:213-216.  The function is called once per sample, in order, but a batch ahead of the wave that
+            # consumes the samples: it sees the tree as of the batch start, not of the previous iteration (documented
+            # deviation; the default sampler never looks at the tree).
+            if not _callable(xrand_gen):
+                raise ValueError("Expected xrand_gen to be None, an integer >= 1,  or a function.")
         else:
-            min_time = specific_time
-            max_time = specific_time
-
-        # Default sampler description (planner.py:176-198)
-        if xrand_gen is None or type(xrand_gen) is int:
+            # description of the default sampler (planner.py:176-198)
             if goal_bias is None:
-                goal_bias = [0] * self.nstates
+                bias = np.zeros(self.nstates)
             elif hasattr(goal_bias, '__contains__'):
                 if len(goal_bias) != self.nstates:
                     raise ValueError("Expected goal_bias to be scalar or have same length as state.")
+                bias = np.array(goal_bias, dtype=np.float64)
             else:
-                goal_bias = [goal_bias] * self.nstates
+                bias = np.full(self.nstates, goal_bias, dtype=np.float64)
             tries_limit = xrand_gen if (xrand_gen is not None and xrand_gen > 0) else 10
-            sample_space = np.array(sample_space, dtype=np.float64)
-            if sample_space.shape != (self.nstates, 2):
+            space = np.array(sample_space, dtype=np.float64)
+            if space.shape != (self.nstates, 2):
                 raise ValueError("Expected sample_space to be list of nstates tuples.")
-            sampling_centers = np.mean(sample_space, axis=1)
-            sampling_spans = np.diff(sample_space).flatten()
-        else:
-            # A user sampling function (planner.py:213-216).  It is called once per sample, in order, but a
-            # whole batch ahead of the wave that consumes it, so it sees the tree as of the batch start
-            # rather than of the previous iteration (documented deviation; the default sampler never looks
-            # at the tree, so it is unaffected).
-            if not hasattr(xrand_gen, '__call__'):
-                raise ValueError("Expected xrand_gen to be None, an integer >= 1,  or a function.")
 
-        # Store guide state
-        if guide is None:
-            self.xguide = np.copy(self.goal)
-        else:
-            self.xguide = np.array(guide, dtype=np.float64)
+        self.xguide = np.copy(self.goal) if guide is None else np.array(guide, dtype=np.float64)
 
-        # Reset the tree on the device (planner.py:172)
+        # the device tree is about to be overwritten: a Tree object from the previous plan keeps its contents
+        if self.tree is not None:
+            self.tree._detach()
         eng = self._get_engine()
         if self.hfactor:
-            # adaptive horizon: rollouts go to hspan[1] steps (see include/lqrrt_hip.h, lqrrt_resolution.adaptive)
-            eng.set_resolution(self.dt, self.FPR, int(self.hspan[1]), self.error_tol, self.goal,
-                               self.constraints.goal_buffer, adaptive=True, hspan_min=int(self.hspan[0]),
-                               horizon_iters_state=int(self.horizon_iters))
+            # adaptive horizon: rollouts may run hspan[1] steps (include/lqrrt_hip.h, lqrrt_resolution.adaptive)
+            eng.set_resolution(self.dt, self.FPR, int(self.hspan[1]), self.error_tol, self.goal, self.constraints.goal_buffer,
+                               adaptive=True, hspan_min=int(self.hspan[0]), horizon_iters_state=int(self.horizon_iters))
         else:
-            eng.set_resolution(self.dt, self.FPR, self.horizon_iters, self.error_tol, self.goal,
-                               self.constraints.goal_buffer)
-        eng.tree_reset(x0)
-        user_sampler = hasattr(xrand_gen, '__call__')
+            eng.set_resolution(self.dt, self.FPR, self.horizon_iters, self.error_tol, self.goal, self.constraints.goal_buffer)
+        eng.tree_reset(x0)                                          # planner.py:172
         if not user_sampler:
-            eng.set_sampler(sampling_centers, sampling_spans, np.array(goal_bias, dtype=np.float64), tries_limit)
+            eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), bias, tries_limit)
             eng.seed_from_numpy_global()
-        self.tree = Tree(eng)
+        S0 = self.system.Smatrix()
+        self.tree = Tree(x0, (S0, np.zeros((self.ncontrols, self.nstates))))
+        self.tree._bind(eng, S0)
 
         if self.printing:
             print("\n...planning...")
@@ -188,22 +164,30 @@ class Planner:
         time_start = self.sys_time()
         best_end = -1
         total = None
+        rate = None                                                 # attempts per second of real time, measured
+        adopted = False
 
-        # Planning loop: each native call grows the tree by a few waves and returns at every goal hit
+        # Each native call grows the tree by a few waves and returns at every goal hit.  The clock and the kill flag
+        # are looked at between calls, so a call is sized to what the time budget still allows.
         while True:
-            budget = 4 * self.wave_size
+            exit_at = min_time if self.plan_reached_goal else max_time
+            budget = self._attempt_budget(rate, exit_at - time_elapsed)
             if user_sampler:
                 missing = budget - eng.queued_samples()
                 if missing > 0:
                     eng.push_samples(np.array([np.array(xrand_gen(self), dtype=np.float64) for _ in range(missing)]))
+            t_call = time.perf_counter()
             st = eng.extend(self.wave_size, max_attempts=budget, node_limit=int(self.max_nodes),
                             pruning=pruning, stop_on_goal=True)
+            dt_call = time.perf_counter() - t_call
+            if st.attempts > 0 and dt_call > 0:
+                rate = st.attempts / dt_call if rate is None else 0.5 * rate + 0.5 * st.attempts / dt_call
             total = st if total is None else _add_stats(total, st)
 
             if st.goal_hits:
                 self.plan_reached_goal = True
                 end, steps, _ = eng.plan_best()
-                if end != best_end:                    # a faster plan was found (planner.py:276)
+                if end != best_end:                                 # a faster plan (planner.py:276)
                     best_end = end
                     self.T = steps * self.dt
                     if self.printing:
@@ -213,24 +197,22 @@ class Planner:
 
             if self.killed:
                 break
-
-            elif self.plan_reached_goal and time_elapsed >= min_time:
+            if self.plan_reached_goal and time_elapsed >= min_time:
                 self._adopt_plan(best_end)
+                adopted = True
                 if finish_on_goal:
                     self._finish_on_goal()
                 if self.printing:
                     print("Tree size: {0}\nETA: {1} s".format(self.tree.size, np.round(self.T, 2)))
                 self._prepare_interpolators()
                 break
-
-            elif time_elapsed >= max_time or self.tree.size > self.max_nodes:
-                # Find closest node to guide state (planner.py:311-323)
+            if time_elapsed >= max_time or self.tree.size > self.max_nodes:
+                # no goal hit (or not enough time spent): plan to the node nearest the guide state (planner.py:311-323)
                 Sguide = np.array(self.system.Smatrix(), dtype=np.float64)
-                for i, g in enumerate(self.constraints.goal_buffer):
-                    if np.isinf(g):
-                        Sguide[:, i] = 0
+                Sguide[:, np.isinf(np.asarray(self.constraints.goal_buffer, dtype=np.float64))] = 0
                 ids, _ = eng.nn_argmin(self.xguide.reshape(1, -1), S=Sguide, use_ignore=False)
                 self._adopt_plan(int(ids[0]))
+                adopted = True
                 if self.printing:
                     print("Didn't reach goal.\nTree size: {0}\nETA: {1} s".format(self.tree.size, np.round(self.T, 2)))
                 self._prepare_interpolators()
@@ -239,23 +221,35 @@ class Planner:
         if not user_sampler:
             eng.sync_numpy_global()
         if self.hfactor:
-            self.horizon_iters = eng.horizon_iters_state()       # planner.py:421,424: the heuristic's state persists
+            self.horizon_iters = eng.horizon_iters_state()           # planner.py:421,424: the heuristic's state persists
         self.stats = total.as_dict() if total is not None else None
 
         if self.killed or self.tree.size > self.max_nodes:
-            if self.killed and best_end >= 0 and not hasattr(self, "node_seq"):
+            # The reference keeps node_seq / x_seq / u_seq / t_seq up to date inside the loop (planner.py:276-281), so
+            # after a kill they describe the best plan of THIS tree whenever one was found.
+            if self.killed and not adopted and best_end >= 0:
                 self._adopt_plan(best_end)
             if self.printing:
                 print("Plan update terminated abruptly!")
             self.killed = False
             return False
-        else:
-            return True
+        return True
 
-#################################################
+    def _attempt_budget(self, rate, remaining):
+        """Attempts the next native call may commit: at most 4 waves, at most what fits in about half of the time left
+        at the measured throughput, at least a small wave.  Before a rate is known: one wave."""
+        cap = 4 * self.wave_size
+        if rate is None:
+            return min(cap, self.wave_size)
+        if not np.isfinite(remaining):
+            return cap
+        budget = int(min(cap, max(32, 0.5 * rate * max(float(remaining), 0.0))))
+        if self.wave_mode == 'synchronous':                        # whole waves only: the wave size defines the result
+            budget = max(self.wave_size, budget // self.wave_size * self.wave_size)
+        return budget
 
     def _adopt_plan(self, end_node):
-        """Climb + trajectory for the chosen end node (planner.py:266-281 / :319-323)."""
+        """The plan that ends in `end_node`: climb to the seed, lay the edges end to end (planner.py:266-281, :319-323)."""
         self.node_seq = self.tree.climb(end_node)
         self.x_seq, self.u_seq = self.tree.trajectory(self.node_seq)
         self.T = len(self.x_seq) * self.dt
@@ -263,20 +257,20 @@ class Planner:
 
     def _finish_on_goal(self):
         """
-        planner.py:294-303: steer from the plan's last node to the exact goal (force_arrive) and, if that
-        produced anything, tack it onto the plan and the tree.  The reference stops this rollout on a
-        wall-clock timeout of clip(min_time/2, 0.1, inf) seconds (:402-406); here the same budget is turned
-        into a step cap at the reference's measured ~0.3 ms per simulated step, which is deterministic.
+        planner.py:294-303: steer from the plan's last node to the exact goal (force_arrive) and, if that produced
+        anything, tack it onto the plan and the tree.  The reference ends this rollout on a wall-clock timeout of
+        clip(min_time/2, 0.1, inf) seconds (:402-406); here the same budget becomes a step cap at the reference's
+        measured ~0.3 ms per simulated step, which is deterministic.
         """
         budget_s = float(np.clip(self.min_time / 2, 0.1, np.inf))
         max_steps = int(min(max(budget_s / 3e-4, 64), 20000))
         if getattr(self, "force_arrive_max_steps", None):
-            max_steps = int(self.force_arrive_max_steps)        # explicit override of the timeout stand-in
+            max_steps = int(self.force_arrive_max_steps)            # explicit override of the timeout stand-in
         xgoal_seq, ugoal_seq = self._engine.steer_force(self.node_seq[-1], self.goal, max_steps)
         if len(xgoal_seq) == max_steps and self.printing:
             print("(exact goal-convergence timed-out)")
         if len(xgoal_seq) > 0:
-            xs, us = [row for row in xgoal_seq], [row for row in ugoal_seq]
+            xs, us = list(xgoal_seq), list(ugoal_seq)
             self.tree.add_node(self.node_seq[-1], self.goal, None, xs, us)
             self.node_seq.append(self.tree.size - 1)
             self.x_seq.extend(xs)
@@ -284,163 +278,116 @@ class Planner:
             self.t_seq = np.arange(len(self.x_seq)) * self.dt
 
     def _in_goal(self, x):
-        """Returns True if some state x is in the goal region (planner.py:442-447)."""
-        return all(goal_span[0] < v < goal_span[1] for goal_span, v in zip(self.goal_region, x))
+        """True if x lies strictly inside the goal box (planner.py:442-447)."""
+        x = np.asarray(x, dtype=np.float64)
+        lo, hi = np.array(self.goal_region, dtype=np.float64).T
+        return bool(np.all((lo < x) & (x < hi)))
 
     def _prepare_interpolators(self):
-        """Updates the interpolator functions the user calls (planner.py:451-464)."""
+        """get_state(t) / get_effort(t) over the current plan; held at the last sample beyond its end (planner.py:451-464)."""
         if len(self.x_seq) == 1:
-            self.get_state = lambda t: self.x_seq[0]
-            self.get_effort = lambda t: np.zeros(self.ncontrols)
-        else:
-            self.get_state = scipy.interpolate.interp1d(self.t_seq, np.array(self.x_seq), axis=0, assume_sorted=True,
-                                                        bounds_error=False, fill_value=self.x_seq[-1][:])
-            self.get_effort = scipy.interpolate.interp1d(self.t_seq, np.array(self.u_seq), axis=0, assume_sorted=True,
-                                                         bounds_error=False, fill_value=self.u_seq[-1][:])
+            only, zero = self.x_seq[0], np.zeros(self.ncontrols)
+            self.get_state = lambda t: only
+            self.get_effort = lambda t: zero
+            return
+        for name, seq in (("get_state", self.x_seq), ("get_effort", self.u_seq)):
+            table = np.array(seq)
+            setattr(self, name, scipy.interpolate.interp1d(self.t_seq, table, axis=0, assume_sorted=True,
+                                                           bounds_error=False, fill_value=table[-1].copy()))
 
-#################################################
-
+    # ------------------------------------------------------------------------------------------ setters
     def set_goal(self, goal):
-        """
-        Modifies the goal state and region (planner.py:468-487).
-        Be sure to update the plan after modifying the goal.
-        """
+        """New goal state and goal region (planner.py:468-487); update the plan afterwards."""
         if goal is None:
             self.goal = None
-        else:
-            if len(goal) == self.nstates:
-                self.goal = np.array(goal, dtype=np.float64)
-            else:
-                raise ValueError("The goal state must have same dimensionality as state space.")
-
-            goal_region = []
-            for i, buff in enumerate(self.constraints.goal_buffer):
-                goal_region.append((self.goal[i] - buff, self.goal[i] + buff))
-
-            self.goal_region = goal_region
-            self.plan_reached_goal = False
-
-#################################################
+            return
+        if len(goal) != self.nstates:
+            raise ValueError("The goal state must have same dimensionality as state space.")
+        self.goal = np.array(goal, dtype=np.float64)
+        buff = np.asarray(self.constraints.goal_buffer, dtype=np.float64)
+        self.goal_region = list(zip(self.goal - buff, self.goal + buff))
+        self.plan_reached_goal = False
 
     def set_runtime(self, min_time=None, max_time=None, max_nodes=None, sys_time=None):
-        """Arguments not given are not modified (planner.py:491-513)."""
-        if min_time is not None:
-            self.min_time = min_time
-
-        if max_time is not None:
-            self.max_time = max_time
-
-        if self.min_time > self.max_time:
+        """planner.py:491-513; arguments left at None keep their value."""
+        if sys_time is not None and not _callable(sys_time):
+            raise ValueError("Expected sys_time to be a function.")
+        lo = self.min_time if min_time is None else min_time
+        hi = self.max_time if max_time is None else max_time
+        self.min_time, self.max_time = lo, hi
+        if lo > hi:
             raise ValueError("The min_time must be less than or equal to the max_time.")
-
         if max_nodes is not None:
             self.max_nodes = max_nodes
-
         if sys_time is not None:
-            if hasattr(sys_time, '__call__'):
-                self.sys_time = sys_time
-            else:
-                raise ValueError("Expected sys_time to be a function.")
-
-#################################################
+            self.sys_time = sys_time
 
     def set_resolution(self, horizon=None, dt=None, FPR=None, error_tol=None):
-        """Arguments not given are not modified (planner.py:517-553)."""
-        if horizon is not None:
-            self.horizon = horizon
-
-        if dt is not None:
-            self.dt = dt
-
-        if FPR is not None:
-            self.FPR = FPR
-
+        """planner.py:517-553; arguments left at None keep their value.  horizon may be a (min, max) pair, which
+        switches the adaptive-horizon heuristic on (hfactor = 2, starting from one step)."""
+        for name, value in (("horizon", horizon), ("dt", dt), ("FPR", FPR)):
+            if value is not None:
+                setattr(self, name, value)
         if error_tol is not None:
-            if np.shape(error_tol) in [(), (self.nstates,)]:
-                self.error_tol = np.abs(error_tol).astype(np.float64)
-            else:
+            if np.shape(error_tol) not in [(), (self.nstates,)]:
                 raise ValueError("Shape of error_tol must be scalar or length of state.")
-
+            self.error_tol = np.abs(error_tol).astype(np.float64)
         if hasattr(self.horizon, '__contains__'):
             if len(self.horizon) != 2:
                 raise ValueError("Expected horizon to be tuple (min, max) or a single scalar.")
-            if self.horizon[0] < self.dt:
+            shortest, longest = self.horizon
+            if shortest < self.dt:
                 raise ValueError("The minimum horizon must be at least as big as dt.")
-            if self.horizon[0] >= self.horizon[1]:
+            if shortest >= longest:
                 raise ValueError("A horizon range tuple must be given as (min, max) where min < max.")
-            self.horizon_iters = 1
             self.hspan = np.divide(self.horizon, self.dt).astype(np.int64)
-            self.hfactor = int(2)
-        elif self.horizon >= self.dt:
-            self.horizon_iters = int(self.horizon / self.dt)
-            self.hspan = (self.horizon_iters, self.horizon_iters)
-            self.hfactor = 0
+            self.horizon_iters, self.hfactor = 1, 2
         else:
-            raise ValueError("The horizon must be at least as big as dt.")
-
-#################################################
+            if self.horizon < self.dt:
+                raise ValueError("The horizon must be at least as big as dt.")
+            steps = int(self.horizon / self.dt)
+            self.horizon_iters, self.hspan, self.hfactor = steps, (steps, steps), 0
 
     def set_system(self, dynamics=None, lqr=None, constraints=None, erf=None):
         """
-        Arguments not given are not modified (planner.py:557-592).
-        If dynamics gets modified, so must lqr (and vis versa).  All handles must come from
-        the same native system object.
+        planner.py:557-592; arguments left at None keep their value, and dynamics and lqr can only be replaced
+        together.  All handles must belong to one native system object.
         """
         if dynamics is not None or lqr is not None:
-            if hasattr(dynamics, '__call__'):
-                system = plugin_system(dynamics, "dynamics")
-            else:
+            if not _callable(dynamics):
                 raise ValueError("Expected dynamics to be a function.")
-            if hasattr(lqr, '__call__'):
-                if plugin_system(lqr, "lqr") is not system:
-                    raise ValueError("dynamics and lqr belong to different native systems.")
-            else:
+            if not _callable(lqr):
                 raise ValueError("Expected lqr to be a function.")
-            self.dynamics = dynamics
-            self.lqr = lqr
-            self.system = system
-
+            system = plugin_system(dynamics, "dynamics")
+            if plugin_system(lqr, "lqr") is not system:
+                raise ValueError("dynamics and lqr belong to different native systems.")
+            self.dynamics, self.lqr, self.system = dynamics, lqr, system
         if constraints is not None:
-            if isinstance(constraints, Constraints):
-                self.constraints = constraints
-                self.nstates = self.constraints.nstates
-                self.ncontrols = self.constraints.ncontrols
-            else:
+            if not isinstance(constraints, Constraints):
                 raise ValueError("Expected constraints to be an instance of the Constraints class.")
-
+            self.constraints = constraints
+            self.nstates, self.ncontrols = constraints.nstates, constraints.ncontrols
         if erf is not None:
-            if hasattr(erf, '__call__'):
-                if erf is np.subtract:
-                    if self.system.wrap_dims:
-                        raise ValueError("This system has angular states; pass its .erf handle.")
-                elif plugin_system(erf, "erf") is not self.system:
-                    raise ValueError("erf belongs to a different native system.")
-                self.erf = erf
-            else:
+            if not _callable(erf):
                 raise ValueError("Expected erf to be a function.")
-
-        if getattr(self, "constraints", None) is not None and getattr(self, "system", None) is not None:
-            if self.constraints.system is not self.system:
-                raise ValueError("constraints.is_feasible belongs to a different native system.")
-
+            if erf is np.subtract:
+                if self.system.wrap_dims:
+                    raise ValueError("This system has angular states; pass its .erf handle.")
+            elif plugin_system(erf, "erf") is not self.system:
+                raise ValueError("erf belongs to a different native system.")
+            self.erf = erf
+        have = getattr(self, "constraints", None), getattr(self, "system", None)
+        if have[0] is not None and have[1] is not None and have[0].system is not have[1]:
+            raise ValueError("constraints.is_feasible belongs to a different native system.")
         self.plan_reached_goal = False
 
-#################################################
-
     def kill_update(self):
-        """Raises a flag that will cause an abrupt termination of the update_plan routine."""
+        """Asks a running update_plan (another thread's) to stop; it returns False at its next check."""
         self.killed = True
 
     def unkill(self):
-        """Lowers the kill_update flag. Do this if you made a mistake."""
+        """Withdraws a kill_update that has not been honoured yet."""
         self.killed = False
-
-    def visualize(self, dx, dy):
-        """Plots the (dx,dy)-cross-section of the current tree, highlighting the plan."""
-        if hasattr(self, 'node_seq'):
-            self.tree.visualize(dx, dy, node_seq=self.node_seq)
-        else:
-            print("There is no plan to visualize!")
 
 
 def _add_stats(a, b):

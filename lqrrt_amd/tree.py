@@ -1,171 +1,193 @@
 """
-Tree -- the reference's node store (lqrrt/tree.py) as a view over the device-resident SoA
-tree held by the HIP engine.
+Tree -- the reference's node store (lqrrt/tree.py) for a tree that lives on the GPU while it grows.
 
-Same features as tree.py:1-27: `state` (N x n array), `pID`, `lqr` [(S, K)], `x_seq`, `u_seq`
-(edge trajectories, parent -> node, parent excluded), `size`, `nstates`, `ncontrols`, plus
-`climb` and `trajectory`.  Values are copied from HBM on access (cached until the tree
-grows), so unlike the reference they do not alias the planner's storage.
+Features, as in tree.py:1-27: `state` (N x n array), `pID`, `lqr` [(S, K)], `x_seq` / `u_seq` (edge trajectories
+parent -> node, parent excluded), `size`, `nstates`, `ncontrols`; methods `add_node`, `climb`, `trajectory`.
+
+Two residences:
+  * host    Tree(seed_state, seed_lqr) builds an ordinary host-side tree, exactly the reference's constructor
+            (tree.py:50).  add_node appends to it.
+  * device  During Planner.update_plan the planner binds the tree to its engine: the nodes are then the engine's
+            SoA buffers in HBM and every feature is copied out on access (cached until the tree grows).  When the
+            engine is about to be reused for the next plan the planner detaches the tree first, i.e. snapshots
+            all features to the host in a handful of bulk copies -- so a Tree object kept from an earlier plan
+            (the ROS node does that: lqrrt_node.py:477 keeps planner.tree and reads it at :889, :1149 while the
+            next plan grows) stays what it was, and never touches the engine again.
+
+Unlike the reference ("PASSES BY REFERENCE", tree.py:27) values read from a device-resident tree are copies.
 """
 import numpy as np
 
 
-class _EdgeSeq(object):
-    """Lazy sequence: seq[ID] -> list of arrays along the edge into node ID (tree.py:21-25)."""
+class _Rows(object):
+    """Read-only sequence over the nodes of a tree; item i is produced by `get(i)`."""
 
-    def __init__(self, tree, which):
-        self._tree, self._which = tree, which
+    def __init__(self, tree, get):
+        self._tree, self._get = tree, get
 
     def __len__(self):
         return self._tree.size
 
-    def __getitem__(self, ID):
-        if isinstance(ID, slice):
-            return [self[i] for i in range(*ID.indices(len(self)))]
-        ID = int(ID)
-        if ID < 0:
-            ID += len(self)
-        return self._tree._edge(ID)[self._which]
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._get(k) for k in range(*i.indices(len(self)))]
+        i = int(i)
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError("node %d does not exist" % i)
+        return self._get(i)
 
     def __iter__(self):
-        return (self[i] for i in range(len(self)))
-
-
-class _LqrSeq(object):
-    """Lazy sequence of (S, K) per node (tree.py:67,91)."""
-
-    def __init__(self, tree):
-        self._tree = tree
-
-    def __len__(self):
-        return self._tree.size
-
-    def __getitem__(self, ID):
-        ID = int(ID)
-        if ID < 0:
-            ID += len(self)
-        base = self._tree._e.size
-        if ID >= base:
-            return self._tree._extra[ID - base][2]
-        return (self._tree._S, self._tree._gains()[ID])
+        return (self._get(k) for k in range(len(self)))
 
 
 class Tree:
     """
-    Device-backed tree.  The reference constructs Tree(seed_state, seed_lqr) inside
-    update_plan (planner.py:172); here the planner binds it to its engine, whose
-    lqrrt_tree_reset() kernel creates the seed node (pID -1, edge [[seed]], [[0]]).
+    Tree(seed_state, seed_lqr): seed_state is the state of the root, seed_lqr the (S, K) tuple of local LQR
+    cost-to-go and gain matrices there (tree.py:41-47).
     """
 
-    def __init__(self, engine):
-        self._e = engine
-        self.nstates = engine.n
-        self.ncontrols = engine.m
-        self._S = engine.system.Smatrix()
+    def __init__(self, seed_state, seed_lqr):
+        seed = np.array(seed_state, dtype=np.float64)
+        self.nstates = len(seed)
+        K0 = seed_lqr[1] if seed_lqr is not None else None
+        self.ncontrols = int(np.shape(K0)[0]) if K0 is not None and np.ndim(K0) == 2 else 1     # tree.py:57-62
+        # host residence: per-node python lists (the tree is small whenever it lives here while growing)
+        self._h_state = [seed]
+        self._h_pID = [-1]
+        self._h_lqr = [seed_lqr]
+        self._h_x = [[seed]]                                    # tree.py:69: the root's edge is the seed itself
+        self._h_u = [[np.zeros(self.ncontrols)]]                # tree.py:70
+        # device residence
+        self._e = None
+        self._generation = None
+        self._S = None
         self._cache = {}
         self._cache_size = -1
-        self._extra = []          # host-side nodes appended after planning (finish_on_goal, planner.py:299)
-        self.x_seq = _EdgeSeq(self, 0)
-        self.u_seq = _EdgeSeq(self, 1)
-        self.lqr = _LqrSeq(self)
+        self.x_seq = _Rows(self, lambda i: self._edge(i)[0])
+        self.u_seq = _Rows(self, lambda i: self._edge(i)[1])
+        self.lqr = _Rows(self, self._lqr_of)
+
+    # -- residence ---------------------------------------------------------------------------------
+    def _bind(self, engine, S):
+        """The engine's tree (just reset to this tree's seed) becomes the storage of nodes [0, engine.size)."""
+        self._e = engine
+        self._generation = engine.generation
+        self._S = S
+        self._cache, self._cache_size = {}, -1
+        self._h_state, self._h_pID, self._h_lqr, self._h_x, self._h_u = [], [], [], [], []     # host part: later nodes only
+
+    @property
+    def on_device(self):
+        return self._e is not None
+
+    def _dev(self):
+        """The engine, after checking that it still holds THIS tree."""
+        if self._e.generation != self._generation:
+            raise RuntimeError("this Tree's engine was reset for another plan before the tree was detached")
+        return self._e
+
+    def _detach(self):
+        """Snapshots every feature to the host (bulk copies) and lets go of the engine."""
+        if self._e is None:
+            return
+        e = self._dev()
+        N = e.size
+        state, pid, K = e.states(), e.parents().tolist(), e.gains()
+        xe, ue, ln = e.edges()
+        tail = (self._h_state, self._h_pID, self._h_lqr, self._h_x, self._h_u)
+        self._h_state = [state[i] for i in range(N)] + tail[0]
+        self._h_pID = pid + tail[1]
+        self._h_lqr = [(self._S, K[i]) for i in range(N)] + tail[2]
+        self._h_x = [[xe[i, k] for k in range(ln[i])] for i in range(N)] + tail[3]
+        self._h_u = [[ue[i, k] for k in range(ln[i])] for i in range(N)] + tail[4]
+        self._e, self._generation, self._cache, self._cache_size = None, None, {}, -1
+
+    # -- features -----------------------------------------------------------------------------------
+    def _ndev(self):
+        return self._dev().size if self._e is not None else 0
 
     @property
     def size(self):
-        return self._e.size + len(self._extra)
+        return self._ndev() + len(self._h_pID)
 
     def _fresh(self):
-        n = self._e.size
+        n = self._ndev()
         if n != self._cache_size:
-            self._cache = {}
-            self._cache_size = n
+            self._cache, self._cache_size = {}, n
         return self._cache
 
     @property
     def state(self):
+        host = np.array(self._h_state, dtype=np.float64).reshape(len(self._h_state), self.nstates)
+        if self._e is None:
+            return host
         c = self._fresh()
         if "state" not in c:
-            c["state"] = self._e.states()
-        if self._extra:
-            return np.vstack([c["state"]] + [np.asarray(x[1], dtype=np.float64) for x in self._extra])
-        return c["state"]
+            c["state"] = self._dev().states()
+        return np.vstack((c["state"], host)) if len(host) else c["state"]
 
     @property
     def pID(self):
+        if self._e is None:
+            return self._h_pID
         c = self._fresh()
         if "pID" not in c:
-            c["pID"] = self._e.parents().tolist()
-        if self._extra:
-            return c["pID"] + [int(x[0]) for x in self._extra]
-        return c["pID"]
+            c["pID"] = self._dev().parents().tolist()
+        return c["pID"] + self._h_pID if self._h_pID else c["pID"]
 
-    def _gains(self):
+    def _lqr_of(self, i):
+        n = self._ndev()
+        if i >= n:
+            return self._h_lqr[i - n]
         c = self._fresh()
         if "K" not in c:
-            c["K"] = self._e.gains()
-        return c["K"]
+            c["K"] = self._dev().gains()
+        return (self._S, c["K"][i])
 
-    def _edge(self, ID):
+    def _edge(self, i):
+        n = self._ndev()
+        if i >= n:
+            return (self._h_x[i - n], self._h_u[i - n])
         c = self._fresh()
-        if ID >= self._e.size and ID - self._e.size < len(self._extra):
-            x = self._extra[ID - self._e.size]
-            return (x[3], x[4])
-        key = ("edge", ID)
+        key = ("edge", i)
         if key not in c:
-            if ID >= self.size or ID < 0:
-                raise IndexError("node %d does not exist" % ID)
-            x, u = self._e.edge(ID)
-            c[key] = ([row for row in x], [row for row in u])
+            x, u = self._dev().edge(i)
+            c[key] = (list(x), list(u))
         return c[key]
 
+    # -- the reference's methods ----------------------------------------------------------------------
     def add_node(self, pID, state, lqr, x_seq, u_seq):
         """
-        tree.py:77-96.  During planning nodes are appended on the device by the waves; this host-side
-        append exists for what the reference adds afterwards (the finish_on_goal node, planner.py:299).
+        Adds a node to the tree (tree.py:77-96).  While the tree is growing on the device the waves append there
+        (csrc k_append); this host-side append serves a tree built by hand and what the reference adds after
+        planning (the finish_on_goal node, planner.py:299).
         """
         if pID >= self.size or pID < 0:
             raise ValueError("The given parent ID, {}, doesn't exist.".format(pID))
-        self._extra.append((pID, state, lqr, x_seq, u_seq))
+        self._h_state.append(np.array(state, dtype=np.float64))
+        self._h_pID.append(int(pID))
+        self._h_lqr.append(lqr)
+        self._h_x.append(x_seq)
+        self._h_u.append(u_seq)
 
     def climb(self, ID):
-        """
-        Returns a list of node IDs that connect the seed to the node with the given ID
-        (first element 0, last element ID) -- tree.py:100-117.
-        """
+        """Node IDs from the seed (first element, 0) down to ID (last element) -- tree.py:100-117."""
         if ID >= self.size or ID < 0:
             raise ValueError("The given ID, {}, doesn't exist.".format(ID))
         parents = self.pID
-        IDs = []
-        while ID != -1:
-            IDs.append(int(ID))
-            ID = parents[ID]
-        return IDs[::-1]
+        chain = [int(ID)]
+        while parents[chain[-1]] != -1:
+            chain.append(int(parents[chain[-1]]))
+        chain.reverse()
+        return chain
 
     def trajectory(self, IDs):
-        """Concatenated (x_seq_full, u_seq_full) over the listed nodes -- tree.py:121-132."""
-        x_seq_full = []
-        u_seq_full = []
+        """(x_seq_full, u_seq_full): the edges of the listed nodes laid end to end -- tree.py:121-132."""
+        xs, us = [], []
         for ID in IDs:
-            xs, us = self._edge(int(ID))
-            x_seq_full.extend(xs)
-            u_seq_full.extend(us)
-        return (x_seq_full, u_seq_full)
-
-    def visualize(self, dx, dy, node_seq=None):
-        """Cross-section plot of the tree (tree.py:136-171); needs matplotlib."""
-        from matplotlib import pyplot as plt
-        fig = plt.figure()
-        fig.suptitle('Tree')
-        ax = fig.add_subplot(1, 1, 1)
-        ax.set_xlabel('- State {} +'.format(dx))
-        ax.set_ylabel('- State {} +'.format(dy))
-        ax.grid(True)
-        path = set(node_seq or [])
-        parents = self.pID
-        st = self.state
-        for ID in range(1, self.size):
-            xs = np.vstack((st[parents[ID]], np.array(self._edge(ID)[0])))
-            ax.plot(xs[:, dx], xs[:, dy], color='r' if ID in path else '0.75', zorder=2 if ID in path else 1)
-        ax.scatter(st[0, dx], st[0, dy], color='b', s=48)
-        if node_seq:
-            ax.scatter(st[node_seq[-1], dx], st[node_seq[-1], dy], color='r', s=48)
-        plt.show()
+            ex, eu = self._edge(int(ID))
+            xs += list(ex)
+            us += list(eu)
+        return (xs, us)

@@ -133,3 +133,25 @@ def test_integration_stub_matches_binding():
     assert m, "stub not found"
     names = re.findall(r'\("(\w+)"', m.group(1))
     assert names == [f[0] for f in nat.SystemDesc._fields_]
+
+
+def test_reference_package_name_and_tree_constructor():
+    """`import lqrrt` resolves to this build (lqrrt/__init__.py:1-2 of the reference exports Constraints, Planner) and
+    Tree has the reference's constructor Tree(seed_state, seed_lqr) (tree.py:50) with its host-side behaviour."""
+    import lqrrt
+    import lqrrt_amd
+    assert lqrrt.Planner is lqrrt_amd.Planner and lqrrt.Constraints is lqrrt_amd.Constraints and lqrrt.Tree is lqrrt_amd.Tree
+    S, K = np.eye(3), np.arange(6.0).reshape(2, 3)
+    t = lqrrt.Tree([1.0, 2.0, 3.0], (S, K))
+    assert (t.size, t.nstates, t.ncontrols, t.pID) == (1, 3, 2, [-1]) and not t.on_device
+    assert t.state.shape == (1, 3) and t.lqr[0][1] is K
+    assert np.array_equal(t.x_seq[0][0], [1.0, 2.0, 3.0]) and np.array_equal(t.u_seq[0][0], np.zeros(2))   # tree.py:69-70
+    t.add_node(0, [2.0, 2.0, 2.0], (S, K + 1), [np.ones(3), 2 * np.ones(3)], [np.zeros(2), np.ones(2)])
+    t.add_node(1, [3.0, 3.0, 3.0], (S, K + 2), [3 * np.ones(3)], [np.ones(2)])
+    assert t.size == 3 and t.climb(2) == [0, 1, 2] and t.state.shape == (3, 3)
+    xs, us = t.trajectory([0, 1, 2])
+    assert len(xs) == 4 and len(us) == 4 and np.array_equal(xs[-1], 3 * np.ones(3))
+    with pytest.raises(ValueError, match="doesn't exist"):
+        t.add_node(3, [0, 0, 0], None, [], [])                    # tree.py:83-84
+    with pytest.raises(ValueError, match="doesn't exist"):
+        t.climb(9)                                                 # tree.py:109-110

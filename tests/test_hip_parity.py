@@ -394,11 +394,40 @@ def test_replanning_and_control_surface():
     ref.update_plan(rs.x0, rs.sample_space, goal_bias=rs.goal_bias, xrand_gen=10)
     assert p.tree.size == ref.tree.size == 121 and list(p.tree.pID) == list(ref.tree.pID)
     assert max(len(e) for e in p.tree.x_seq) <= 30
+    # A Tree kept from an earlier plan (the ROS node does: lqrrt_node.py:477) is detached when the engine is reused:
+    # it keeps its contents, on the host, and never looks at the device again.
+    old = p.tree
+    assert old.on_device
+    keep = dict(size=old.size, pID=list(old.pID), state=np.copy(old.state), K7=np.copy(old.lqr[7][1]),
+                x5=[np.copy(v) for v in old.x_seq[5]], u5=[np.copy(v) for v in old.u_seq[5]], chain=old.climb(old.size - 1))
     # kill flag: polled between native calls; returns False and lowers the flag (planner.py:330-336)
     p.set_runtime(max_nodes=100000)
     p.kill_update()
     assert p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10) is False
     assert p.killed is False and hasattr(p, "node_seq")
+    assert p.tree is not old and not old.on_device and p.tree.on_device
+    assert old.size == keep["size"] and list(old.pID) == keep["pID"] and np.array_equal(old.state, keep["state"])
+    assert np.array_equal(old.lqr[7][1], keep["K7"]) and old.climb(old.size - 1) == keep["chain"]
+    assert all(np.array_equal(a, b) for a, b in zip(old.x_seq[5], keep["x5"])) and len(old.x_seq[5]) == len(keep["x5"])
+    assert all(np.array_equal(a, b) for a, b in zip(old.u_seq[5], keep["u5"]))
+    # a kill AFTER this tree reached the goal leaves the plan attributes describing THIS tree's best plan
+    # (planner.py:276-281 updates them inside the loop), not the previous tree's
+    calls = [0]
+
+    def clock():
+        calls[0] += 1
+        if p.plan_reached_goal and calls[0] > 2:
+            p.kill_update()
+        return 0.0
+    p.set_runtime(sys_time=clock)
+    np.random.seed(21)
+    assert p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10) is False
+    assert p.plan_reached_goal and p._in_goal(p.x_seq[-1])
+    assert p.node_seq[-1] < p.tree.size and p.node_seq == p.tree.climb(p.node_seq[-1])
+    xs, _ = p.tree.trajectory(p.node_seq)
+    assert len(xs) == len(p.x_seq) and all(np.array_equal(a, b) for a, b in zip(xs, p.x_seq))
+    assert p.T == len(p.x_seq) * p.dt
+    p.set_runtime(sys_time=lambda: 0.0)
     # wall-clock budget with the real clock: returns True once a plan exists and specific_time elapsed
     import time
     # (max_nodes far above what the budget can grow -- ~3e5 nodes/s for the car -- or the node limit, not the clock,

@@ -156,3 +156,51 @@ def test_hip_bit_exact_vs_coracle(golden_dir, name):
     np.testing.assert_array_equal(eng.edge_lengths(), o.edge_lengths())
     np.testing.assert_array_equal(eng.ignored(), o.ignored())
     assert eng.horizon_iters_state() == o.horizon_iters
+
+
+@pytest.mark.parametrize("name", BEHAVIORS)
+def test_coracle_teacher_forced(golden_dir, name):
+    """Every decision of the reference behaviour's own run replayed from the reference's tree (tests/teacher.py): the
+    'car' behaviour, whose free-running states drift (_states_close), agrees decision by decision."""
+    import coracle
+    import teacher
+    g = _fixture(golden_dir, name)
+    if "xrand_all" not in g.files:
+        pytest.skip("fixture has no teacher data")
+    s = _native(name, g)
+    sch = teacher.Schedule(g, s.goal, np.abs(s.goal_buffer))
+    o = coracle.make(s, len(sch.state) + 8, seed=1)
+    o.load_tree(sch.state, sch.K, sch.pID)
+    bad_near = bad_len = 0
+    worst = 0.0
+    cur = None
+    for size, a, b in sch.groups():
+        ign = sch.ignored_at(size)
+        if ign is not cur:
+            o.set_ignored(ign)
+            cur = ign
+        for t in range(a, b):
+            bad_near += int(o.nearest_prefix(sch.xrand[t], size) != sch.nearest[t])
+            ln, xs, _, _ = o.steer_from(sch.nearest[t], sch.xrand[t])
+            bad_len += int(ln != sch.steer_len[t])
+            if ln > 0 and ln == sch.steer_len[t]:
+                worst = max(worst, float(np.abs(xs[-1] - sch.state[sch.new_node[t]]).max()))
+    assert bad_near == 0 and bad_len == 0 and worst < ATOL, (bad_near, bad_len, worst)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", BEHAVIORS)
+def test_hip_teacher_forced(golden_dir, name):
+    import teacher
+    from test_teacher_gpu import replay_hip
+    g = _fixture(golden_dir, name)
+    if "xrand_all" not in g.files:
+        pytest.skip("fixture has no teacher data")
+    s = _native(name, g)
+    sch = teacher.Schedule(g, s.goal, np.abs(s.goal_buffer))
+    kw = s.plan_kwargs
+    hspan = np.divide(kw["horizon"], kw["dt"]).astype(np.int64)
+    r = replay_hip(s, sch, kw["dt"], kw["FPR"], int(hspan[1]), adaptive=(int(hspan[0]), int(hspan[1])), wave=128)
+    print(r)
+    assert r["nearest_miss"] == 0 and r["steer_len_mismatch"] == 0
+    assert r["end_state_compared"] == len(sch.state) - 1 and r["end_state_max_err"] < ATOL

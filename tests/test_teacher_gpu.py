@@ -1,0 +1,149 @@
+"""
+Teacher-forced parity of the HIP path against runs of the reference itself (GPU, through the C ABI).
+
+The reference's own tree is put on the device with lqrrt_tree_load; then, for EVERY iteration of the reference's
+run (36 936 of them for the 10 000-node demo_boat_advanced tree of BASELINE config 4), lqrrt_nn_argmin must return
+the node the reference chose (planner.py:236-247, searched over the prefix of the tree that existed at that
+iteration, with the ignore set of that moment) and lqrrt_steer_batch from that node must return the reference's
+edge length and end state (planner.py:250-257).  See tests/teacher.py.
+
+Bars: >= 99.9 % nearest ids exact, every miss with a relative cost gap < 1e-12; steer length
+equal wherever the start speed exceeds 1e-2 m/s (mismatches counted and attributed); end states <= 1e-9 there.
+The numbers observed are stricter than the bars and are asserted as observed where that is robust.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import teacher
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(golden_dir, fname):
+    path = os.path.join(golden_dir, fname)
+    if not os.path.exists(path):
+        pytest.skip("fixture %s missing" % fname)
+    g = np.load(path)
+    if "xrand_all" not in g.files:
+        pytest.skip("fixture %s has no teacher data" % fname)
+    return g
+
+
+def replay_hip(s, sch, dt, FPR, horizon_iters, adaptive=None, wave=1024):
+    """Backward sweep: the full tree is loaded once and truncated group by group (nodes are append-only)."""
+    from lqrrt_amd.engine import Engine
+    N = len(sch.state)
+    eng = Engine(s, capacity=N + 8, max_wave=wave)
+    if adaptive:
+        eng.set_resolution(dt, FPR, adaptive[1], np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer), adaptive=True, hspan_min=adaptive[0],
+                           horizon_iters_state=1)
+    else:
+        eng.set_resolution(dt, FPR, horizon_iters, np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer))
+    eng.tree_load(sch.state, sch.K, sch.pID)
+    # steer does not depend on the prefix: all iterations in a few launches
+    ln = np.zeros(sch.iters, dtype=np.int64)
+    xe = np.zeros((sch.iters, s.nstates))
+    Ke = np.zeros((sch.iters, s.ncontrols, s.nstates))
+    for a in range(0, sch.iters, wave):
+        b = min(a + wave, sch.iters)
+        l, _, _, x, K = eng.steer_batch(sch.nearest[a:b], sch.xrand[a:b])
+        ln[a:b], xe[a:b], Ke[a:b] = l, x, K
+    near = np.zeros(sch.iters, dtype=np.int64)
+    gaps = {}
+    cur = None
+    for size, a, b in reversed(sch.groups()):
+        eng.tree_truncate(size)
+        ign = sch.ignored_at(size)
+        if ign is not cur:
+            eng.set_ignored(ign[:size])
+            cur = ign
+        for c in range(a, b, wave):
+            d = min(c + wave, b)
+            ids, _ = eng.nn_argmin(sch.xrand[c:d], use_ignore=True)
+            near[c:d] = ids
+            for t in np.flatnonzero(ids != sch.nearest[c:d]) + c:
+                cost = eng.costs_to_go(sch.xrand[t])
+                u, v = cost[near[t]], cost[sch.nearest[t]]
+                gaps[int(t)] = abs(u - v) / max(abs(u), abs(v), 1e-300)
+    r = teacher.summarize("hip", sch, near, ln, xe, lambda t: gaps[t])
+    both = (ln > 0) & (ln == sch.steer_len)
+    idx = np.flatnonzero(both)
+    r["gain_max_err"] = float(np.abs(Ke[idx] - sch.K[sch.new_node[idx]]).max()) if len(idx) else 0.0
+    eng.close()
+    return r
+
+
+def _record(name, r):
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "teacher_%s.json" % name), "w") as f:
+            json.dump(r, f, indent=1)
+    except OSError:
+        pass
+    print(r)
+
+
+@pytest.mark.parametrize("tag", ["3000", "10k"])
+def test_boat_advanced_teacher_forced(golden_dir, tag):
+    import lqrrt_amd
+    g = _load(golden_dir, "traj_boat_advanced_%s.npz" % tag)
+    s = lqrrt_amd.systems.SYSTEMS["boat_advanced"](0)
+    sch = teacher.Schedule(g, s.goal, s.goal_buffer)
+    kw = s.plan_kwargs
+    r = replay_hip(s, sch, kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]))
+    _record("boat_advanced_" + tag, r)
+    assert r["iterations"] == int(g["iterations"])
+    assert r["nearest_exact"] >= 0.999 * r["iterations"]
+    assert r["nearest_miss_max_rel_gap"] < 1e-12
+    assert r["steer_len_mismatch_fast_start"] == 0
+    assert r["end_state_over_1e9_fast_start"] == 0
+    # observed (MI355X, round 2): every decision identical, worst end-state error ~1e-11
+    assert r["nearest_miss"] == 0 and r["steer_len_mismatch"] == 0 and r["end_state_max_err"] < 1e-9
+    assert r["end_state_compared"] == len(sch.state) - 1
+    assert r["gain_max_err"] < 1e-8
+
+
+@pytest.mark.parametrize("name,tag,exact", [("car", "500", True), ("car", "2000", True), ("pendulum", "150", True),
+                                            ("car", "2000_unpatched", False), ("pendulum", "150_unpatched", False)])
+def test_demo_teacher_forced(golden_dir, name, tag, exact):
+    """Car / pendulum, both the tie-stabilised and the untouched reference (the latter: other node only on bit-equal cost)."""
+    import lqrrt_amd
+    g = _load(golden_dir, "traj_%s_%s.npz" % (name, tag))
+    s = lqrrt_amd.systems.SYSTEMS[name](0)
+    sch = teacher.Schedule(g, s.goal, s.goal_buffer)
+    kw = s.plan_kwargs
+    r = replay_hip(s, sch, kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]), wave=256)
+    _record("%s_%s" % (name, tag), r)
+    if exact:
+        assert r["nearest_miss"] == 0
+    else:
+        assert r["nearest_miss"] > 0 and r["nearest_miss_max_rel_gap"] == 0.0
+    assert r["steer_len_mismatch"] == 0 and r["end_state_max_err"] < 1e-9
+    assert r["end_state_compared"] == len(sch.state) - 1
+
+
+def test_costs_to_go_fixture_through_the_scan_kernels(golden_dir):
+    """ops_*.npz `ctg_costs` (planner._costs_to_go of the reference against a frozen 512-node table) through k_costs and
+    k_nn_scan/k_nn_reduce: the node table goes onto the device with lqrrt_tree_load."""
+    import lqrrt_amd
+    from lqrrt_amd.engine import Engine
+    for name in ("boat_advanced", "boat_intermediate", "boat_novice", "car", "pendulum"):
+        g = np.load(os.path.join(golden_dir, "ops_%s.npz" % name))
+        s = lqrrt_amd.systems.SYSTEMS[name](0)
+        nodes, qs, want = g["ctg_nodes"], g["ctg_x"], g["ctg_costs"]
+        eng = Engine(s, capacity=len(nodes) + 8, max_wave=64)
+        eng.set_resolution(float(g["dt"]), 0.0, 2, s.error_tol, s.goal, s.goal_buffer)
+        N = len(nodes)
+        pid = np.arange(-1, N - 1, dtype=np.int32)
+        eng.tree_load(nodes, np.zeros((N, s.ncontrols, s.nstates)), pid)
+        for q, w in zip(qs, want):
+            got = eng.costs_to_go(q)
+            np.testing.assert_allclose(got, w, rtol=1e-12, atol=1e-9)
+        ids, cost = eng.nn_argmin(qs, use_ignore=False)
+        np.testing.assert_array_equal(ids, np.argmin(want, axis=1))
+        np.testing.assert_allclose(cost, want.min(axis=1), rtol=1e-12, atol=1e-9)
+        eng.close()

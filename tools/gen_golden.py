@@ -341,12 +341,12 @@ def gen_ros_behaviors():
         planner.set_runtime(min_time=2, max_time=3, max_nodes=300, sys_time=lambda: 0.0)
         planner.set_goal(goal)
         ss = mod.gen_ss(x0, goal)
-        nearest, slen = [], []
+        nearest, slen, xrands = [], [], []
         steer = planner._steer
 
         def spy(ID, xtar, force_arrive=False, _s=steer):
             r = _s(ID, xtar, force_arrive)
-            nearest.append(int(ID)); slen.append(len(r[0]))
+            nearest.append(int(ID)); slen.append(len(r[0])); xrands.append(np.copy(xtar))
             return r
         planner._steer = spy
         np.random.seed(PLAN_SEED)
@@ -360,11 +360,73 @@ def gen_ros_behaviors():
                    plan_x=np.array(planner.x_seq), plan_T=np.float64(planner.T), sample_space=np.array(ss, dtype=np.float64),
                    goal=goal, goal_buffer=np.array(planner.constraints.goal_buffer), error_tol=np.array(planner.error_tol),
                    grid=grid.astype(np.int8), origin=origin, cpm=np.float64(cpm), threshold=np.float64(90.0),
-                   pid_hash=np.array(pid_hash(tree.pID)))
+                   pid_hash=np.array(pid_hash(tree.pID)), xrand_all=np.array(xrands, dtype=np.float64))
         path = os.path.join(OUT, "ros_%s.npz" % name)
         np.savez_compressed(path, **out)
         print("wrote %s: iters=%d nodes=%d goal=%s horizon_iters=%d edges<=%d" % (
             path, len(nearest), tree.size, bool(planner.plan_reached_goal), planner.horizon_iters, out["edge_len"].max()))
+
+
+# --------------------------------------------------------------------------- config 5
+
+def gen_config5(max_nodes=600, n_boxes=3000, tag=None):
+    """
+    BASELINE config 5 is not in the reference; SURVEY 8(d) names its oracle: "the reference Planner driven by the
+    build's own NumPy callbacks for this system".  That is what runs here: the REFERENCE's Planner / Constraints /
+    Tree classes with oracle/systems_np.DoubleIntegrator's dynamics / lqr / is_feasible (erf = np.subtract, the
+    reference's default), S and K from scipy.linalg.solve_discrete_are.
+    """
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from systems_np import DoubleIntegrator
+    lq = rl.import_reference()
+    s = DoubleIntegrator(n_boxes=n_boxes, seed=OBS_SEED)
+    cons = lq.Constraints(nstates=s.nstates, ncontrols=s.ncontrols, goal_buffer=s.goal_buffer, is_feasible=s.is_feasible)
+    planner = lq.Planner(s.dynamics, s.lqr, cons, error_tol=s.error_tol, min_time=2, max_time=3, max_nodes=max_nodes,
+                         goal0=s.goal, printing=False, sys_time=lambda: 0.0, **s.plan_kwargs)
+    # (copies taken BEFORE planning: the reference's fallback plan zeroes columns of the S its lqr returns, in place,
+    #  planner.py:314-316)
+    S_before, K_before = np.array(s.S), np.array(s.K)
+    xrands, nearest, slen, ties = [], [], [], []
+    ctg, steer = planner._costs_to_go, planner._steer
+
+    def ctg_spy(x):
+        xrands.append(np.copy(x))
+        c = ctg(x)
+        ties.append(len(np.unique(c)) < len(c))
+        return c
+
+    def steer_spy(ID, xtar, force_arrive=False):
+        r = steer(ID, xtar, force_arrive)
+        nearest.append(int(ID)); slen.append(len(r[0]))
+        return r
+    planner._costs_to_go, planner._steer = ctg_spy, steer_spy
+    np.random.seed(PLAN_SEED)
+    t0 = time.time()
+    ret = planner.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10)
+    wall = time.time() - t0
+    n = s.nstates
+    probe = np.random.sample()
+    stream = np.random.RandomState(PLAN_SEED).random_sample((len(xrands) * 12 + 64) * (n + 1))
+    pos = int(np.flatnonzero(stream == probe)[0])
+    assert pos % (n + 1) == 0
+    tree = planner.tree
+    out = dict(max_nodes=np.int64(max_nodes), n_boxes=np.int64(n_boxes), box_seed=np.int64(OBS_SEED), min_time=np.float64(2),
+               iterations=np.int64(len(nearest)), n_candidates=np.int64(pos // (n + 1)), returned=np.bool_(ret),
+               reached_goal=np.bool_(planner.plan_reached_goal), pID=np.array(tree.pID, dtype=np.int32),
+               state=np.array(tree.state), K=np.array([lk[1] for lk in tree.lqr]), S=S_before, Kconst=K_before,
+               edge_len=np.array([len(e) for e in tree.x_seq], dtype=np.int32), nearest=np.array(nearest, dtype=np.int32),
+               steer_len=np.array(slen, dtype=np.int16), xrand_all=np.array(xrands), tie_any_mask=np.array(ties),
+               node_seq=np.array(planner.node_seq, dtype=np.int32), plan_x=np.array(planner.x_seq), plan_u=np.array(planner.u_seq),
+               plan_T=np.float64(planner.T), pid_hash=np.array(pid_hash(tree.pID)), box_lo_sum=np.float64(s.box_lo.sum()),
+               box_hi_sum=np.float64(s.box_hi.sum()), ref_wall_s=np.float64(wall), pruning=np.bool_(True), tries=np.int64(10))
+    for tagid, ID in (("a", 1), ("b", tree.size // 2), ("c", tree.size - 1)):
+        out["edge_%s_id" % tagid] = np.int32(ID)
+        out["edge_%s_x" % tagid] = np.array(tree.x_seq[ID], dtype=np.float64)
+        out["edge_%s_u" % tagid] = np.array(tree.u_seq[ID], dtype=np.float64)
+    path = os.path.join(OUT, "traj_double_integrator_%s.npz" % (tag or str(max_nodes)))
+    np.savez_compressed(path, **out)
+    print("wrote %s: iters=%d cand=%d nodes=%d hash=%s goal=%s ties=%d wall=%.1fs" % (
+        path, len(nearest), out["n_candidates"], tree.size, out["pid_hash"], bool(planner.plan_reached_goal), int(np.sum(ties)), wall))
 
 
 def main():
@@ -387,6 +449,9 @@ def main():
         "car500u": lambda: run_traj("car", 500, keep_xrand=64, tag="500_unpatched", teacher=True, stable_ties=False),
         "car2000u": lambda: run_traj("car", 2000, keep_xrand=64, tag="2000_unpatched", teacher=True, stable_ties=False),
         "pend150u": lambda: run_traj("pendulum", 150, keep_xrand=64, tag="150_unpatched", teacher=True, stable_ties=False),
+        # BASELINE config 5 on the reference's Planner with the build's NumPy callbacks
+        "di600": lambda: gen_config5(600, 3000),
+        "di2500": lambda: gen_config5(2500, 3000),
     }
     if args.job:
         jobs[args.job]()
