@@ -162,6 +162,7 @@ struct lqrrt_engine {
     std::vector<int64_t> pool_rows_end;  // candidate rows consumed through each pooled sample
     bool explicit_samples = false; // samples pushed by the host (callable xrand_gen) instead of the sampler
     int tries_carry = 0;          // tries already spent on the sample under construction
+    double* d_pool_trig = nullptr; // cos/sin of their angular coordinates [count][2*nw] (k_sample_trig)
     double* d_pool = nullptr;     // device mirror of the samples [cursor_at_upload ..)
     int64_t d_pool_base = 0, d_pool_count = 0;
     int64_t d_pool_cap = 0;
@@ -334,7 +335,8 @@ static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
 // NN over a node table for W samples at xs (device, [W][n]); writes id/cost and/or records.
 static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int W, const double* Sd,
                      bool tri, int* out_id, double* out_cost, double* rec, hipStream_t st,
-                     bool profile, int* n_chunks_out = nullptr, int wave_lo = -1, bool defer_reduce = false) {
+                     bool profile, int* n_chunks_out = nullptr, int wave_lo = -1, bool defer_reduce = false,
+                     const double* xtrig = nullptr) {
     if (W <= 0) return 0;
     int chunk, n_chunks;
     if (tri) { chunk = tri_chunk(); n_chunks = (nv.count + chunk - 1) / chunk; }   // in-wave pass: the reduction is fused into k_decide
@@ -347,12 +349,12 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     ev.a = ev.b = nullptr;
     if (profile) prof_begin(e, st, &ev, 0);
 #define NN_LAUNCH(DENSE, TRI)                                                                            \
-    DISPATCH(e, hipExtLaunchKernelGGL((k_nn_scan<S, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, W, S_use, chunk, \
+    DISPATCH(e, hipExtLaunchKernelGGL((k_nn_scan<S, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
                                       e->d_pcost, e->d_pidx, ps_c, ps_t))
     // structured forms of the engine's own S are instantiated only for the systems that have them
     const int sm = !S_use ? S_IDENT : (Sd ? S_DENSE : e->smode);
 #define NN_ONE(SYS, DENSE, TRI)                                                                            \
-    hipExtLaunchKernelGGL((k_nn_scan<SYS, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, W, S_use, chunk, \
+    hipExtLaunchKernelGGL((k_nn_scan<SYS, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
                           e->d_pcost, e->d_pidx, ps_c, ps_t)
     if (sm == S_BAND2 && e->model == LQRRT_MODEL_DOUBLE_INTEGRATOR) {
         if (tri) NN_ONE(DoubleIntegratorT<6>, S_BAND2, true); else NN_ONE(DoubleIntegratorT<6>, S_BAND2, false);
@@ -417,7 +419,7 @@ static void free_all(lqrrt_engine* e) {
     void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_og, e->d_ogc, e->d_cell_start, e->d_cell_items, e->d_S, e->tv.state, e->tv.trig, e->tv.K, e->tv.pID, e->tv.elen,
                     e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_M,
                     e->d_pidx, e->d_par_done, e->d_par_want, e->d_list,
-                    e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_cand, e->d_flags};
+                    e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_pool_trig, e->d_cand, e->d_flags};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_ign_pin) (void)hipHostFree(e->h_ign_pin);
@@ -1142,6 +1144,25 @@ extern "C" int lqrrt_steer_force(lqrrt_engine* e, int parent, const double* xtar
 // --------------------------------------------------------------------------------------------
 // sample stream (default sampler closure, planner.py:176-211)
 
+// host pool [off, off+cnt) -> device, plus the samples' trig table
+static int upload_pool(lqrrt_engine* e, int64_t off, int64_t cnt, hipStream_t st) {
+    const int n = e->n;
+    if (cnt > e->d_pool_cap) {
+        if (e->d_pool) (void)hipFree(e->d_pool);
+        if (e->d_pool_trig) (void)hipFree(e->d_pool_trig);
+        e->d_pool_cap = cnt + cnt / 2;
+        TRY(dalloc(&e->d_pool, (size_t)e->d_pool_cap * n));
+        TRY(dalloc(&e->d_pool_trig, (size_t)e->d_pool_cap * 2 * std::max(e->nw, 1)));
+    }
+    HIPCHK(hipMemcpyAsync(e->d_pool, e->pool.data() + off * n, sizeof(double) * cnt * n, hipMemcpyHostToDevice, st));
+    if (e->nw > 0 && cnt > 0) {
+        DISPATCH(e, hipLaunchKernelGGL((k_sample_trig<S>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, e->d_pool, (int)cnt, e->d_pool_trig));
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
 static int ensure_samples(lqrrt_engine* e, int64_t need_end, hipStream_t st) {
     // makes samples [cursor, need_end) available on the device at d_pool (index - d_pool_base)
     if (e->explicit_samples) {
@@ -1151,13 +1172,7 @@ static int ensure_samples(lqrrt_engine* e, int64_t need_end, hipStream_t st) {
             const int n = e->n;
             const int64_t off = e->cursor - e->pool_base;
             const int64_t cnt = (int64_t)e->pool_rows_end.size() - off;
-            if (cnt > e->d_pool_cap) {
-                if (e->d_pool) (void)hipFree(e->d_pool);
-                e->d_pool_cap = cnt + cnt / 2;
-                TRY(dalloc(&e->d_pool, (size_t)e->d_pool_cap * n));
-            }
-            HIPCHK(hipMemcpyAsync(e->d_pool, e->pool.data() + off * n, sizeof(double) * cnt * n, hipMemcpyHostToDevice, st));
-            HIPCHK(hipStreamSynchronize(st));
+            TRY(upload_pool(e, off, cnt, st));
             e->d_pool_base = e->cursor;
             e->d_pool_count = cnt;
         }
@@ -1211,13 +1226,7 @@ static int ensure_samples(lqrrt_engine* e, int64_t need_end, hipStream_t st) {
     // upload [cursor, pool_end)
     const int64_t off = e->cursor - e->pool_base;
     const int64_t cnt = (int64_t)e->pool_rows_end.size() - off;
-    if (cnt > e->d_pool_cap) {
-        if (e->d_pool) (void)hipFree(e->d_pool);
-        e->d_pool_cap = cnt + cnt / 2;
-        TRY(dalloc(&e->d_pool, (size_t)e->d_pool_cap * n));
-    }
-    HIPCHK(hipMemcpyAsync(e->d_pool, e->pool.data() + off * n, sizeof(double) * cnt * n, hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
+    TRY(upload_pool(e, off, cnt, st));
     e->d_pool_base = e->cursor;
     e->d_pool_count = cnt;
     return 0;
@@ -1250,6 +1259,9 @@ extern "C" int lqrrt_engine_queued_samples(lqrrt_engine* e) {
 
 static const double* wave_samples(const lqrrt_engine* e) {
     return e->d_pool + (size_t)(e->cursor - e->d_pool_base) * e->n;
+}
+static const double* wave_sample_trig(const lqrrt_engine* e) {
+    return e->nw > 0 ? e->d_pool_trig + (size_t)(e->cursor - e->d_pool_base) * 2 * e->nw : nullptr;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1293,13 +1305,15 @@ extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void
         // of the in-wave cost matrix
         const NodeView nv = tree_view(e, true);
         int n_chunks = 0;
+        const double* xtr = wave_sample_trig(e);
         TRY(launch_nn(e, nv, xs + (size_t)lo * e->n, cnt, nullptr, false, nullptr, nullptr,
-                      e->d_rec + (size_t)lo * e->L.R, st, true, &n_chunks, lo, true));
+                      e->d_rec + (size_t)lo * e->L.R, st, true, &n_chunks, lo, true, xtr ? xtr + (size_t)lo * 2 * e->nw : nullptr));
         SteerFuse f;
         memset(&f, 0, sizeof f);
         f.pcost = e->d_pcost; f.pidx = e->d_pidx; f.n_chunks = n_chunks; f.nv = nv;
         f.changed = e->d_changed; f.stale = e->d_stale; f.par_out = e->d_par_done;
         f.M = (e->wave_matrix && whole) ? e->d_M : nullptr; f.W = W;
+        f.xtrig = xtr;
         TRY(launch_steer(e, xs, nullptr, lo, cnt, e->d_par_done, st, nullptr, &f));
     }
     HIPCHK(hipGetLastError());
@@ -1404,6 +1418,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     SteerFuse rf;
     memset(&rf, 0, sizeof rf);
     rf.M = mat ? e->d_M : nullptr; rf.W = W;
+    rf.xtrig = wave_sample_trig(e);
 
     const int guard = 4 * W + 8;
     int rounds = 0;
@@ -1416,7 +1431,8 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
                                e->h_summary_dev + 4, e->d_summary, ++e->seq);
         } else {
             int n_chunks = 1;
-            TRY(launch_nn(e, record_view(e, W), xs, W, nullptr, true, nullptr, nullptr, nullptr, st, false, &n_chunks));
+            TRY(launch_nn(e, record_view(e, W), xs, W, nullptr, true, nullptr, nullptr, nullptr, st, false, &n_chunks, -1, false,
+                          wave_sample_trig(e)));
             hipLaunchKernelGGL(k_decide, dim3(1), dim3(dthreads), 0, st, e->d_rec, e->L, W, e->d_pcost, e->d_pidx, n_chunks, tri_chunk(),
                                e->d_par_done, e->d_par_want, e->d_changed, e->d_stale, e->d_need, e->d_list, e->h_summary_dev,
                                e->h_summary_dev + 4, e->d_summary, ++e->seq);

@@ -143,22 +143,25 @@ __device__ __forceinline__ double quad_cost(const double* e, const double* Sd) {
 }
 
 // ------------------------------------------------------------------------------------------
-// NN scan.  grid = (ceil(W/64), n_chunks), block = 64.  Lane = sample, uniform loop over the
-// chunk's nodes.  TRI: only nodes with index < sample index are eligible (in-wave pass; a
-// separate instantiation so that profiles tell it apart from the tree scan).
-// Output: partial minima over the eligible nodes (not ignored / accepted in-wave record) at
-// [chunk * ps_c + sample * ps_t]: the tree scan writes sample-major (ps_c = 1) so that k_nn_reduce reads a
-// sample's partials contiguously; the in-wave scan writes chunk-major (ps_t = 1), the order k_decide wants.
+// NN scan.  grid = (ceil(W/64), n_chunks), block = 64 (one wavefront).  Lane = sample; the loop over the chunk's
+// nodes is WAVE-UNIFORM, so a node's data (state, trig, eligibility) is the same for all 64 lanes: it is fetched
+// by the scalar unit (s_load through the scalar cache, straight from the node table in L2) into SGPRs and used as
+// the scalar operand of the per-lane fp64 arithmetic.  Nothing is staged in LDS and no vector-memory or LDS
+// instruction sits in the inner loop -- round 1 read every node with five ds_read_b128 broadcasts per wavefront and
+// was bound by the LDS pipe, not by the VALU.  Ineligible nodes (ignore bit / empty in-wave record) are skipped by a
+// scalar branch before any arithmetic.
+// TRI: only nodes with index < sample index are eligible (in-wave pass; a separate instantiation so that profiles
+// tell it apart from the tree scan).
+// Output: partial minima over the eligible nodes at [chunk * ps_c + sample * ps_t]: the tree scan writes
+// sample-major (ps_c = 1) so that the reduce reads a sample's partials contiguously; the in-wave scan writes
+// chunk-major (ps_t = 1), the order k_decide wants.
+// xtrig: cos/sin of the samples' angular coordinates [W][2*NW] if the caller has them (the engine computes them once
+// per sample batch), else null and they are computed here.
 template <class S, int DENSE, bool TRI>
-__global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __restrict__ xs, int W,
-                                                const double* __restrict__ Sd, int chunk,
+__global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __restrict__ xs, const double* __restrict__ xtrig,
+                                                int W, const double* __restrict__ Sd, int chunk,
                                                 double* __restrict__ pcost, int* __restrict__ pidx,
                                                 int ps_c, int ps_t) {
-    // one node = N state doubles + 2*NW trig doubles + 1 eligibility flag, padded to an even count so
-    // that every node starts 16-byte aligned in LDS (ds_read_b128 broadcasts)
-    constexpr int NV = S::N + 2 * S::NW;
-    constexpr int NVP = (NV + 1 + S::NW + 1) & ~1;      // + flag + one precomputed angle error per wrapped state
-    __shared__ __attribute__((aligned(16))) double tile[64 * NVP];
     const int lane = threadIdx.x;
     // XCD-aware tile mapping: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each
     // with its own L2.  Re-index so that XCD k owns a contiguous band of node chunks (for every sample
@@ -186,10 +189,15 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
     double xg[S::N], gtrig[2 * S::NW + 1];
 #pragma unroll
     for (int d = 0; d < S::N; ++d) xg[d] = xs[(size_t)ts * S::N + d];
-    trig_of<S>(xg, gtrig);
+    if (xtrig) {
+#pragma unroll
+        for (int j = 0; j < 2 * S::NW; ++j) gtrig[j] = xtrig[(size_t)ts * (2 * S::NW) + j];
+    } else {
+        trig_of<S>(xg, gtrig);
+    }
     // When every sample of this wavefront has the same angular coordinates (e.g. the boat demos sample
     // the heading over the empty interval (0,0), demo_boat_advanced.py:231), the angle error of a node is
-    // the same for all 64 lanes: compute it once per node while staging instead of once per pair.
+    // the same for all 64 lanes: one lane computes it per node (64 nodes at a time) instead of every pair.
     bool same_angles = S::NW > 0;
 #pragma unroll
     for (int j = 0; j < 2 * S::NW; ++j) same_angles = same_angles && (gtrig[j] == __shfl(gtrig[j], 0));
@@ -197,53 +205,131 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
 
     double best = INFINITY;
     int bidx = -1;
+    // (two copies of the loop, chosen once: the shared-angle case must not carry the per-pair atan2 in its body)
+    auto scan = [&](auto same_c) {
+    constexpr bool SAME = decltype(same_c)::value;
     for (int base = i0; base < i1; base += 64) {
         const int cnt = (i1 - base) < 64 ? (i1 - base) : 64;
-        __syncthreads();
-        if (lane < cnt) {                      // lane j stages node base+j (coalesced on the SoA tree)
-            const int i = base + lane;
-            double* nd = tile + lane * NVP;
+        // eligibility of the tile's nodes as one wave-uniform 64-bit mask (lane j looks at node base + j)
+        bool el = false;
+        if (lane < cnt) {
+            const long long i = base + lane;
+            if constexpr (TRI) el = nv.len[i * nv.sn] > 0.0;
+            else el = nv.ignore ? ((nv.ignore[i >> 6] >> (i & 63)) & 1ull) == 0 : true;
+        }
+        unsigned long long m = __ballot(el);
+        if (m == 0) continue;
+        // shared-angle case: lane j computes the angle error(s) of node base + j (coalesced on the SoA tree); the node
+        // loop then pulls them out of that lane's register with v_readlane (no LDS: LDS and scalar loads share one
+        // completion counter, so waiting for an LDS word would also wait for the prefetched scalar loads)
+        double werr[S::NW > 0 ? S::NW : 1];
+        if constexpr (SAME) {
+            const long long i = base + (lane < cnt ? lane : 0);
 #pragma unroll
-            for (int d = 0; d < S::N; ++d) nd[d] = nv.x[(long long)i * nv.sn + d * nv.sd];
+            for (int k = 0; k < S::NW; ++k)
+                werr[k] = wrap_err(gtrig[2 * k], gtrig[2 * k + 1], nv.trig[i * nv.tn + (2 * k) * nv.td],
+                                   nv.trig[i * nv.tn + (2 * k + 1) * nv.td]);
+        }
+        // Walk the eligible nodes two at a time (an aligned pair of node slots = one 16-byte scalar load per state
+        // component on the SoA tree; the in-wave records are AoS and take two 8-byte loads).  The pair fetched for the
+        // NEXT iteration is in flight while the vector unit works on the current one: scalar loads return out of order,
+        // so a wait right before the arithmetic would otherwise expose their latency on every node.  Two buffers
+        // alternate (A, B) instead of being copied: scalar-ALU instructions share the issue bandwidth of the wavefront
+        // with the fp64 ones, so the loop keeps them to a handful per node.
+        constexpr int NT = S::N + 2 * S::NW;
+        struct Pair { double a[NT + 1], b[NT + 1]; };
+        unsigned long long pm = (m | (m >> 1)) & 0x5555555555555555ull;   // bit 2g set: pair g holds an eligible node
+        auto fetch = [&](int g2, Pair& q) {                      // g2 = 2g: slots g2, g2 + 1 of the tile
+            const long long i = base + g2;
+            if constexpr (!TRI) {
+                // SoA, node index fastest: the pair is contiguous (reading one slot past the chunk is harmless, the
+                // tables are padded to a multiple of 64 nodes and that slot is masked out)
 #pragma unroll
-            for (int j = 0; j < 2 * S::NW; ++j) nd[S::N + j] = nv.trig[(long long)i * nv.tn + j * nv.td];
-            bool ign;
-            if constexpr (TRI) ign = !(nv.len[(long long)i * nv.sn] > 0.0);
-            else ign = nv.ignore ? ((nv.ignore[i >> 6] >> (i & 63)) & 1ull) != 0 : false;
-            nd[NV] = ign ? 1.0 : 0.0;
-            if (same_angles) {
+                for (int d = 0; d < S::N; ++d) {
+                    const double2 v = *reinterpret_cast<const double2*>(nv.x + i + d * nv.sd);
+                    q.a[d] = v.x; q.b[d] = v.y;
+                }
+                if constexpr (!SAME) {
+#pragma unroll
+                    for (int k = 0; k < 2 * S::NW; ++k) {
+                        const double2 v = *reinterpret_cast<const double2*>(nv.trig + i + k * nv.td);
+                        q.a[S::N + k] = v.x; q.b[S::N + k] = v.y;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) {
+                    q.a[d] = nv.x[i * nv.sn + d * nv.sd];
+                    q.b[d] = nv.x[(i + 1) * nv.sn + d * nv.sd];
+                }
+                if constexpr (!SAME) {
+#pragma unroll
+                    for (int k = 0; k < 2 * S::NW; ++k) {
+                        q.a[S::N + k] = nv.trig[i * nv.tn + k * nv.td];
+                        q.b[S::N + k] = nv.trig[(i + 1) * nv.tn + k * nv.td];
+                    }
+                }
+            }
+        };
+        auto visit = [&](const double* nd, int jj) {            // one (sample, node) pair per lane
+            double e[S::N];
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) e[d] = xg[d] - nd[d];
+            if constexpr (SAME) {
 #pragma unroll
                 for (int k = 0; k < S::NW; ++k)
-                    nd[NV + 1 + k] = wrap_err(gtrig[2 * k], gtrig[2 * k + 1], nd[S::N + 2 * k], nd[S::N + 2 * k + 1]);
-            }
-        }
-        __syncthreads();
-#pragma unroll 2
-        for (int j = 0; j < cnt; ++j) {        // every lane reads the same node: LDS broadcast
-            const double* nd = tile + j * NVP;
-            double x[S::N], trig[2 * S::NW + 1], e[S::N];
-#pragma unroll
-            for (int d = 0; d < S::N; ++d) x[d] = nd[d];
-#pragma unroll
-            for (int k = 0; k < 2 * S::NW; ++k) trig[k] = nd[S::N + k];
-            if (same_angles) {
-#pragma unroll
-                for (int d = 0; d < S::N; ++d) e[d] = xg[d] - x[d];
-#pragma unroll
-                for (int k = 0; k < S::NW; ++k) e[S::wd(k)] = nd[NV + 1 + k];
+                    e[S::wd(k)] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(werr[k]), jj),
+                                                   __builtin_amdgcn_readlane(__double2loint(werr[k]), jj));
             } else {
-                erf_cached<S>(xg, gtrig, x, trig, e);
+#pragma unroll
+                for (int k = 0; k < S::NW; ++k)
+                    e[S::wd(k)] = wrap_err(gtrig[2 * k], gtrig[2 * k + 1], nd[S::N + 2 * k], nd[S::N + 2 * k + 1]);
             }
             const double c = quad_cost<S, DENSE>(e, Sd);
-            const int i = base + j;
-            const bool ign = nd[NV] != 0.0;
+            const int i = base + jj;
             const bool ok = TRI ? (i < t) : true;
-            if (ok && !ign && c < best) { best = c; bidx = i; }
+            if (ok && c < best) { best = c; bidx = i; }
+        };
+        auto work = [&](const Pair& q, int g2) {
+            if ((m >> g2) & 1ull) visit(q.a, g2);
+            if ((m >> g2) & 2ull) visit(q.b, g2 + 1);
+        };
+        Pair A, B;
+        int ga = __builtin_ctzll(pm), gb = 0;
+        pm &= pm - 1;
+        fetch(ga, A);
+        while (true) {
+            bool more = pm != 0;
+            if (more) { gb = __builtin_ctzll(pm); pm &= pm - 1; fetch(gb, B); }
+            work(A, ga);
+            if (!more) break;
+            more = pm != 0;
+            if (more) { ga = __builtin_ctzll(pm); pm &= pm - 1; fetch(ga, A); }
+            work(B, gb);
+            if (!more) break;
         }
     }
+    };
+    if (same_angles) scan(std::true_type{}); else scan(std::false_type{});
     if (t < W) {
         const size_t o = (size_t)by * ps_c + (size_t)t * ps_t;
         pcost[o] = best; pidx[o] = bidx;
+    }
+}
+
+// cos/sin of the angular coordinates of a batch of samples, [B][2*NW]: computed once per sample batch so that
+// neither the scan nor the steer pays a sincos per (sample, launch)
+template <class S>
+__global__ void k_sample_trig(const double* __restrict__ xs, int B, double* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if constexpr (S::NW > 0) {
+        double x[S::N], tr[2 * S::NW + 1];
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) x[d] = xs[(size_t)b * S::N + d];
+        trig_of<S>(x, tr);
+#pragma unroll
+        for (int j = 0; j < 2 * S::NW; ++j) out[(size_t)b * (2 * S::NW) + j] = tr[j];
     }
 }
 
@@ -427,6 +513,7 @@ struct SteerFuse {
     NodeView nv; const double* Sd;
     unsigned char* changed; unsigned char* stale; int* par_out;   // wave bookkeeping initialised by the prologue
     double* M; int W;                                        // M != null: row epilogue, leading dimension W
+    const double* xtrig;                                     // cos/sin of the samples' angular coordinates [..][2*NW], or null
 };
 
 #ifdef STEER_TIMING
@@ -457,13 +544,19 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
     const int lane = threadIdx.x;
     __shared__ double Pl[MAXP];
     __shared__ double tol_l[MAXN], glo_l[MAXN], ghi_l[MAXN];
+    __shared__ double node_l[MAXN + 4 + MAXM * MAXN];        // the new node on its way out: xend | trig | K
     const int t = list ? list[blockIdx.x + (list_count ? lo : 0)] : lo + (int)blockIdx.x;
     double* my = rec + (size_t)t * L.R;
 
     double x[S::N], K[S::M * S::N], trig[2 * S::NW + 1], xt[S::N], ttrig[2 * S::NW + 1];
 #pragma unroll
     for (int d = 0; d < S::N; ++d) xt[d] = xs[(size_t)t * S::N + d];
-    trig_of<S>(xt, ttrig);
+    if (f.xtrig) {
+#pragma unroll
+        for (int j = 0; j < 2 * S::NW; ++j) ttrig[j] = f.xtrig[(size_t)t * (2 * S::NW) + j];
+    } else {
+        trig_of<S>(xt, ttrig);
+    }
     int pref;
     if (f.n_chunks > 0) {
         // nearest node of this sample from the scan's partial minima (see k_nn_reduce for the rules)
@@ -614,9 +707,17 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         flags = in ? 1 : 0;
         for (int q = lane; q < cnt * S::N; q += 64) my[L.off_xseq + q] = hx[q];
         for (int q = lane; q < cnt * S::M; q += 64) my[L.off_useq + q] = hu[q];
-        store_uniform<S::N>(my + L.off_xend, x, lane);
-        if constexpr (S::NW > 0) store_uniform<2 * S::NW>(my + L.off_trig, trig, lane);
-        store_uniform<S::M * S::N>(my + L.off_K, K, lane);
+        // The node itself (xend | trig | K, contiguous in the record) leaves through LDS: every lane holds the same
+        // wave-uniform values, so all of them write the same bits to the same LDS words (static indices, no
+        // scratch, no select chain) and the lanes then copy one word each to HBM.
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) node_l[d] = x[d];
+#pragma unroll
+        for (int j = 0; j < 2 * S::NW; ++j) node_l[S::N + j] = trig[j];
+#pragma unroll
+        for (int j = 0; j < S::M * S::N; ++j) node_l[S::N + 2 * S::NW + j] = K[j];
+        __syncthreads();
+        for (int q = lane; q < S::N + 2 * S::NW + S::M * S::N; q += 64) my[L.off_xend + q] = node_l[q];
     }
     if (lane == 0) {
         my[L.off_len] = (double)cnt;
@@ -632,7 +733,12 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
             double xu[S::N], tu[2 * S::NW + 1], e[S::N];
 #pragma unroll
             for (int d = 0; d < S::N; ++d) xu[d] = xs[(size_t)u * S::N + d];
-            trig_of<S>(xu, tu);
+            if (f.xtrig) {
+#pragma unroll
+                for (int j = 0; j < 2 * S::NW; ++j) tu[j] = f.xtrig[(size_t)u * (2 * S::NW) + j];
+            } else {
+                trig_of<S>(xu, tu);
+            }
             double c = INFINITY;
             if (cnt > 0) {
                 erf_cached<S>(xu, tu, x, trig, e);
