@@ -173,6 +173,10 @@ struct lqrrt_engine {
     // the reference's Planner.horizon_iters in adaptive-horizon mode (replayed over committed attempts)
     int h_iters = 1, hspan_min = 1;
 
+    // sampler with fixed angular coordinates: the tree keeps the nodes' angle errors w.r.t. them (TreeView::werr)
+    FixedAngles fix{};
+    bool werr_valid = false;            // tv.werr holds every node [0, N) for the current `fix`
+
     // adaptive wave size (exactness does not depend on W, only speed does)
     double ctl_w = 0.0;
     bool sync_mode = false;             // synchronous wave semantics (LQRRT_WAVE_SYNCHRONOUS) instead of exact
@@ -232,6 +236,9 @@ static bool model_dims(int model, int* n, int* m, int* nw) {
     return false;
 }
 
+// index of the k-th angular (wrapped) state of a model: S::wd(k) on the host
+static int model_wd(int model, int k) { return model == LQRRT_MODEL_PENDULUM ? k : 2; }
+
 static size_t geo_lds_bytes(const lqrrt_engine* e) {
     if (e->geo.og) return e->geo.og_lds ? sizeof(double) * (size_t)2 * e->geo.V : 0;
     return e->geo.oc ? sizeof(double) * ((size_t)2 * e->geo.V + (size_t)4 * e->geo.O) : 0;
@@ -256,6 +263,8 @@ static NodeView tree_view(const lqrrt_engine* e, bool use_ignore) {
     v.sn = 1; v.sd = e->cap; v.tn = 1; v.td = e->cap;
     v.ignore = use_ignore ? e->tv.ignore : nullptr;
     v.len = nullptr;
+    v.werr = (e->fix.on && e->werr_valid) ? e->tv.werr : nullptr; v.wk = e->cap;
+    for (int j = 0; j < 4; ++j) v.wtrig[j] = e->fix.t[j];
     v.count = e->N; v.pad = 0;
     return v;
 }
@@ -265,10 +274,15 @@ static NodeView record_view(const lqrrt_engine* e, int W) {
     v.x = e->d_rec + e->L.off_xend; v.trig = e->d_rec + e->L.off_trig;
     v.sn = e->L.R; v.sd = 1; v.tn = e->L.R; v.td = 1;
     v.ignore = nullptr;
+    v.werr = nullptr; v.wk = 0;
+    for (int j = 0; j < 4; ++j) v.wtrig[j] = 0.0;
     v.len = e->d_rec + e->L.off_len;
     v.count = W; v.pad = 0;
     return v;
 }
+
+// Brings tv.werr up to date for all nodes (after a sampler change, a tree load, ...): appends keep it current.
+static int ensure_werr(lqrrt_engine* e, hipStream_t st);
 
 // --------------------------------------------------------------------------------------------
 // profiling helpers
@@ -322,12 +336,16 @@ static int tri_chunk() {
 }
 
 static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
+    // One wavefront per (64-sample group, node chunk).  The scan hides its scalar-load latency behind the other
+    // wavefronts of a SIMD, so the launch is cut into ~4 wavefronts per SIMD (1024 SIMDs) when there is enough work;
+    // chunks are multiples of 8 nodes (aligned 4-node scalar loads, whole quads).
     const int groups = (W + 63) / 64;
-    static const int target_waves = getenv("LQRRT_NN_WAVES") ? atoi(getenv("LQRRT_NN_WAVES")) : 2048;
+    static const int target_waves = getenv("LQRRT_NN_WAVES") ? atoi(getenv("LQRRT_NN_WAVES")) : 4096;
+    static const int min_chunk = getenv("LQRRT_NN_MIN_CHUNK") ? atoi(getenv("LQRRT_NN_MIN_CHUNK")) : 16;
     int want = target_waves / (groups > 0 ? groups : 1);
     want = std::max(1, std::min(want, (int)lqrrt_engine::MAXCH));
     int c = (count + want - 1) / want;
-    c = std::max(c, 8);
+    c = std::max((c + 7) / 8 * 8, std::max(8, min_chunk / 8 * 8));
     *chunk = c;
     *n_chunks = std::max(1, (count + c - 1) / c);
 }
@@ -403,6 +421,14 @@ static int launch_steer(lqrrt_engine* e, const double* xs, const int* list, int 
     return 0;
 }
 
+static int ensure_werr(lqrrt_engine* e, hipStream_t st) {
+    if (!e->fix.on || e->werr_valid || e->N < 1 || e->nw == 0) return 0;
+    DISPATCH(e, hipLaunchKernelGGL((k_tree_werr<S>), dim3((e->N + 255) / 256), dim3(256), 0, st, e->tv, 0, e->N, e->fix));
+    HIPCHK(hipGetLastError());
+    e->werr_valid = true;
+    return 0;
+}
+
 // --------------------------------------------------------------------------------------------
 // lifecycle
 
@@ -416,7 +442,7 @@ extern "C" int lqrrt_device_count(void) {
 }
 
 static void free_all(lqrrt_engine* e) {
-    void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_og, e->d_ogc, e->d_cell_start, e->d_cell_items, e->d_S, e->tv.state, e->tv.trig, e->tv.K, e->tv.pID, e->tv.elen,
+    void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_og, e->d_ogc, e->d_cell_start, e->d_cell_items, e->d_S, e->tv.state, e->tv.trig, e->tv.werr, e->tv.K, e->tv.pID, e->tv.elen,
                     e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_M,
                     e->d_pidx, e->d_par_done, e->d_par_want, e->d_list,
                     e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_pool_trig, e->d_cand, e->d_flags};
@@ -604,6 +630,7 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     e->tv.cap = e->cap;
     if (!rc) rc = dalloc(&e->tv.state, (size_t)n * e->cap);
     if (!rc) rc = dalloc(&e->tv.trig, (size_t)(2 * nw + 1) * e->cap);
+    if (!rc) rc = dalloc(&e->tv.werr, (size_t)(nw + 1) * e->cap);
     if (!rc) rc = dalloc(&e->tv.K, (size_t)e->cap * m * n);
     if (!rc) rc = dalloc(&e->tv.pID, (size_t)e->cap);
     if (!rc) rc = dalloc(&e->tv.elen, (size_t)e->cap);
@@ -731,6 +758,18 @@ extern "C" int lqrrt_engine_set_sampler(lqrrt_engine* e, const lqrrt_sampler_des
     e->has_sampler = true;
     e->explicit_samples = false;
     invalidate_samples(e);
+    // fixed angular coordinates: zero-width span and never goal-biased on every wrapped state (planner.py:201-206:
+    // the sample's angle is then `center` in every draw)
+    FixedAngles fx;
+    memset(&fx, 0, sizeof fx);
+    fx.on = e->nw > 0;
+    for (int k = 0; k < e->nw; ++k) {
+        const int d = model_wd(e->model, k);
+        if (s->spans[d] != 0.0 || s->goal_bias[d] > 0.0) fx.on = 0;
+        const double ang = s->centers[d] + s->spans[d] * (0.5 - 0.5);
+        lq_sincos(ang, &fx.t[2 * k + 1], &fx.t[2 * k]);
+    }
+    if (memcmp(&fx, &e->fix, sizeof fx) != 0) { e->fix = fx; e->werr_valid = false; }
     return 0;
 }
 
@@ -795,6 +834,7 @@ extern "C" int lqrrt_tree_reset(lqrrt_engine* e, const double* x0_host, void* st
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     e->N = 1;
+    e->werr_valid = false;
     e->h_pid.assign(1, -1);
     e->h_elen.assign(1, 1);
     std::fill(e->h_ign.begin(), e->h_ign.end(), 0ull);
@@ -946,6 +986,7 @@ extern "C" int lqrrt_tree_load(lqrrt_engine* e, int count, const double* states,
     e->ign_hi = std::max(e->ign_hi, std::max(e->N, count));
     e->ign_dirty = true;
     e->N = count;
+    e->werr_valid = false;
     TRY(flush_ignore(e, st, false));
     HIPCHK(hipStreamSynchronize(st));
     e->goal_hits = 0; e->best_end = -1; e->best_steps = -1;
@@ -1081,6 +1122,7 @@ extern "C" int lqrrt_nn_argmin(lqrrt_engine* e, const double* xs, int W, const d
     TRY(use_device(e));
     hipStream_t st = (hipStream_t)stream;
     TRY(flush_ignore(e, st, true));
+    TRY(ensure_werr(e, st));
     return launch_nn(e, tree_view(e, use_ignore != 0), xs, W, S_dev, false, id, cost, nullptr, st, true);
 }
 
@@ -1291,6 +1333,7 @@ extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void
     hipStream_t st = (hipStream_t)stream;
     TRY(ensure_samples(e, e->cursor + W, st));
     TRY(flush_ignore(e, st, false));
+    TRY(ensure_werr(e, st));
     const double* xs = wave_samples(e);
     const int cnt = hi - lo;
     const bool whole = (lo == 0 && hi == W);
@@ -1482,7 +1525,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     const int base = e->N;
     if (acc > 0) {
         // ranks are read by the kernel straight from pinned host memory (written before the launch)
-        DISPATCH(e, hipLaunchKernelGGL((k_append<S>), dim3(C), dim3(64), 0, st, e->tv, e->d_rec, e->L, C, base, e->h_rank_dev, e->d_par_done));
+        DISPATCH(e, hipLaunchKernelGGL((k_append<S>), dim3(C), dim3(64), 0, st, e->tv, e->d_rec, e->L, C, base, e->h_rank_dev, e->d_par_done, e->fix));
         HIPCHK(hipGetLastError());
     }
     if (e->res.adaptive) {

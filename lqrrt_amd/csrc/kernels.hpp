@@ -40,12 +40,19 @@ struct NodeView {
     long long sn, sd, tn, td;
     const unsigned long long* ignore;   // bit i set -> node i not eligible (may be null)
     const double* len;      // in-wave pass: node i eligible iff len[i*sn] > 0 (record field), else null
+    // Optional table of per-node angle errors w.r.t. ONE fixed sample angle per wrapped state (the default sampler
+    // with a zero-width span on that state, e.g. the boats' heading: demo_boat_advanced.py:231): entry k of node i at
+    // werr[k*wk + i], valid for samples whose cos/sin equal wtrig bit for bit.  Null = none.
+    const double* werr;
+    long long wk;
+    double wtrig[4];
     int count, pad;
 };
 
 struct TreeView {
     double* state;          // [n][cap]
     double* trig;           // [2*NW][cap]
+    double* werr;           // [NW][cap]: angle errors w.r.t. the sampler's fixed angles (NodeView::werr), when it has them
     double* K;              // [cap][m*n]
     int* pID;               // [cap]
     int* elen;              // [cap]
@@ -54,6 +61,10 @@ struct TreeView {
     unsigned long long* ignore;  // [cap/64]
     int cap, H;
 };
+
+// The default sampler's fixed angular coordinates (zero-width span on every wrapped state), as cos/sin pairs: the tree
+// then keeps every node's angle error w.r.t. them (TreeView::werr) so that the scan needs no atan2 at all.
+struct FixedAngles { double t[4]; int on, pad; };
 
 // Wave record layout (doubles).  One record per sample of the wave.
 struct RecLayout {
@@ -195,19 +206,29 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
     } else {
         trig_of<S>(xg, gtrig);
     }
-    // When every sample of this wavefront has the same angular coordinates (e.g. the boat demos sample
-    // the heading over the empty interval (0,0), demo_boat_advanced.py:231), the angle error of a node is
-    // the same for all 64 lanes: one lane computes it per node (64 nodes at a time) instead of every pair.
-    bool same_angles = S::NW > 0;
+    // Angle errors.  mode 2: every sample of this wavefront has the sampler's fixed angular coordinates and the tree
+    // carries the nodes' errors w.r.t. them (NodeView::werr): the error is one more scalar load per node.  mode 1: the
+    // wavefront's samples share their angular coordinates (any value): lane j computes the error of node j of a
+    // 64-node tile once and the node loop pulls it out of that lane with v_readlane (no LDS: LDS and scalar loads
+    // share one completion counter, so waiting for an LDS word would also wait for the prefetched scalar loads).
+    // mode 0: one atan2 per (sample, node) pair.
+    int mode = 0;
+    if constexpr (S::NW > 0) {
+        bool same = true, fixed = nv.werr != nullptr;
 #pragma unroll
-    for (int j = 0; j < 2 * S::NW; ++j) same_angles = same_angles && (gtrig[j] == __shfl(gtrig[j], 0));
-    same_angles = S::NW > 0 && __all(same_angles) != 0;
+        for (int j = 0; j < 2 * S::NW; ++j) {
+            same = same && (gtrig[j] == __shfl(gtrig[j], 0));
+            fixed = fixed && (gtrig[j] == nv.wtrig[j]);
+        }
+        mode = __all(fixed) ? 2 : (__all(same) ? 1 : 0);
+    }
 
     double best = INFINITY;
     int bidx = -1;
-    // (two copies of the loop, chosen once: the shared-angle case must not carry the per-pair atan2 in its body)
-    auto scan = [&](auto same_c) {
-    constexpr bool SAME = decltype(same_c)::value;
+    // (one copy of the loop per mode, chosen once per wavefront: the cheap modes must not carry the atan2 in their body)
+    auto scan = [&](auto mode_c) {
+    constexpr int MODE = S::NW > 0 ? decltype(mode_c)::value : 0;
+    constexpr int NT = S::N + (MODE == 0 ? 2 * S::NW : (MODE == 2 ? S::NW : 0));   // doubles fetched per node
     for (int base = i0; base < i1; base += 64) {
         const int cnt = (i1 - base) < 64 ? (i1 - base) : 64;
         // eligibility of the tile's nodes as one wave-uniform 64-bit mask (lane j looks at node base + j)
@@ -217,56 +238,49 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
             if constexpr (TRI) el = nv.len[i * nv.sn] > 0.0;
             else el = nv.ignore ? ((nv.ignore[i >> 6] >> (i & 63)) & 1ull) == 0 : true;
         }
-        unsigned long long m = __ballot(el);
+        const unsigned long long m = __ballot(el);
         if (m == 0) continue;
-        // shared-angle case: lane j computes the angle error(s) of node base + j (coalesced on the SoA tree); the node
-        // loop then pulls them out of that lane's register with v_readlane (no LDS: LDS and scalar loads share one
-        // completion counter, so waiting for an LDS word would also wait for the prefetched scalar loads)
         double werr[S::NW > 0 ? S::NW : 1];
-        if constexpr (SAME) {
-            const long long i = base + (lane < cnt ? lane : 0);
+        if constexpr (MODE == 1) {
+            const long long i = base + (lane < cnt ? lane : 0);  // coalesced on the SoA tree
 #pragma unroll
             for (int k = 0; k < S::NW; ++k)
                 werr[k] = wrap_err(gtrig[2 * k], gtrig[2 * k + 1], nv.trig[i * nv.tn + (2 * k) * nv.td],
                                    nv.trig[i * nv.tn + (2 * k + 1) * nv.td]);
         }
-        // Walk the eligible nodes two at a time (an aligned pair of node slots = one 16-byte scalar load per state
-        // component on the SoA tree; the in-wave records are AoS and take two 8-byte loads).  The pair fetched for the
-        // NEXT iteration is in flight while the vector unit works on the current one: scalar loads return out of order,
-        // so a wait right before the arithmetic would otherwise expose their latency on every node.  Two buffers
-        // alternate (A, B) instead of being copied: scalar-ALU instructions share the issue bandwidth of the wavefront
-        // with the fp64 ones, so the loop keeps them to a handful per node.
-        constexpr int NT = S::N + 2 * S::NW;
-        struct Pair { double a[NT + 1], b[NT + 1]; };
-        unsigned long long pm = (m | (m >> 1)) & 0x5555555555555555ull;   // bit 2g set: pair g holds an eligible node
-        auto fetch = [&](int g2, Pair& q) {                      // g2 = 2g: slots g2, g2 + 1 of the tile
-            const long long i = base + g2;
+        // Nodes are fetched four at a time: an aligned quad of node slots is one 32-byte scalar load per component on
+        // the SoA tree (the in-wave records are AoS and take four 8-byte loads).  The load latency is hidden by the other
+        // wavefronts of the SIMD -- the launch is cut into enough workgroups for several of them -- rather than by
+        // software pipelining inside this one: a second quad in flight needs more SGPRs than the wavefront has, and
+        // scalar-ALU instructions share its issue bandwidth with the fp64 ones, so the loop keeps them to a handful per
+        // node (no mask tests at all when the whole tile is eligible).
+        struct Quad { double v[4][NT + 1]; };
+        auto fetch = [&](int j0, Quad& q) {                      // slots j0 .. j0 + 3 of the tile
+            const long long i = base + j0;
             if constexpr (!TRI) {
-                // SoA, node index fastest: the pair is contiguous (reading one slot past the chunk is harmless, the
-                // tables are padded to a multiple of 64 nodes and that slot is masked out)
+                // SoA, node index fastest: the quad is contiguous (reading up to three slots past the chunk is harmless:
+                // the tables are padded to a multiple of 64 nodes and those slots are never visited)
+                auto quad = [&](const double* p, int c) {
+                    const double4 w = *reinterpret_cast<const double4*>(p);
+                    q.v[0][c] = w.x; q.v[1][c] = w.y; q.v[2][c] = w.z; q.v[3][c] = w.w;
+                };
 #pragma unroll
-                for (int d = 0; d < S::N; ++d) {
-                    const double2 v = *reinterpret_cast<const double2*>(nv.x + i + d * nv.sd);
-                    q.a[d] = v.x; q.b[d] = v.y;
-                }
-                if constexpr (!SAME) {
+                for (int d = 0; d < S::N; ++d) quad(nv.x + i + d * nv.sd, d);
+                if constexpr (MODE == 0) {
 #pragma unroll
-                    for (int k = 0; k < 2 * S::NW; ++k) {
-                        const double2 v = *reinterpret_cast<const double2*>(nv.trig + i + k * nv.td);
-                        q.a[S::N + k] = v.x; q.b[S::N + k] = v.y;
-                    }
+                    for (int k = 0; k < 2 * S::NW; ++k) quad(nv.trig + i + k * nv.td, S::N + k);
+                } else if constexpr (MODE == 2) {
+#pragma unroll
+                    for (int k = 0; k < S::NW; ++k) quad(nv.werr + i + k * nv.wk, S::N + k);
                 }
             } else {
 #pragma unroll
-                for (int d = 0; d < S::N; ++d) {
-                    q.a[d] = nv.x[i * nv.sn + d * nv.sd];
-                    q.b[d] = nv.x[(i + 1) * nv.sn + d * nv.sd];
-                }
-                if constexpr (!SAME) {
+                for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                    for (int k = 0; k < 2 * S::NW; ++k) {
-                        q.a[S::N + k] = nv.trig[i * nv.tn + k * nv.td];
-                        q.b[S::N + k] = nv.trig[(i + 1) * nv.tn + k * nv.td];
+                    for (int d = 0; d < S::N; ++d) q.v[r][d] = nv.x[(i + r) * nv.sn + d * nv.sd];
+                    if constexpr (MODE == 0) {
+#pragma unroll
+                        for (int k = 0; k < 2 * S::NW; ++k) q.v[r][S::N + k] = nv.trig[(i + r) * nv.tn + k * nv.td];
                     }
                 }
             }
@@ -275,42 +289,44 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
             double e[S::N];
 #pragma unroll
             for (int d = 0; d < S::N; ++d) e[d] = xg[d] - nd[d];
-            if constexpr (SAME) {
 #pragma unroll
-                for (int k = 0; k < S::NW; ++k)
+            for (int k = 0; k < S::NW; ++k) {
+                if constexpr (MODE == 2) e[S::wd(k)] = nd[S::N + k];
+                else if constexpr (MODE == 1)
                     e[S::wd(k)] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(werr[k]), jj),
                                                    __builtin_amdgcn_readlane(__double2loint(werr[k]), jj));
-            } else {
-#pragma unroll
-                for (int k = 0; k < S::NW; ++k)
-                    e[S::wd(k)] = wrap_err(gtrig[2 * k], gtrig[2 * k + 1], nd[S::N + 2 * k], nd[S::N + 2 * k + 1]);
+                else e[S::wd(k)] = wrap_err(gtrig[2 * k], gtrig[2 * k + 1], nd[S::N + 2 * k], nd[S::N + 2 * k + 1]);
             }
             const double c = quad_cost<S, DENSE>(e, Sd);
             const int i = base + jj;
-            const bool ok = TRI ? (i < t) : true;
-            if (ok && c < best) { best = c; bidx = i; }
+            const bool ok = (TRI ? (i < t) : true) && c < best;   // strict: the older node keeps an exactly equal cost
+            bidx = ok ? i : bidx;
+            best = ok ? c : best;
         };
-        auto work = [&](const Pair& q, int g2) {
-            if ((m >> g2) & 1ull) visit(q.a, g2);
-            if ((m >> g2) & 2ull) visit(q.b, g2 + 1);
-        };
-        Pair A, B;
-        int ga = __builtin_ctzll(pm), gb = 0;
-        pm &= pm - 1;
-        fetch(ga, A);
-        while (true) {
-            bool more = pm != 0;
-            if (more) { gb = __builtin_ctzll(pm); pm &= pm - 1; fetch(gb, B); }
-            work(A, ga);
-            if (!more) break;
-            more = pm != 0;
-            if (more) { ga = __builtin_ctzll(pm); pm &= pm - 1; fetch(ga, A); }
-            work(B, gb);
-            if (!more) break;
+        Quad Q;
+        if (m == (cnt == 64 ? ~0ull : (1ull << cnt) - 1ull) && (cnt & 3) == 0) {
+#pragma unroll 1
+            for (int j0 = 0; j0 < cnt; j0 += 4) {                // every node of the tile eligible: no mask tests
+                fetch(j0, Q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) visit(Q.v[r], j0 + r);
+            }
+            continue;
+        }
+        unsigned long long qm = (m | (m >> 1) | (m >> 2) | (m >> 3)) & 0x1111111111111111ull;   // bit 4g: quad g has an eligible node
+        while (qm) {
+            const int j0 = __builtin_ctzll(qm);
+            qm &= qm - 1;
+            fetch(j0, Q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if ((m >> (j0 + r)) & 1ull) visit(Q.v[r], j0 + r);
         }
     }
     };
-    if (same_angles) scan(std::true_type{}); else scan(std::false_type{});
+    if (mode == 2) scan(std::integral_constant<int, 2>{});
+    else if (mode == 1) scan(std::integral_constant<int, 1>{});
+    else scan(std::integral_constant<int, 0>{});
     if (t < W) {
         const size_t o = (size_t)by * ps_c + (size_t)t * ps_t;
         pcost[o] = best; pidx[o] = bidx;
@@ -832,6 +848,19 @@ __global__ __launch_bounds__(64) void k_steer_force(Params P, Geo g, Res r, Tree
 
 // ------------------------------------------------------------------------------------------
 // Tree root (tree.py:50-73 via planner.py:172): state, trig, K = lqr(x0, 0)[1], pID -1, edge = [x0],[0].
+// angle errors of nodes [first, first + count) w.r.t. the sampler's fixed angles (TreeView::werr)
+template <class S>
+__global__ void k_tree_werr(TreeView tv, int first, int count, FixedAngles fx) {
+    const int i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= first + count) return;
+    if constexpr (S::NW > 0) {
+#pragma unroll
+        for (int k = 0; k < S::NW; ++k)
+            tv.werr[(size_t)k * tv.cap + i] = wrap_err(fx.t[2 * k], fx.t[2 * k + 1], tv.trig[(size_t)(2 * k) * tv.cap + i],
+                                                       tv.trig[(size_t)(2 * k + 1) * tv.cap + i]);
+    }
+}
+
 template <class S>
 __global__ void k_tree_root(Params P, TreeView tv, const double* __restrict__ x0) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -984,7 +1013,7 @@ __global__ __launch_bounds__(1024) void k_publish(const double* __restrict__ rec
 template <class S>
 __global__ __launch_bounds__(64) void k_append(TreeView tv, const double* __restrict__ rec, RecLayout L,
                                                int C, int base, const int* __restrict__ rank,
-                                               const int* __restrict__ par_done) {
+                                               const int* __restrict__ par_done, FixedAngles fx) {
     const int t = blockIdx.x;
     if (t >= C) return;
     const double* my = rec + (size_t)t * L.R;
@@ -994,6 +1023,12 @@ __global__ __launch_bounds__(64) void k_append(TreeView tv, const double* __rest
     const int lane = threadIdx.x;
     if (lane < S::N) tv.state[(size_t)lane * tv.cap + id] = my[L.off_xend + lane];
     if (lane < 2 * S::NW) tv.trig[(size_t)lane * tv.cap + id] = my[L.off_trig + lane];
+    if constexpr (S::NW > 0) {
+        if (fx.on && lane >= 32 && lane < 32 + S::NW) {          // keeps TreeView::werr complete (a lane of its own: an atan2)
+            const int k = lane - 32;
+            tv.werr[(size_t)k * tv.cap + id] = wrap_err(fx.t[2 * k], fx.t[2 * k + 1], my[L.off_trig + 2 * k], my[L.off_trig + 2 * k + 1]);
+        }
+    }
     for (int q = lane; q < S::M * S::N; q += 64) tv.K[(size_t)id * S::M * S::N + q] = my[L.off_K + q];
     if (lane == 0) {
         const int p = par_done[t];
