@@ -51,6 +51,9 @@ extern "C" {
 #define LQRRT_MODEL_PENDULUM           5  /* demos/demo_pendulum.py:54-157          */
 #define LQRRT_MODEL_DOUBLE_INTEGRATOR  6  /* BASELINE.json config 5 (not in the reference) */
 #define LQRRT_MODEL_ROS_BOAT           7  /* demos/lqrrt_ros/behaviors/{boat,car,escape}.py  */
+#define LQRRT_MODEL_PENDULUM_LQR       8  /* demos/demo_pendulum.py dynamics with the lqr of the API contract (planner.py:39-42):
+                                           * S, K from the discrete Riccati equation of the dynamics linearised about (x,u) by
+                                           * central differences, recomputed per rollout step, per new node and per sample */
 
 #define LQRRT_MAX_STATES   12
 #define LQRRT_MAX_CONTROLS 6

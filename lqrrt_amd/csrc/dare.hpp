@@ -11,7 +11,7 @@
 // One problem per wavefront; all matrices (n <= 12) live in LDS; the 64 lanes split matrix
 // elements.  ~9 doubling iterations reach 1e-14 where plain Riccati sweeps need >100.
 #pragma once
-#include "kernels.hpp"
+#include "systems.hpp"
 
 namespace lq {
 
@@ -73,22 +73,30 @@ __device__ __forceinline__ void solve_inplace(double* W, double* RHS, int n, int
     }
 }
 
+// LDS work space of one problem (one wavefront)
+template <int n, int m>
+struct DareLds {
+    double A[n * n], Bm[n * m], Ak[n * n], G[n * n], Hm[n * n], W[n * n], T1[n * n], T2[n * n], T3[n * n];
+    double Rm[m * m], X[m * n], Y[m * n], Z[m * m];
+    double red[2];
+};
+
+// lqr(x, u) of the API contract for one (x0, u0), computed by the calling wavefront (all 64 lanes must call; x0 / u0 are
+// wave-uniform per-thread arrays): A, B by central differences of S::step, S by doubling, K = (R + B'SB)^-1 B'SA.
+// P: model parameters; Qd (n x n), Rd (m x m): weights (any address space).  Results are left in the work space:
+// L.T1 = S (symmetrised), L.Y = K (m x n), L.A / L.Bm = the linearisation.  Returns the doubling iterations used.
+// Every sum runs in a fixed order inside ONE lane (mm, solve_inplace), so the result does not depend on the lane
+// count and oracle/lqrrt_oracle.c restates it sequentially bit for bit.
 template <class S>
-__global__ __launch_bounds__(64) void k_lqr_dare(Params P, const double* __restrict__ xs, const double* __restrict__ us, int B,
-                                                 const double* __restrict__ Qd, const double* __restrict__ Rd, double dt, double eps,
-                                                 int max_iter, double tol, double* __restrict__ S_out, double* __restrict__ K_out,
-                                                 double* __restrict__ A_out, double* __restrict__ B_out, int* __restrict__ iters_out) {
+__device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const double* u0, const double* Qd, const double* Rd,
+                                        double dt, double eps, int max_iter, double tol, DareLds<S::N, S::M>& L, int lane) {
     constexpr int n = S::N, m = S::M;
-    __shared__ double A[n * n], Bm[n * m], Ak[n * n], G[n * n], Hm[n * n], W[n * n], T1[n * n], T2[n * n], T3[n * n];
-    __shared__ double Rm[m * m], X[m * n], Y[m * n], Z[m * m];
-    __shared__ double red[2];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= B) return;
+    double *A = L.A, *Bm = L.Bm, *Ak = L.Ak, *G = L.G, *Hm = L.Hm, *W = L.W, *T1 = L.T1, *T2 = L.T2, *T3 = L.T3;
+    double *Rm = L.Rm, *X = L.X, *Y = L.Y, *Z = L.Z, *red = L.red;
+    __syncthreads();                                             // the previous user of the work space is done
     // ---- central differences: lane j < n perturbs state j, lanes n..n+m-1 perturb effort j-n
     if (lane < n + m) {
-        double x0[n], u0[m], xp[n], xm[n], tr[2 * S::NW + 1], uc[m];
-        for (int d = 0; d < n; ++d) x0[d] = xs[(size_t)b * n + d];
-        for (int j = 0; j < m; ++j) u0[j] = us ? us[(size_t)b * m + j] : 0.0;
+        double xp[n], xm[n], tr[2 * S::NW + 1], uc[m];
         double xa[n], ua[m];
         for (int sgn = 0; sgn < 2; ++sgn) {
             for (int d = 0; d < n; ++d) xa[d] = x0[d];
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(64) void k_lqr_dare(Params P, const double* __restr
             else { for (int j = 0; j < m; ++j) if (j == lane - n) ua[j] += h; }
             trig_of<S>(xa, tr);
             for (int j = 0; j < m; ++j) uc[j] = ua[j];
-            S::step(P.p, xa, tr, uc, dt, sgn == 0 ? xp : xm);
+            S::step(P, xa, tr, uc, dt, sgn == 0 ? xp : xm);
         }
         for (int d = 0; d < n; ++d) {
             const double v = (xp[d] - xm[d]) / (2.0 * eps);
@@ -154,10 +162,27 @@ __global__ __launch_bounds__(64) void k_lqr_dare(Params P, const double* __restr
     for (int i = lane; i < m * m; i += 64) Z[i] += Rm[i];
     mm(Y, X, A, m, n, n, false, false, lane);                                  // Y = B' S A   (m x n)
     solve_inplace(Z, Y, m, n, lane);                                           // Y = K
-    for (int i = lane; i < n * n; i += 64) S_out[(size_t)b * n * n + i] = T1[i];
-    for (int i = lane; i < m * n; i += 64) K_out[(size_t)b * m * n + i] = Y[i];
-    if (A_out) for (int i = lane; i < n * n; i += 64) A_out[(size_t)b * n * n + i] = A[i];
-    if (B_out) for (int i = lane; i < n * m; i += 64) B_out[(size_t)b * n * m + i] = Bm[i];
+    __syncthreads();
+    return it;
+}
+
+template <class S>
+__global__ __launch_bounds__(64) void k_lqr_dare(Params P, const double* __restrict__ xs, const double* __restrict__ us, int B,
+                                                 const double* __restrict__ Qd, const double* __restrict__ Rd, double dt, double eps,
+                                                 int max_iter, double tol, double* __restrict__ S_out, double* __restrict__ K_out,
+                                                 double* __restrict__ A_out, double* __restrict__ B_out, int* __restrict__ iters_out) {
+    constexpr int n = S::N, m = S::M;
+    __shared__ DareLds<n, m> L;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= B) return;
+    double x0[n], u0[m];
+    for (int d = 0; d < n; ++d) x0[d] = xs[(size_t)b * n + d];
+    for (int j = 0; j < m; ++j) u0[j] = us ? us[(size_t)b * m + j] : 0.0;
+    const int it = dare_lqr<S>(P.p, x0, u0, Qd, Rd, dt, eps, max_iter, tol, L, lane);
+    if (S_out) for (int i = lane; i < n * n; i += 64) S_out[(size_t)b * n * n + i] = L.T1[i];
+    if (K_out) for (int i = lane; i < m * n; i += 64) K_out[(size_t)b * m * n + i] = L.Y[i];
+    if (A_out) for (int i = lane; i < n * n; i += 64) A_out[(size_t)b * n * n + i] = L.A[i];
+    if (B_out) for (int i = lane; i < n * m; i += 64) B_out[(size_t)b * n * m + i] = L.Bm[i];
     if (iters_out && lane == 0) iters_out[b] = it;
 }
 

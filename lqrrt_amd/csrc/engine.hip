@@ -8,7 +8,6 @@
 // point returns LQRRT_E_NODEVICE.
 #include "../../include/lqrrt_hip.h"
 #include "kernels.hpp"
-#include "dare.hpp"
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -112,6 +111,10 @@ struct lqrrt_engine {
     unsigned char* d_ogc = nullptr;   // its 8x8 max-pooled companion
     int* d_cell_start = nullptr;  // box obstacles: uniform grid (CSR) over the boxes' bounding volume
     int* d_cell_items = nullptr;
+    bool riccati = false;         // lqr = Riccati solution of the local linearisation (model_riccati): S per sample
+    double* d_QR = nullptr;       // its weights on the device: Q (n x n) then R (m x m)
+    double* d_Sop = nullptr;      // [maxW][n*n] per-sample S of the operator calls
+    double* d_pool_S = nullptr;   // [pool][n*n] per-sample S of the queued samples
     double* d_S = nullptr;        // dense system S (n x n) or null = identity
     int smode = 1;                // form of d_S for the scans: S_DENSE, S_DIAG or S_BAND2 (kernels.hpp quad_cost)
 
@@ -205,6 +208,7 @@ struct lqrrt_engine {
         case LQRRT_MODEL_PENDULUM:          { using S = Pendulum;         __VA_ARGS__; } break;   \
         case LQRRT_MODEL_DOUBLE_INTEGRATOR: { using S = DoubleIntegratorT<6>; __VA_ARGS__; } break; \
         case LQRRT_MODEL_ROS_BOAT:          { using S = RosBoat;          __VA_ARGS__; } break;   \
+        case LQRRT_MODEL_PENDULUM_LQR:      { using S = PendulumLqr;      __VA_ARGS__; } break;   \
         default: return fail(LQRRT_E_ARG, "unknown model %d", (e)->model);                        \
     }
 
@@ -230,6 +234,7 @@ static bool model_dims(int model, int* n, int* m, int* nw) {
         case LQRRT_MODEL_ROS_BOAT:
         case LQRRT_MODEL_BOAT_NOVICE: *n = 6; *m = 3; *nw = 1; return true;
         case LQRRT_MODEL_CAR: *n = 5; *m = 2; *nw = 1; return true;
+        case LQRRT_MODEL_PENDULUM_LQR:
         case LQRRT_MODEL_PENDULUM: *n = 4; *m = 1; *nw = 2; return true;
         case LQRRT_MODEL_DOUBLE_INTEGRATOR: *n = 12; *m = 6; *nw = 0; return true;
     }
@@ -237,7 +242,10 @@ static bool model_dims(int model, int* n, int* m, int* nw) {
 }
 
 // index of the k-th angular (wrapped) state of a model: S::wd(k) on the host
-static int model_wd(int model, int k) { return model == LQRRT_MODEL_PENDULUM ? k : 2; }
+static int model_wd(int model, int k) { return (model == LQRRT_MODEL_PENDULUM || model == LQRRT_MODEL_PENDULUM_LQR) ? k : 2; }
+// systems whose lqr is a per-state Riccati solution: cooperative gain kernels, one cost-to-go matrix per sample
+static bool model_riccati(int model) { return model == LQRRT_MODEL_PENDULUM_LQR; }
+static constexpr int PLQR_Q = 18, PLQR_R = 34, PLQR_EPS = 35;      // systems.hpp PendulumLqr parameter layout
 
 static size_t geo_lds_bytes(const lqrrt_engine* e) {
     if (e->geo.og) return e->geo.og_lds ? sizeof(double) * (size_t)2 * e->geo.V : 0;
@@ -354,14 +362,17 @@ static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
 static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int W, const double* Sd,
                      bool tri, int* out_id, double* out_cost, double* rec, hipStream_t st,
                      bool profile, int* n_chunks_out = nullptr, int wave_lo = -1, bool defer_reduce = false,
-                     const double* xtrig = nullptr) {
+                     const double* xtrig = nullptr, const double* Spers = nullptr) {
+    // Spers: one dense S per sample, [W][n*n] (Riccati systems: S = lqr(sample, 0)[0], planner.py:344-345); else Sd (one
+    // matrix for all samples) or the system's constant S
     if (W <= 0) return 0;
     int chunk, n_chunks;
     if (tri) { chunk = tri_chunk(); n_chunks = (nv.count + chunk - 1) / chunk; }   // in-wave pass: the reduction is fused into k_decide
     else pick_chunks(nv.count, W, &chunk, &n_chunks);
     if (n_chunks_out) *n_chunks_out = n_chunks;
     dim3 grid((W + 63) / 64, n_chunks);
-    const double* S_use = Sd ? Sd : e->d_S;
+    const double* S_use = Spers ? Spers : (Sd ? Sd : e->d_S);
+    const long long s_stride = Spers ? (long long)e->n * e->n : 0;
     const int ps_c = tri ? W : 1, ps_t = tri ? 1 : n_chunks;     // chunk-major for k_decide, sample-major for k_nn_reduce
     EvPair ev;
     ev.a = ev.b = nullptr;
@@ -374,7 +385,10 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
 #define NN_ONE(SYS, DENSE, TRI)                                                                            \
     hipExtLaunchKernelGGL((k_nn_scan<SYS, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
                           e->d_pcost, e->d_pidx, ps_c, ps_t)
-    if (sm == S_BAND2 && e->model == LQRRT_MODEL_DOUBLE_INTEGRATOR) {
+    if (Spers) {
+        if (e->model != LQRRT_MODEL_PENDULUM_LQR) return fail(LQRRT_E_ARG, "per-sample S is only instantiated for Riccati systems");
+        if (tri) NN_ONE(PendulumLqr, S_PERSAMPLE, true); else NN_ONE(PendulumLqr, S_PERSAMPLE, false);
+    } else if (sm == S_BAND2 && e->model == LQRRT_MODEL_DOUBLE_INTEGRATOR) {
         if (tri) NN_ONE(DoubleIntegratorT<6>, S_BAND2, true); else NN_ONE(DoubleIntegratorT<6>, S_BAND2, false);
     } else if (sm == S_DIAG && e->model == LQRRT_MODEL_ROS_BOAT) {
         if (tri) NN_ONE(RosBoat, S_DIAG, true); else NN_ONE(RosBoat, S_DIAG, false);
@@ -389,7 +403,7 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     if (tri || defer_reduce) { HIPCHK(hipGetLastError()); return 0; }     // deferred: the steer launch reduces (SteerFuse)
 #define RED_LAUNCH(DENSE)                                                                                 \
     DISPATCH(e, hipLaunchKernelGGL((k_nn_reduce<S, DENSE>), dim3(W), dim3(64), 0, st, e->d_pcost, e->d_pidx, W, n_chunks, nv, \
-                                   xs, S_use, out_id, out_cost, rec, e->L.R, e->L.off_cost, e->L.off_parent,               \
+                                   xs, S_use, s_stride, out_id, out_cost, rec, e->L.R, e->L.off_cost, e->L.off_parent,     \
                                    wave_lo >= 0 ? e->d_par_done + wave_lo : nullptr,                                      \
                                    wave_lo >= 0 ? e->d_changed + wave_lo : nullptr,                                       \
                                    wave_lo >= 0 ? e->d_stale + wave_lo : nullptr))
@@ -406,10 +420,10 @@ static int launch_steer(lqrrt_engine* e, const double* xs, const int* list, int 
     SteerFuse f;
     memset(&f, 0, sizeof f);
     if (fuse) f = *fuse;
-    f.Sd = e->d_S;
+    if (!f.Sd) { f.Sd = e->d_S; f.s_stride = 0; }
     EvPair ev;
     prof_begin(e, st, &ev, 1);
-    if (e->d_S) {
+    if (f.Sd) {
         DISPATCH(e, hipExtLaunchKernelGGL((k_steer<S, true>), dim3(count), dim3(64), lds, st, ev.a, ev.b, 0, e->P, e->geo, e->res, e->tv,
                                            e->d_rec, e->L, xs, list, lo, par, list_count, f));
     } else {
@@ -445,7 +459,7 @@ static void free_all(lqrrt_engine* e) {
     void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_og, e->d_ogc, e->d_cell_start, e->d_cell_items, e->d_S, e->tv.state, e->tv.trig, e->tv.werr, e->tv.K, e->tv.pID, e->tv.elen,
                     e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_M,
                     e->d_pidx, e->d_par_done, e->d_par_want, e->d_list,
-                    e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_pool_trig, e->d_cand, e->d_flags};
+                    e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_pool_trig, e->d_pool_S, e->d_QR, e->d_Sop, e->d_cand, e->d_flags};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_ign_pin) (void)hipHostFree(e->h_ign_pin);
@@ -589,6 +603,26 @@ static int upload_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys) {
     return rc;
 }
 
+// Riccati systems: weights Q, R of the parameter block on the device (k_lqr_dare reads them from HBM)
+static int upload_weights(lqrrt_engine* e) {
+    if (!e->riccati) return 0;
+    if (!e->d_QR) TRY(dalloc(&e->d_QR, (size_t)e->n * e->n + (size_t)e->m * e->m));
+    HIPCHK(hipMemcpy(e->d_QR, e->P.p + PLQR_Q, sizeof(double) * e->n * e->n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_QR + e->n * e->n, e->P.p + PLQR_R, sizeof(double) * e->m * e->m, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// S = lqr(x, 0)[0] for B states (Riccati systems): the cost-to-go matrix about each sample, planner.py:344-345
+static int launch_sample_S(lqrrt_engine* e, const double* xs, int B, double* S_out, hipStream_t st) {
+    if (B <= 0) return 0;
+    if (!e->has_res) return fail(LQRRT_E_STATE, "set_resolution first (dt)");
+    DISPATCH(e, hipLaunchKernelGGL((k_lqr_dare<S>), dim3(B), dim3(64), 0, st, e->P, xs, (const double*)nullptr, B, e->d_QR,
+                                   e->d_QR + e->n * e->n, e->res.dt, e->P.p[PLQR_EPS], 64, 1e-14, S_out, (double*)nullptr,
+                                   (double*)nullptr, (double*)nullptr, (int*)nullptr));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 static void free_geometry(lqrrt_engine* e) {
     void** ptrs[] = {(void**)&e->d_vps, (void**)&e->d_obs, (void**)&e->d_oc, (void**)&e->d_og, (void**)&e->d_ogc, (void**)&e->d_cell_start, (void**)&e->d_cell_items};
     for (void** p : ptrs) {
@@ -626,7 +660,10 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
         delete e;
         return fail(LQRRT_E_ARG, "vps/obs pointer missing");
     }
+    e->riccati = model_riccati(sys->model);
     rc = upload_geometry(e, sys);
+    if (!rc) rc = upload_weights(e);
+    if (!rc && e->riccati) rc = dalloc(&e->d_Sop, (size_t)e->maxW * n * n);
     e->tv.cap = e->cap;
     if (!rc) rc = dalloc(&e->tv.state, (size_t)n * e->cap);
     if (!rc) rc = dalloc(&e->tv.trig, (size_t)(2 * nw + 1) * e->cap);
@@ -717,6 +754,7 @@ extern "C" int lqrrt_engine_set_resolution(lqrrt_engine* e, const lqrrt_resoluti
         e->goal[d] = r->goal[d];
     }
     const bool goal_changed = true;
+    e->d_pool_count = 0;                                      // per-sample trig / S tables are rebuilt with the next upload
     e->has_goal = r->has_goal != 0;
     e->has_res = true;
     if (r->horizon_iters != e->H) {
@@ -786,6 +824,8 @@ extern "C" int lqrrt_engine_set_geometry(lqrrt_engine* e, const lqrrt_system_des
     memset(&e->P, 0, sizeof e->P);
     memcpy(e->P.p, sys->params, sizeof(double) * sys->n_params);
     TRY(upload_geometry(e, sys));
+    TRY(upload_weights(e));
+    e->d_pool_count = 0;                                      // (per-sample S of the device pool depends on the parameters)
     if (!e->explicit_samples) invalidate_samples(e);          // queued samples were filtered against the old world
     return 0;
 }
@@ -830,7 +870,8 @@ extern "C" int lqrrt_tree_reset(lqrrt_engine* e, const double* x0_host, void* st
     double* d_x0 = e->d_pcost;    // scratch: the scan partials are idle while the tree is being reset
     HIPCHK(hipMemcpyAsync(d_x0, x0_host, sizeof(double) * e->n, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(e->tv.ignore, 0, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1), st));
-    DISPATCH(e, hipLaunchKernelGGL((k_tree_root<S>), dim3(1), dim3(64), 0, st, e->P, e->tv, d_x0));
+    if (e->riccati && !e->has_res) return fail(LQRRT_E_STATE, "set_resolution first (the seed's Riccati gain needs dt)");
+    DISPATCH(e, hipLaunchKernelGGL((k_tree_root<S>), dim3(1), dim3(64), 0, st, e->P, e->tv, d_x0, e->res.dt));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     e->N = 1;
@@ -1085,7 +1126,9 @@ extern "C" int lqrrt_gain_batch(lqrrt_engine* e, const double* x, const double* 
     if (!e || !x || !K || B < 0) return fail(LQRRT_E_ARG, "bad argument");
     if (!B) return 0;
     TRY(use_device(e));
-    DISPATCH(e, hipLaunchKernelGGL((k_gain_batch<S>), dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, e->P, x, u, B, K));
+    if (e->riccati && !e->has_res) return fail(LQRRT_E_STATE, "set_resolution first (dt)");
+    DISPATCH(e, hipLaunchKernelGGL((k_gain_batch<S>), dim3(e->riccati ? B : (B + 63) / 64), dim3(64), 0, (hipStream_t)stream, e->P, x, u, B,
+                                   e->res.dt, K));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1123,7 +1166,12 @@ extern "C" int lqrrt_nn_argmin(lqrrt_engine* e, const double* xs, int W, const d
     hipStream_t st = (hipStream_t)stream;
     TRY(flush_ignore(e, st, true));
     TRY(ensure_werr(e, st));
-    return launch_nn(e, tree_view(e, use_ignore != 0), xs, W, S_dev, false, id, cost, nullptr, st, true);
+    const double* Spers = nullptr;
+    if (e->riccati && !S_dev) {                                // the system's own S: one Riccati solution per sample
+        TRY(launch_sample_S(e, xs, W, e->d_Sop, st));
+        Spers = e->d_Sop;
+    }
+    return launch_nn(e, tree_view(e, use_ignore != 0), xs, W, S_dev, false, id, cost, nullptr, st, true, nullptr, -1, false, nullptr, Spers);
 }
 
 extern "C" int lqrrt_costs_to_go(lqrrt_engine* e, const double* x, const double* S_dev, double* cost, void* stream) {
@@ -1132,6 +1180,10 @@ extern "C" int lqrrt_costs_to_go(lqrrt_engine* e, const double* x, const double*
     TRY(use_device(e));
     NodeView nv = tree_view(e, false);
     const double* S_use = S_dev ? S_dev : e->d_S;
+    if (e->riccati && !S_dev) {
+        TRY(launch_sample_S(e, x, 1, e->d_Sop, (hipStream_t)stream));
+        S_use = e->d_Sop;
+    }
     dim3 grid((e->N + 255) / 256);
     if (S_use) {
         DISPATCH(e, hipLaunchKernelGGL((k_costs<S, true>), grid, dim3(256), 0, (hipStream_t)stream, nv, x, S_use, cost));
@@ -1195,12 +1247,17 @@ static int upload_pool(lqrrt_engine* e, int64_t off, int64_t cnt, hipStream_t st
         e->d_pool_cap = cnt + cnt / 2;
         TRY(dalloc(&e->d_pool, (size_t)e->d_pool_cap * n));
         TRY(dalloc(&e->d_pool_trig, (size_t)e->d_pool_cap * 2 * std::max(e->nw, 1)));
+        if (e->riccati) {
+            if (e->d_pool_S) (void)hipFree(e->d_pool_S);
+            TRY(dalloc(&e->d_pool_S, (size_t)e->d_pool_cap * n * n));
+        }
     }
     HIPCHK(hipMemcpyAsync(e->d_pool, e->pool.data() + off * n, sizeof(double) * cnt * n, hipMemcpyHostToDevice, st));
     if (e->nw > 0 && cnt > 0) {
         DISPATCH(e, hipLaunchKernelGGL((k_sample_trig<S>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, e->d_pool, (int)cnt, e->d_pool_trig));
         HIPCHK(hipGetLastError());
     }
+    if (e->riccati) TRY(launch_sample_S(e, e->d_pool, (int)cnt, e->d_pool_S, st));
     HIPCHK(hipStreamSynchronize(st));
     return 0;
 }
@@ -1302,6 +1359,9 @@ extern "C" int lqrrt_engine_queued_samples(lqrrt_engine* e) {
 static const double* wave_samples(const lqrrt_engine* e) {
     return e->d_pool + (size_t)(e->cursor - e->d_pool_base) * e->n;
 }
+static const double* wave_sample_S(const lqrrt_engine* e) {
+    return e->riccati ? e->d_pool_S + (size_t)(e->cursor - e->d_pool_base) * e->n * e->n : nullptr;
+}
 static const double* wave_sample_trig(const lqrrt_engine* e) {
     return e->nw > 0 ? e->d_pool_trig + (size_t)(e->cursor - e->d_pool_base) * 2 * e->nw : nullptr;
 }
@@ -1339,7 +1399,7 @@ extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void
     const bool whole = (lo == 0 && hi == W);
     static const int matrix_max = getenv("LQRRT_MATRIX_MAX_W") ? std::min(atoi(getenv("LQRRT_MATRIX_MAX_W")), (int)lqrrt_engine::MATRIX_MAX_W)
                                                                 : (int)lqrrt_engine::MATRIX_MAX_W;
-    e->wave_matrix = W <= matrix_max && !e->sync_mode;
+    e->wave_matrix = W <= matrix_max && !e->sync_mode && !e->riccati;
     if (cnt > 0) {
         // snapshot NN for the slice: records lo..hi-1 get (cost, parent); the reduce also initialises the
         // slice's wave bookkeeping (parent-in-use, changed, stale)
@@ -1350,13 +1410,15 @@ extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void
         int n_chunks = 0;
         const double* xtr = wave_sample_trig(e);
         TRY(launch_nn(e, nv, xs + (size_t)lo * e->n, cnt, nullptr, false, nullptr, nullptr,
-                      e->d_rec + (size_t)lo * e->L.R, st, true, &n_chunks, lo, true, xtr ? xtr + (size_t)lo * 2 * e->nw : nullptr));
+                      e->d_rec + (size_t)lo * e->L.R, st, true, &n_chunks, lo, true, xtr ? xtr + (size_t)lo * 2 * e->nw : nullptr,
+                      e->riccati ? wave_sample_S(e) + (size_t)lo * e->n * e->n : nullptr));
         SteerFuse f;
         memset(&f, 0, sizeof f);
         f.pcost = e->d_pcost; f.pidx = e->d_pidx; f.n_chunks = n_chunks; f.nv = nv;
         f.changed = e->d_changed; f.stale = e->d_stale; f.par_out = e->d_par_done;
         f.M = (e->wave_matrix && whole) ? e->d_M : nullptr; f.W = W;
         f.xtrig = xtr;
+        if (e->riccati) { f.Sd = wave_sample_S(e); f.s_stride = (long long)e->n * e->n; }
         TRY(launch_steer(e, xs, nullptr, lo, cnt, e->d_par_done, st, nullptr, &f));
     }
     HIPCHK(hipGetLastError());
@@ -1475,7 +1537,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
         } else {
             int n_chunks = 1;
             TRY(launch_nn(e, record_view(e, W), xs, W, nullptr, true, nullptr, nullptr, nullptr, st, false, &n_chunks, -1, false,
-                          wave_sample_trig(e)));
+                          wave_sample_trig(e), wave_sample_S(e)));
             hipLaunchKernelGGL(k_decide, dim3(1), dim3(dthreads), 0, st, e->d_rec, e->L, W, e->d_pcost, e->d_pidx, n_chunks, tri_chunk(),
                                e->d_par_done, e->d_par_want, e->d_changed, e->d_stale, e->d_need, e->d_list, e->h_summary_dev,
                                e->h_summary_dev + 4, e->d_summary, ++e->seq);

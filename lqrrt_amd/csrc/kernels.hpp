@@ -22,6 +22,7 @@
 #pragma once
 #include <type_traits>
 #include "systems.hpp"
+#include "dare.hpp"
 
 namespace lq {
 
@@ -83,6 +84,26 @@ __host__ __device__ inline RecLayout make_layout(int n, int m, int nw, int H) {
     return L;
 }
 
+// Systems whose lqr is the Riccati solution of the local linearisation (systems.hpp PendulumLqr) declare DARE_GAIN.
+template <class S, class = void> struct has_dare_gain : std::false_type {};
+template <class S> struct has_dare_gain<S, std::enable_if_t<S::DARE_GAIN>> : std::true_type {};
+template <class S> struct NoLds {};
+template <class S> using GainLds = std::conditional_t<has_dare_gain<S>::value, DareLds<S::N, S::M>, NoLds<S>>;
+
+// K = lqr(x, u)[1].  Analytic gains are evaluated redundantly by every lane; a Riccati gain is computed by the whole
+// wavefront in LDS (all 64 lanes must call with the same x, u) and then read back by every lane.
+template <class S>
+__device__ __forceinline__ void system_gain(const double* P, const double* x, const double* trig, const double* u, double dt,
+                                            GainLds<S>& L, int lane, double* K) {
+    if constexpr (has_dare_gain<S>::value) {
+        dare_lqr<S>(P, x, u, P + S::P_Q, P + S::P_R, dt, P[S::P_EPS], 64, 1e-14, L, lane);
+#pragma unroll
+        for (int j = 0; j < S::M * S::N; ++j) K[j] = L.Y[j];
+    } else {
+        S::gain(P, x, trig, u, K);
+    }
+}
+
 // Stores a wave-uniform register array: lane j writes element j (and j+64, ... for longer arrays).
 // The select chain has compile-time bounds, so the array stays in registers (no dynamic indexing,
 // no scratch).
@@ -94,14 +115,6 @@ __device__ __forceinline__ void store_uniform(double* dst, const double* a, int 
     for (int j = BASE + 1; j < END; ++j) v = (lane == j - BASE) ? a[j] : v;
     if (BASE + lane < CNT) dst[BASE + lane] = v;
     if constexpr (END < CNT) store_uniform<CNT, END>(dst, a, lane);
-}
-
-template <class S>
-__device__ __forceinline__ void trig_of(const double* x, double* trig) {
-#pragma unroll
-    for (int k = 0; k < S::NW; ++k) {
-        lq_sincos(x[S::wd(k)], &trig[2 * k + 1], &trig[2 * k]);
-    }
 }
 
 // erf(xgoal, x) with cached trig of both arguments.
@@ -122,7 +135,7 @@ __device__ __forceinline__ void erf_cached(const double* xg, const double* gtrig
 // dense loop with its zero terms left out -- the same partial sums in the same order, so the same bits except for
 // the sign of an exact zero, which no comparison can see (costs are only ever compared).  The host classifies S
 // (lqrrt_engine_set_dense_S); only the tree / in-wave scans are specialised, everything else stays dense.
-constexpr int S_IDENT = 0, S_DENSE = 1, S_DIAG = 2, S_BAND2 = 3;
+constexpr int S_IDENT = 0, S_DENSE = 1, S_DIAG = 2, S_BAND2 = 3, S_PERSAMPLE = 4;   // 4: one dense S per sample, [W][N*N]
 template <class S, int DENSE>
 __device__ __forceinline__ double quad_cost(const double* e, const double* Sd) {
     double prod[S::N];
@@ -223,6 +236,16 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
         mode = __all(fixed) ? 2 : (__all(same) ? 1 : 0);
     }
 
+    // cost-to-go matrix about the SAMPLE (planner.py:344-345): a constant of the system, or one matrix per sample
+    double Sl[DENSE == S_PERSAMPLE ? S::N * S::N : 1];
+    const double* Suse = Sd;
+    if constexpr (DENSE == S_PERSAMPLE) {
+#pragma unroll
+        for (int q = 0; q < S::N * S::N; ++q) Sl[q] = Sd[(size_t)ts * (S::N * S::N) + q];
+        Suse = Sl;
+    }
+    constexpr int QC = DENSE == S_PERSAMPLE ? S_DENSE : DENSE;
+
     double best = INFINITY;
     int bidx = -1;
     // (one copy of the loop per mode, chosen once per wavefront: the cheap modes must not carry the atan2 in their body)
@@ -297,7 +320,7 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
                                                    __builtin_amdgcn_readlane(__double2loint(werr[k]), jj));
                 else e[S::wd(k)] = wrap_err(gtrig[2 * k], gtrig[2 * k + 1], nd[S::N + 2 * k], nd[S::N + 2 * k + 1]);
             }
-            const double c = quad_cost<S, DENSE>(e, Sd);
+            const double c = quad_cost<S, QC>(e, Suse);
             const int i = base + jj;
             const bool ok = (TRI ? (i < t) : true) && c < best;   // strict: the older node keeps an exactly equal cost
             bidx = ok ? i : bidx;
@@ -367,7 +390,7 @@ __device__ __forceinline__ void lexmin_wave(double& c, int& i) {
 template <class S, int DENSE>
 __global__ __launch_bounds__(64) void k_nn_reduce(const double* __restrict__ pcost, const int* __restrict__ pidx,
                                                   int W, int n_chunks, NodeView nv, const double* __restrict__ xs,
-                                                  const double* __restrict__ Sd,
+                                                  const double* __restrict__ Sd, long long s_stride,
                                                   int* __restrict__ out_id, double* __restrict__ out_cost,
                                                   double* __restrict__ rec, int R, int off_cost, int off_parent,
                                                   int* __restrict__ par_done, unsigned char* __restrict__ changed,
@@ -401,7 +424,7 @@ __global__ __launch_bounds__(64) void k_nn_reduce(const double* __restrict__ pco
 #pragma unroll
             for (int j = 0; j < 2 * S::NW; ++j) trig[j] = nv.trig[(long long)i * nv.tn + j * nv.td];
             erf_cached<S>(xg, gtrig, x, trig, e);
-            const double c = quad_cost<S, DENSE>(e, Sd);
+            const double c = quad_cost<S, DENSE>(e, Sd + (size_t)t * s_stride);
             if (bi < 0 || c < b) { b = c; bi = i; }
         }
         lexmin_wave(b, bi);
@@ -473,10 +496,13 @@ __global__ void k_dynamics_batch(Params P, const double* __restrict__ x, const d
     for (int d = 0; d < S::N; ++d) xn[(size_t)b * S::N + d] = o[d];
 }
 
+// thread per item for analytic gains (grid = ceil(B / blockDim)); one wavefront per item for Riccati gains (grid = B, block = 64)
 template <class S>
 __global__ void k_gain_batch(Params P, const double* __restrict__ x, const double* __restrict__ u,
-                             int B, double* __restrict__ K) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+                             int B, double dt, double* __restrict__ K) {
+    __shared__ GainLds<S> gl_lds;
+    const bool coop = has_dare_gain<S>::value;
+    const int b = coop ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (b >= B) return;
     double xs[S::N], us[S::M], trig[2 * S::NW + 1], k[S::M * S::N];
 #pragma unroll
@@ -484,7 +510,8 @@ __global__ void k_gain_batch(Params P, const double* __restrict__ x, const doubl
 #pragma unroll
     for (int j = 0; j < S::M; ++j) us[j] = u ? u[(size_t)b * S::M + j] : 0.0;
     trig_of<S>(xs, trig);
-    S::gain(P.p, xs, trig, us, k);
+    system_gain<S>(P.p, xs, trig, us, dt, gl_lds, threadIdx.x, k);
+    if (coop && threadIdx.x != 0) return;
 #pragma unroll
     for (int j = 0; j < S::M * S::N; ++j) K[(size_t)b * S::M * S::N + j] = k[j];
 }
@@ -526,7 +553,7 @@ __device__ __forceinline__ bool uniform_true(bool b) { return __builtin_amdgcn_r
 //    column minima and the per-round in-wave scan launch disappears.
 struct SteerFuse {
     const double* pcost; const int* pidx; int n_chunks;    // n_chunks > 0: reduce prologue, partials of local sample blockIdx.x
-    NodeView nv; const double* Sd;
+    NodeView nv; const double* Sd; long long s_stride;      // S of sample t at Sd + t * s_stride (0: one S for all)
     unsigned char* changed; unsigned char* stale; int* par_out;   // wave bookkeeping initialised by the prologue
     double* M; int W;                                        // M != null: row epilogue, leading dimension W
     const double* xtrig;                                     // cos/sin of the samples' angular coordinates [..][2*NW], or null
@@ -561,6 +588,7 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
     __shared__ double Pl[MAXP];
     __shared__ double tol_l[MAXN], glo_l[MAXN], ghi_l[MAXN];
     __shared__ double node_l[MAXN + 4 + MAXM * MAXN];        // the new node on its way out: xend | trig | K
+    __shared__ GainLds<S> gl_lds;                            // work space of a Riccati gain (empty for analytic gains)
     const int t = list ? list[blockIdx.x + (list_count ? lo : 0)] : lo + (int)blockIdx.x;
     double* my = rec + (size_t)t * L.R;
 
@@ -595,7 +623,7 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
 #pragma unroll
                 for (int j = 0; j < 2 * S::NW; ++j) ti[j] = f.nv.trig[(long long)i * f.nv.tn + j * f.nv.td];
                 erf_cached<S>(xt, ttrig, xi, ti, e);
-                const double c = quad_cost<S, DENSE>(e, f.Sd);
+                const double c = quad_cost<S, DENSE>(e, f.Sd + (size_t)t * f.s_stride);
                 if (bi < 0 || c < b) { b = c; bi = i; }
             }
             lexmin_wave(b, bi);
@@ -696,7 +724,7 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         for (int d = 0; d < S::N; ++d) x[d] = xn[d];
 #pragma unroll
         for (int j = 0; j < 2 * S::NW; ++j) trig[j] = trn[j];
-        S::gain(Pl, x, trig, u, K);                             // planner.py:436
+        system_gain<S>(Pl, x, trig, u, r.dt, gl_lds, lane, K);  // planner.py:436
         STEP_TS(ts3);
         STEP_ACC(2, ts2, ts3); STEP_ACC(3, ts0, ts0 + 1);
     }
@@ -715,7 +743,7 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
 #pragma unroll
             for (int j = 0; j < S::M; ++j) ul[j] = hu[(cnt - 1) * S::M + j];
             trig_of<S>(x, trig);
-            S::gain(Pl, x, trig, ul, K);                        // planner.py:257: lqr(xnew, u_last)
+            system_gain<S>(Pl, x, trig, ul, r.dt, gl_lds, lane, K);   // planner.py:257: lqr(xnew, u_last)
         }
         bool in = true;                                          // planner.py:442-447 (strict)
 #pragma unroll
@@ -805,6 +833,7 @@ __global__ __launch_bounds__(64) void k_steer_force(Params P, Geo g, Res r, Tree
                                                     const double* __restrict__ xtar, int max_steps, double rtol, double atol,
                                                     int* __restrict__ out_len, double* __restrict__ xseq, double* __restrict__ useq) {
     extern __shared__ double geo_lds[];
+    __shared__ GainLds<S> gl_lds;
     const int lane = threadIdx.x;
     const GeoL gl = stage_geo(g, geo_lds, lane, 64);
     __syncthreads();
@@ -862,14 +891,18 @@ __global__ void k_tree_werr(TreeView tv, int first, int count, FixedAngles fx) {
 }
 
 template <class S>
-__global__ void k_tree_root(Params P, TreeView tv, const double* __restrict__ x0) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+__global__ __launch_bounds__(64) void k_tree_root(Params P, TreeView tv, const double* __restrict__ x0, double dt) {
+    __shared__ GainLds<S> gl_lds;
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;                               // one wavefront; everything is wave-uniform, lane 0 writes
     double x[S::N], trig[2 * S::NW + 1], K[S::M * S::N], u0[S::M];
-    for (int d = 0; d < S::N; ++d) { x[d] = x0[d]; tv.state[(size_t)d * tv.cap] = x[d]; }
+    for (int d = 0; d < S::N; ++d) x[d] = x0[d];
     for (int j = 0; j < S::M; ++j) u0[j] = 0.0;
     trig_of<S>(x, trig);
+    system_gain<S>(P.p, x, trig, u0, dt, gl_lds, lane, K);
+    if (lane != 0) return;
+    for (int d = 0; d < S::N; ++d) tv.state[(size_t)d * tv.cap] = x[d];
     for (int j = 0; j < 2 * S::NW; ++j) tv.trig[(size_t)j * tv.cap] = trig[j];
-    S::gain(P.p, x, trig, u0, K);
     for (int j = 0; j < S::M * S::N; ++j) tv.K[j] = K[j];
     tv.pID[0] = -1;
     tv.elen[0] = 1;

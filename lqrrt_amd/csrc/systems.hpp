@@ -625,6 +625,17 @@ struct Pendulum {
     }
 };
 
+// The double pendulum with the lqr of the reference's API contract (planner.py:39-42, tree.py:44-47): S and K from the
+// discrete Riccati equation of the dynamics linearised about (x, u) by central differences -- what demo_pendulum.py
+// imports scipy.linalg.solve_discrete_are for (:19) and never calls.  Dynamics, erf and feasibility are Pendulum's.
+// The weights and the difference step come with the parameters: 18 Q[4][4] | 34 R | 35 eps.  There is no per-lane
+// gain(): the wavefront computes it cooperatively (dare.hpp dare_lqr, kernels.hpp system_gain), once per recorded
+// rollout step (planner.py:436), per new node (:257) and per sample for the cost-to-go matrix (:344-345).
+struct PendulumLqr : Pendulum {
+    static constexpr bool DARE_GAIN = true;
+    static constexpr int P_Q = 18, P_R = 34, P_EPS = 35;
+};
+
 // ---------------------------------------------------------------------------------------------
 // Synthetic double integrator (BASELINE.json config 5): q,qdot in R^D, u in R^D, boxes on q[0:3].
 
@@ -672,5 +683,14 @@ struct DoubleIntegratorT {
         return __any(hit) == 0;
     }
 };
+
+// cos/sin of every angular state of x: trig[2k], trig[2k+1] = cos, sin of x[wd(k)]
+template <class S>
+__device__ __forceinline__ void trig_of(const double* x, double* trig) {
+#pragma unroll
+    for (int k = 0; k < S::NW; ++k) {
+        lq_sincos(x[S::wd(k)], &trig[2 * k + 1], &trig[2 * k]);
+    }
+}
 
 }  // namespace lq

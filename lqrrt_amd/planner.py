@@ -208,7 +208,7 @@ class Planner:
                 break
             if time_elapsed >= max_time or self.tree.size > self.max_nodes:
                 # no goal hit (or not enough time spent): plan to the node nearest the guide state (planner.py:311-323)
-                Sguide = np.array(self.system.Smatrix(), dtype=np.float64)
+                Sguide = np.array(self.lqr(self.xguide, np.zeros(self.ncontrols))[0], dtype=np.float64)
                 Sguide[:, np.isinf(np.asarray(self.constraints.goal_buffer, dtype=np.float64))] = 0
                 ids, _ = eng.nn_argmin(self.xguide.reshape(1, -1), S=Sguide, use_ignore=False)
                 self._adopt_plan(int(ids[0]))

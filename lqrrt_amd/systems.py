@@ -22,6 +22,7 @@ problem, a *system object* that
   BoatNovice        demos/demo_boat_novice.py:21-175
   Car               demos/demo_car.py:26-193
   DoublePendulum    demos/demo_pendulum.py:23-165
+  PendulumLqr       demos/demo_pendulum.py dynamics + the lqr of the API contract (planner.py:39-42): Riccati gains
   DoubleIntegrator  BASELINE.json config 5 (not in the reference)
 """
 import ctypes as C
@@ -505,6 +506,38 @@ class DoublePendulum(NativeSystem):
                                self.d, self.b, self.c, [self.umax, self.umax_plan], self.K.ravel()))
 
 
+class PendulumLqr(DoublePendulum):
+    """
+    The double pendulum with the lqr of the reference's API contract (planner.py:39-42, tree.py:44-47): for every
+    (x, u) the dynamics are linearised by central differences (step `eps`), S solves the discrete algebraic Riccati
+    equation for the weights Q, R and K = (R + B'SB)^-1 B'SA -- what demo_pendulum.py imports
+    scipy.linalg.solve_discrete_are for (:19) and never calls.  On the device this is the north-star steer pipeline:
+    one problem per wavefront, finite-difference linearise -> doubling DARE -> K-gain forward rollout, K refreshed at
+    every recorded step (planner.py:436); the nearest-neighbour cost uses S about the SAMPLE (:344-345), one matrix per
+    sample.  params: as DoublePendulum, then 18 Q[4][4] | 34 R | 35 eps.
+    """
+    model = nat.MODEL_PENDULUM_LQR
+    riccati = True
+
+    def __init__(self, obstacle_seed=0, Q=(10.0, 10.0, 1.0, 1.0), R=0.1, eps=1e-6):
+        DoublePendulum.__init__(self, obstacle_seed)
+        self.Q = np.diag(np.asarray(Q, dtype=np.float64)) if np.ndim(Q) == 1 else np.array(Q, dtype=np.float64)
+        self.R = np.array([[float(R)]])
+        self.eps = float(eps)
+
+    def params(self):
+        return np.concatenate((DoublePendulum.params(self), self.Q.ravel(), self.R.ravel(), [self.eps]))
+
+    def Smatrix(self):
+        return None                                   # no constant S: it is a function of the state (lqr handle)
+
+    def _eval_lqr(self, x, u):
+        eng = self._engine(self.plan_kwargs["dt"] if self._ops_dt is None else None)
+        S, K, _, _, _ = eng.lqr_dare_batch(np.atleast_2d(x), np.atleast_2d(np.asarray(u, dtype=np.float64).reshape(1, -1)),
+                                           self.Q, self.R, self.eps)
+        return (S[0], K[0])
+
+
 # --------------------------------------------------------------------------- synthetic config 5
 
 class DoubleIntegrator(NativeSystem):
@@ -556,5 +589,6 @@ SYSTEMS = {
     "car": Car,
     "pendulum": DoublePendulum,
     "double_integrator": DoubleIntegrator,
+    "pendulum_lqr": PendulumLqr,
     "ros_boat": RosBoat,
 }

@@ -67,7 +67,7 @@ class COracle(object):
             lib().orc_set_ogrid(self.h, _p(grid), grid.shape[0], grid.shape[1], float(og["origin"][0]),
                                 float(og["origin"][1]), float(og["cpm"]), float(og["threshold"]))
         self.H = 1
-        self.S = None if system.S is None else _f(system.S)
+        self.S = None if getattr(system, "S", None) is None else _f(system.S)
 
     def __del__(self):
         try:
@@ -226,6 +226,13 @@ class COracle(object):
         out = np.empty((self.m, self.n))
         lib().orc_gain(self.h, _p(x), _p(u), _p(out))
         return out
+
+    def lqr(self, x, u):
+        """(S, K, iterations) of the Riccati lqr (pendulum_lqr only)."""
+        x, u = _f(x), _f(np.atleast_1d(u))
+        S, K = np.empty((self.n, self.n)), np.empty((self.m, self.n))
+        it = lib().orc_lqr(self.h, _p(x), _p(u), _p(S), _p(K))
+        return S, K, it
 
     def erf(self, xg, x):
         xg, x = _f(xg), _f(x)

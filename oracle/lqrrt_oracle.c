@@ -28,7 +28,7 @@
 #define MAXN 12
 #define MAXM 6
 
-enum { BOAT_ADV = 1, BOAT_INT = 2, BOAT_NOV = 3, CAR = 4, PEND = 5, DINT = 6, ROS_BOAT = 7 };
+enum { BOAT_ADV = 1, BOAT_INT = 2, BOAT_NOV = 3, CAR = 4, PEND = 5, DINT = 6, ROS_BOAT = 7, PEND_LQR = 8 };
 
 typedef struct {
     int model, n, m, nw, wd[2];
@@ -137,8 +137,110 @@ static int grid_hits(const orc* o, double px, double py, double c, double s) {
 }
 
 /* ------------------------------------------------------------------ plugins */
+static void step(const orc* o, const double* x, const double* tr, double* u, double dt, double* xn);
+
+/*
+ * lqr(x, u) of the reference's API contract (planner.py:39-42) for the PEND_LQR problem: A, B by central differences of
+ * the dynamics about (x, u), S from the discrete algebraic Riccati equation by structure-preserving doubling
+ * (Chu, Fan, Lin, Wang 2004), K = (R + B'SB)^-1 B'SA.  The published algorithm, written sequentially; every sum and
+ * every elimination runs in the order the wavefront version (lqrrt_amd/csrc/dare.hpp) uses inside one lane, so the two
+ * agree bit for bit.  The pin to the reference is SciPy: tests compare against scipy.linalg.solve_discrete_are.
+ */
+static void dmm(double* C, const double* A, const double* B, int r, int k, int c, int ta, int tb) {
+    for (int idx = 0; idx < r * c; ++idx) {
+        const int i = idx / c, j = idx % c;
+        double acc = 0.0;
+        for (int p = 0; p < k; ++p) acc += (ta ? A[p * r + i] : A[i * k + p]) * (tb ? B[j * k + p] : B[p * c + j]);
+        C[idx] = acc;
+    }
+}
+static void dsolve(double* W, double* RHS, int n, int q) {     /* W X = RHS by Gauss-Jordan with partial pivoting */
+    for (int p = 0; p < n; ++p) {
+        double best = -1.0;
+        int brow = p;
+        for (int r = p; r < n; ++r) { const double v = fabs(W[r * n + p]); if (v > best) { best = v; brow = r; } }
+        if (brow != p) {
+            for (int j = 0; j < n; ++j) { const double t = W[p * n + j]; W[p * n + j] = W[brow * n + j]; W[brow * n + j] = t; }
+            for (int j = 0; j < q; ++j) { const double t = RHS[p * q + j]; RHS[p * q + j] = RHS[brow * q + j]; RHS[brow * q + j] = t; }
+        }
+        const double piv = W[p * n + p];
+        for (int j = 0; j < n; ++j) W[p * n + j] = W[p * n + j] / piv;
+        for (int j = 0; j < q; ++j) RHS[p * q + j] = RHS[p * q + j] / piv;
+        for (int r = 0; r < n; ++r) {
+            if (r == p) continue;
+            const double f = W[r * n + p];
+            for (int j = 0; j < n; ++j) if (j != p) W[r * n + j] -= f * W[p * n + j];
+            for (int j = 0; j < q; ++j) RHS[r * q + j] -= f * RHS[p * q + j];
+        }
+        for (int r = 0; r < n; ++r) if (r != p) W[r * n + p] = 0.0;
+    }
+}
+#define PLQR_Q 18
+#define PLQR_R 34
+#define PLQR_EPS 35
+static void trig_of(const orc* o, const double* x, double* tr);
+static int dare_lqr(const orc* o, const double* x0, const double* u0, double* S_out, double* K_out) {
+    enum { NN = MAXN * MAXN };
+    const int n = o->n, m = o->m;
+    const double *Qd = o->P + PLQR_Q, *Rd = o->P + PLQR_R, eps = o->P[PLQR_EPS], dt = o->dt, tol = 1e-14;
+    double A[NN], Bm[NN], Ak[NN], G[NN], Hm[NN], W[NN], T1[NN], T2[NN], T3[NN], Rm[MAXM * MAXM], X[NN], Y[NN], Z[MAXM * MAXM];
+    for (int lane = 0; lane < n + m; ++lane) {                 /* central differences, one perturbed coordinate each */
+        double xp[MAXN], xm[MAXN], xa[MAXN], ua[MAXM], uc[MAXM], tr[4];
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            for (int d = 0; d < n; ++d) xa[d] = x0[d];
+            for (int j = 0; j < m; ++j) ua[j] = u0[j];
+            const double h = sgn == 0 ? eps : -eps;
+            if (lane < n) xa[lane] += h; else ua[lane - n] += h;
+            trig_of(o, xa, tr);
+            for (int j = 0; j < m; ++j) uc[j] = ua[j];
+            step(o, xa, tr, uc, dt, sgn == 0 ? xp : xm);
+        }
+        for (int d = 0; d < n; ++d) {
+            const double v = (xp[d] - xm[d]) / (2.0 * eps);
+            if (lane < n) A[d * n + lane] = v; else Bm[d * m + (lane - n)] = v;
+        }
+    }
+    for (int i = 0; i < m * m; ++i) Rm[i] = Rd[i];
+    for (int i = 0; i < n * n; ++i) { Hm[i] = Qd[i]; Ak[i] = A[i]; }
+    for (int i = 0; i < m * n; ++i) X[i] = Bm[(i % n) * m + (i / n)];
+    for (int i = 0; i < m * m; ++i) Z[i] = Rm[i];
+    dsolve(Z, X, m, n);                                         /* X = R^-1 B' */
+    dmm(G, Bm, X, n, m, n, 0, 0);
+    int it = 0;
+    for (; it < 64; ++it) {
+        dmm(W, G, Hm, n, n, n, 0, 0);
+        for (int i = 0; i < n; ++i) W[i * n + i] += 1.0;
+        for (int i = 0; i < n * n; ++i) { T1[i] = Ak[i]; T2[i] = G[i]; T3[i] = W[i]; }
+        dsolve(W, T1, n, n);                                    /* T1 = (I + G H)^-1 A */
+        dsolve(T3, T2, n, n);                                   /* T2 = (I + G H)^-1 G */
+        dmm(W, Hm, T1, n, n, n, 0, 0);
+        dmm(T3, Ak, W, n, n, n, 1, 0);                          /* T3 = A' H (I + G H)^-1 A */
+        double dmax = 0.0, hmax = 0.0;
+        for (int i = 0; i < n * n; ++i) {
+            const double hn = Hm[i] + T3[i];
+            dmax = fmax(dmax, fabs(T3[i])); hmax = fmax(hmax, fabs(hn));
+            Hm[i] = hn;
+        }
+        dmm(W, Ak, T2, n, n, n, 0, 0);
+        dmm(T3, W, Ak, n, n, n, 0, 1);                          /* T3 = A (I + G H)^-1 G A' */
+        for (int i = 0; i < n * n; ++i) G[i] += T3[i];
+        dmm(W, Ak, T1, n, n, n, 0, 0);
+        for (int i = 0; i < n * n; ++i) Ak[i] = W[i];
+        if (dmax <= tol * fmax(1.0, hmax)) { ++it; break; }
+    }
+    for (int i = 0; i < n * n; ++i) T1[i] = 0.5 * (Hm[i] + Hm[(i % n) * n + (i / n)]);
+    dmm(X, Bm, T1, m, n, n, 1, 0);
+    dmm(Z, X, Bm, m, n, m, 0, 0);
+    for (int i = 0; i < m * m; ++i) Z[i] += Rm[i];
+    dmm(Y, X, A, m, n, n, 0, 0);
+    dsolve(Z, Y, m, n);
+    if (S_out) memcpy(S_out, T1, sizeof(double) * n * n);
+    if (K_out) memcpy(K_out, Y, sizeof(double) * m * n);
+    return it;
+}
+
 static void gain(const orc* o, const double* x, const double* tr, const double* u, double* K) {
-    (void)x; (void)u;
+    if (o->model == PEND_LQR) { dare_lqr(o, x, u, 0, K); return; }
     const double* P = o->P;
     const double c = tr[0], s = tr[1];
     const double *kp = 0, *kd = 0;
@@ -270,6 +372,7 @@ static void step(const orc* o, const double* x, const double* tr, double* u, dou
             if (xn[3] < 0.0) xn[3] = 0.0;
             xn[4] = clipd(fabs(xn[3] / P[8]), 0.0, 1.0) * xn[4];
         } break;
+        case PEND_LQR:
         case PEND: {
             const double c1 = tr[2], s1 = tr[3], c0 = tr[0];
             const double c01 = lq_cos(x[0] + x[1]);
@@ -316,6 +419,7 @@ static int feasible(const orc* o, const double* x, const double* u, const double
         case CAR:
             if (o->og) return !grid_hits(o, x[0], x[1], tr[0], tr[1]);
             return !hull_hits(o, x[0], x[1], tr[0], tr[1], 1);
+        case PEND_LQR:
         case PEND: return !(fabs(u[0]) > P[13]);
         case DINT:
             for (int ob = 0; ob < o->O; ++ob) {
@@ -340,6 +444,7 @@ orc* orc_create(int model, const double* params, int n_params, const double* vps
     switch (model) {
         case BOAT_ADV: case BOAT_INT: case BOAT_NOV: case ROS_BOAT: o->n = 6; o->m = 3; o->nw = 1; o->wd[0] = 2; break;
         case CAR: o->n = 5; o->m = 2; o->nw = 1; o->wd[0] = 2; break;
+        case PEND_LQR:
         case PEND: o->n = 4; o->m = 1; o->nw = 2; o->wd[0] = 0; o->wd[1] = 1; break;
         case DINT: o->n = 12; o->m = 6; o->nw = 0; break;
         default: free(o); return 0;
@@ -448,7 +553,8 @@ static int nearest(const orc* o, const double* xs, const double* Sd, int pruning
 /* nearest among the first `count` nodes (the synchronous wave mode searches the wave-start snapshot) */
 static int nearest_upto(const orc* o, const double* xs, const double* Sd, int pruning, int count) {
     const int n = o->n;
-    double gt[4], e[MAXN], prod[MAXN];
+    double gt[4], e[MAXN], prod[MAXN], Sx[MAXN * MAXN], u0[MAXM] = {0};
+    if (o->model == PEND_LQR && !Sd) { dare_lqr(o, xs, u0, Sx, 0); Sd = Sx; }   /* S = lqr(xrand, 0)[0], planner.py:344-345 */
     trig_of(o, xs, gt);
     double best = INFINITY, best_all = INFINITY;
     int bi = -1, bai = -1;
@@ -654,7 +760,8 @@ int orc_nearest_prefix(orc* o, const double* x, const double* Sd, int pruning, i
 /* planner.py:340-350: the whole cost vector against the first `count` nodes */
 void orc_costs_prefix(orc* o, const double* xs, const double* Sd, int count, double* out) {
     const int n = o->n;
-    double gt[4], e[MAXN], prod[MAXN];
+    double gt[4], e[MAXN], prod[MAXN], Sx[MAXN * MAXN], u0[MAXM] = {0};
+    if (o->model == PEND_LQR && !Sd) { dare_lqr(o, xs, u0, Sx, 0); Sd = Sx; }
     trig_of(o, xs, gt);
     for (int i = 0; i < count; ++i) {
         erf_cached(o, xs, gt, o->state + (size_t)i * n, o->trig + (size_t)i * 4, e);
@@ -708,6 +815,8 @@ void orc_dynamics(const orc* o, const double* x, const double* u, double* xn) {
 }
 int orc_feasible(const orc* o, const double* x, const double* u) { double tr[4]; trig_of(o, x, tr); return feasible(o, x, u, tr); }
 void orc_gain(const orc* o, const double* x, const double* u, double* K) { double tr[4]; trig_of(o, x, tr); gain(o, x, tr, u, K); }
+/* (S, K, doubling iterations) of the Riccati lqr at (x, u) -- PEND_LQR only */
+int orc_lqr(const orc* o, const double* x, const double* u, double* S, double* K) { return dare_lqr(o, x, u, S, K); }
 void orc_erf(const orc* o, const double* xg, const double* x, double* e) {
     double gt[4], tr[4];
     trig_of(o, xg, gt); trig_of(o, x, tr);

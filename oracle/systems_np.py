@@ -500,6 +500,44 @@ class DoublePendulum(object):
         return True
 
 
+class PendulumLqr(DoublePendulum):
+    """
+    The double pendulum with the lqr the reference's API contract describes (planner.py:39-42, tree.py:44-47: "S solves
+    the local Riccati equation, K the feedback gain") -- what demo_pendulum.py imports scipy.linalg.solve_discrete_are
+    for (:19) without calling it: A, B by central differences of `dynamics` about (x, u), S = solve_discrete_are(A, B, Q, R),
+    K = (R + B'SB)^-1 B'SA.  Written the way a user of the reference would write the callback (NumPy + SciPy); the
+    reference Planner driven by it generates tests/golden/traj_pendulum_lqr_*.npz.
+    """
+
+    def __init__(self, obstacle_seed=0, Q=(10.0, 10.0, 1.0, 1.0), R=0.1, eps=1e-6):
+        DoublePendulum.__init__(self, obstacle_seed)
+        self.Q = np.diag(np.asarray(Q, dtype=np.float64))
+        self.R = np.array([[float(R)]])
+        self.eps = float(eps)
+
+    def linearize(self, x, u):
+        n, m, dt, eps = self.nstates, self.ncontrols, self.plan_kwargs["dt"], self.eps
+        x = np.array(x, dtype=np.float64)
+        u = np.atleast_1d(np.array(u, dtype=np.float64))
+        A, B = np.zeros((n, n)), np.zeros((n, m))
+        for j in range(n):
+            d = np.zeros(n)
+            d[j] = eps
+            A[:, j] = (self.dynamics(x + d, np.copy(u), dt) - self.dynamics(x - d, np.copy(u), dt)) / (2 * eps)
+        for j in range(m):
+            d = np.zeros(m)
+            d[j] = eps
+            B[:, j] = (self.dynamics(np.copy(x), u + d, dt) - self.dynamics(np.copy(x), u - d, dt)) / (2 * eps)
+        return A, B
+
+    def lqr(self, x, u):
+        import scipy.linalg
+        A, B = self.linearize(x, u)
+        S = scipy.linalg.solve_discrete_are(A, B, self.Q, self.R)
+        K = npl.solve(self.R + B.T.dot(S).dot(B), B.T.dot(S).dot(A))
+        return (S, K)
+
+
 # --------------------------------------------------------------------------- synthetic config 5
 
 class DoubleIntegrator(object):
@@ -562,6 +600,7 @@ SYSTEMS = {
     "car": Car,
     "pendulum": DoublePendulum,
     "double_integrator": DoubleIntegrator,
+    "pendulum_lqr": PendulumLqr,
     "ros_boat": RosBoat,
 }
 

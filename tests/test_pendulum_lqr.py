@@ -1,0 +1,150 @@
+"""
+The north-star steer pipeline end to end: finite-difference linearise -> discrete Riccati equation -> K-gain forward
+rollout, with K refreshed at every recorded step (planner.py:436), once per new node (:257) and S recomputed about
+every sample for the cost-to-go (:344-345).
+
+System: demo_pendulum.py's double pendulum with the `lqr` the reference's API contract describes (planner.py:39-42;
+the demo imports scipy.linalg.solve_discrete_are at :19 and never calls it).  Fixture
+tests/golden/traj_pendulum_lqr_120.npz = the REFERENCE's Planner driven by oracle/systems_np.PendulumLqr (NumPy
+central differences + SciPy's DARE), tools/gen_golden.py --job plqr120.
+
+Tolerances.  Topology (parents, nearest ids, edge lengths, counts) exact.  The Riccati equation at dt = 1 ms is
+ill-conditioned: SciPy's Schur method and the doubling iteration the oracle / device use agree to ~1e-7 relative on S
+and K (neither is the exact solution), so gains are compared at 2e-5 relative (worst case: samples whose cost-to-go is ~1e11, a nearly uncontrollable linearisation), node states at 1e-7 absolute
+(observed ~1e-10), and HIP against the C oracle -- the same algorithm in the same order -- bit for bit.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import teacher
+
+K_RTOL = 2e-5
+X_ATOL = 1e-7
+
+
+def _fx(golden_dir):
+    path = os.path.join(golden_dir, "traj_pendulum_lqr_120.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture missing")
+    return np.load(path)
+
+
+def _native():
+    import lqrrt_amd
+    return lqrrt_amd.systems.PendulumLqr(0)
+
+
+def test_numpy_twin_reproduces_the_reference_run(golden_dir):
+    from systems_np import PendulumLqr, make_oracle_planner
+    g = _fx(golden_dir)
+    s = PendulumLqr(0)
+    np.testing.assert_array_equal(s.Q, g["Q"])
+    p = make_oracle_planner(s, int(g["max_nodes"]), min_time=60, max_time=61)
+    np.random.seed(1)
+    ret = p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10, trace=True)
+    assert ret == bool(g["returned"]) and p.iterations == int(g["iterations"])
+    np.testing.assert_array_equal(np.array(p.tree.pID, dtype=np.int32), g["pID"])
+    np.testing.assert_array_equal(np.array(p.trace["steer_len"], dtype=np.int16), g["steer_len"])
+    np.testing.assert_allclose(p.tree.state, g["state"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(np.array([lk[1] for lk in p.tree.lqr]), g["K"], rtol=1e-9)
+
+
+def test_c_oracle_riccati_vs_scipy(golden_dir):
+    """S of the sequential doubling solver against SciPy's, at the samples of the reference's run (K: the run test)."""
+    import coracle
+    g = _fx(golden_dir)
+    o = coracle.make(_native(), 16, seed=1)
+    for x, S_ref in zip(g["xrand_all"][:60], g["S_samples"][:60]):
+        S, _, it = o.lqr(x, np.zeros(1))
+        assert it < 40
+        np.testing.assert_allclose(S, S_ref, rtol=K_RTOL, atol=K_RTOL * np.abs(S_ref).max())
+
+
+def test_c_oracle_vs_reference_run(golden_dir):
+    import coracle
+    g = _fx(golden_dir)
+    s = _native()
+    o = coracle.make(s, int(g["max_nodes"]), seed=1)
+    o.enable_trace(int(g["iterations"]) + 16)
+    assert o.extend(max_nodes=int(g["max_nodes"])) == 2
+    assert o.iterations == int(g["iterations"]) and o.candidates == int(g["n_candidates"])
+    np.testing.assert_array_equal(o.parents(), g["pID"])
+    near, ln = o.trace()
+    np.testing.assert_array_equal(near, g["nearest"])
+    np.testing.assert_array_equal(ln, g["steer_len"].astype(np.int32))
+    np.testing.assert_allclose(o.states(), g["state"], rtol=0, atol=X_ATOL)
+    np.testing.assert_allclose(o.gains(), g["K"], rtol=K_RTOL, atol=K_RTOL * np.abs(g["K"]).max())
+    for t in "abc":
+        x, u = o.edge(int(g["edge_%s_id" % t]))
+        np.testing.assert_allclose(x, g["edge_%s_x" % t], rtol=0, atol=X_ATOL)
+    # teacher-forced: every decision of the reference's run from the reference's own tree
+    sch = teacher.Schedule(g, s.goal, s.goal_buffer)
+    o.load_tree(sch.state, sch.K, sch.pID)
+    for size, a, b in sch.groups():
+        for t in range(a, b):
+            assert o.nearest_prefix(sch.xrand[t], size) == sch.nearest[t]
+            k, xs, _, Kend = o.steer_from(sch.nearest[t], sch.xrand[t])
+            assert k == sch.steer_len[t]
+            if k:
+                assert np.abs(xs[-1] - sch.state[sch.new_node[t]]).max() < X_ATOL
+
+
+@pytest.mark.gpu
+def test_hip_riccati_operator_vs_scipy(golden_dir):
+    """lqr plugin handle (lqrrt_lqr_dare_batch) against SciPy's S at the samples of the reference's run."""
+    g = _fx(golden_dir)
+    s = _native()
+    for x, S_ref in zip(g["xrand_all"][:40], g["S_samples"][:40]):
+        S, K = s.lqr(x, np.zeros(1))
+        np.testing.assert_allclose(S, S_ref, rtol=K_RTOL, atol=K_RTOL * np.abs(S_ref).max())
+        assert K.shape == (1, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wave", [16, 64])
+def test_hip_vs_reference_run_and_c_oracle(golden_dir, wave):
+    import coracle
+    import lqrrt_amd as lqrrt
+    g = _fx(golden_dir)
+    s = _native()
+    cons = lqrrt.Constraints(s.nstates, s.ncontrols, s.goal_buffer, s.is_feasible)
+    p = lqrrt.Planner(s.dynamics, s.lqr, cons, error_tol=s.error_tol, erf=s.erf, min_time=60, max_time=61,
+                      max_nodes=int(g["max_nodes"]), goal0=s.goal, sys_time=lambda: 0.0, printing=False, wave_size=wave,
+                      **s.plan_kwargs)
+    np.random.seed(1)
+    ret = p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10)
+    assert ret == bool(g["returned"])
+    assert p.stats["attempts"] == int(g["iterations"]) and p.stats["candidates"] == int(g["n_candidates"])
+    # against the reference's run
+    np.testing.assert_array_equal(np.array(p.tree.pID, dtype=np.int32), g["pID"])
+    np.testing.assert_array_equal(p._engine.edge_lengths(), g["edge_len"])
+    np.testing.assert_allclose(p.tree.state, g["state"], rtol=0, atol=X_ATOL)
+    np.testing.assert_allclose(p._engine.gains(), g["K"], rtol=K_RTOL, atol=K_RTOL * np.abs(g["K"]).max())
+    np.testing.assert_array_equal(np.array(p.node_seq, dtype=np.int32), g["node_seq"])
+    np.testing.assert_allclose(np.array(p.x_seq), g["plan_x"], rtol=0, atol=X_ATOL)
+    # against the sequential C oracle (same Riccati algorithm in the same order): bit for bit
+    o = coracle.make(s, int(g["max_nodes"]), seed=1)
+    assert o.extend(max_nodes=int(g["max_nodes"])) == 2
+    np.testing.assert_array_equal(p._engine.parents(), o.parents())
+    np.testing.assert_array_equal(p._engine.states(), o.states())
+    np.testing.assert_array_equal(p._engine.gains(), o.gains())
+    np.testing.assert_array_equal(p._engine.edge_lengths(), o.edge_lengths())
+    x, u = p._engine.edge(int(g["edge_b_id"]))
+    xo, uo = o.edge(int(g["edge_b_id"]))
+    np.testing.assert_array_equal(x, xo)
+    np.testing.assert_array_equal(u, uo)
+
+
+@pytest.mark.gpu
+def test_hip_teacher_forced(golden_dir):
+    from test_teacher_gpu import replay_hip
+    g = _fx(golden_dir)
+    s = _native()
+    sch = teacher.Schedule(g, s.goal, s.goal_buffer)
+    kw = s.plan_kwargs
+    r = replay_hip(s, sch, kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]), wave=64)
+    print(r)
+    assert r["nearest_miss"] == 0 and r["steer_len_mismatch"] == 0
+    assert r["end_state_compared"] == len(sch.state) - 1 and r["end_state_max_err"] < X_ATOL

@@ -429,6 +429,60 @@ def gen_config5(max_nodes=600, n_boxes=3000, tag=None):
         path, len(nearest), out["n_candidates"], tree.size, out["pid_hash"], bool(planner.plan_reached_goal), int(np.sum(ties)), wall))
 
 
+def gen_pendulum_lqr(max_nodes=120, tag=None):
+    """
+    The north-star steer pipeline on the reference itself: the REFERENCE's Planner with oracle/systems_np.PendulumLqr's
+    callbacks, whose lqr linearises the demo_pendulum dynamics by central differences and calls
+    scipy.linalg.solve_discrete_are for every rollout step, new node and sample.
+    """
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from systems_np import PendulumLqr
+    lq = rl.import_reference()
+    s = PendulumLqr(OBS_SEED)
+    cons = lq.Constraints(nstates=s.nstates, ncontrols=s.ncontrols, goal_buffer=s.goal_buffer, is_feasible=s.is_feasible)
+    planner = lq.Planner(s.dynamics, s.lqr, cons, error_tol=s.error_tol, erf=s.erf, min_time=60, max_time=61, max_nodes=max_nodes,
+                         goal0=s.goal, printing=False, sys_time=lambda: 0.0, **s.plan_kwargs)
+    xrands, nearest, slen, Ssamp = [], [], [], []
+    ctg, steer, lqr = planner._costs_to_go, planner._steer, planner.lqr
+
+    def ctg_spy(x):
+        xrands.append(np.copy(x))
+        Ssamp.append(np.array(lqr(np.copy(x), np.zeros(s.ncontrols))[0]))
+        return ctg(x)
+
+    def steer_spy(ID, xtar, force_arrive=False):
+        r = steer(ID, xtar, force_arrive)
+        nearest.append(int(ID)); slen.append(len(r[0]))
+        return r
+    planner._costs_to_go, planner._steer = ctg_spy, steer_spy
+    np.random.seed(PLAN_SEED)
+    t0 = time.time()
+    ret = planner.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10)
+    wall = time.time() - t0
+    n = s.nstates
+    probe = np.random.sample()
+    stream = np.random.RandomState(PLAN_SEED).random_sample((len(xrands) * 12 + 64) * (n + 1))
+    pos = int(np.flatnonzero(stream == probe)[0])
+    tree = planner.tree
+    out = dict(max_nodes=np.int64(max_nodes), min_time=np.float64(60), iterations=np.int64(len(nearest)),
+               n_candidates=np.int64(pos // (n + 1)), returned=np.bool_(ret), reached_goal=np.bool_(planner.plan_reached_goal),
+               pID=np.array(tree.pID, dtype=np.int32), state=np.array(tree.state), K=np.array([lk[1] for lk in tree.lqr]),
+               S_nodes=np.array([lk[0] for lk in tree.lqr]), S_samples=np.array(Ssamp),
+               edge_len=np.array([len(e) for e in tree.x_seq], dtype=np.int32), nearest=np.array(nearest, dtype=np.int32),
+               steer_len=np.array(slen, dtype=np.int16), xrand_all=np.array(xrands), node_seq=np.array(planner.node_seq, dtype=np.int32),
+               plan_x=np.array(planner.x_seq), plan_u=np.array(planner.u_seq), plan_T=np.float64(planner.T),
+               pid_hash=np.array(pid_hash(tree.pID)), Q=s.Q, R=s.R, eps=np.float64(s.eps), ref_wall_s=np.float64(wall),
+               pruning=np.bool_(True), tries=np.int64(10))
+    for tagid, ID in (("a", 1), ("b", tree.size // 2), ("c", tree.size - 1)):
+        out["edge_%s_id" % tagid] = np.int32(ID)
+        out["edge_%s_x" % tagid] = np.array(tree.x_seq[ID], dtype=np.float64)
+        out["edge_%s_u" % tagid] = np.array(tree.u_seq[ID], dtype=np.float64)
+    path = os.path.join(OUT, "traj_pendulum_lqr_%s.npz" % (tag or str(max_nodes)))
+    np.savez_compressed(path, **out)
+    print("wrote %s: iters=%d cand=%d nodes=%d hash=%s goal=%s wall=%.1fs" % (
+        path, len(nearest), out["n_candidates"], tree.size, out["pid_hash"], bool(planner.plan_reached_goal), wall))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--long", action="store_true", help="also run boat_advanced to 10k nodes (~20 min)")
@@ -452,6 +506,8 @@ def main():
         # BASELINE config 5 on the reference's Planner with the build's NumPy callbacks
         "di600": lambda: gen_config5(600, 3000),
         "di2500": lambda: gen_config5(2500, 3000),
+        # finite-difference linearise -> DARE -> K rollout on the reference's Planner (scipy.linalg.solve_discrete_are)
+        "plqr120": lambda: gen_pendulum_lqr(120),
     }
     if args.job:
         jobs[args.job]()
