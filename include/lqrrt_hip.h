@@ -318,6 +318,17 @@ int lqrrt_wave_suggest(lqrrt_engine* e, int wave_cap);
  * (all-gather of the record buffer), then every rank calls lqrrt_wave_commit. */
 int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void* stream);
 
+/* Tree-sharded wave (the alternative of SURVEY 8e for large trees, e.g. BASELINE config 5): every rank holds the whole
+ * tree but scans only nodes [node_lo, node_hi) -- node_lo a multiple of 64 -- for ALL W samples of the wave, and reduces
+ * them to one candidate per sample: best_dev [W][2] doubles = (cost, node id as a double; id -1 = nothing eligible in
+ * the range).  The candidates of all ranks are all-gathered (16*W bytes per rank: the path's one collective) in
+ * ascending node-range order into [parts][W][2] and handed to lqrrt_wave_steer_candidates, which picks each sample's
+ * nearest node by (cost, id) -- exactly the node a single scan returns, incl. the every-node-ignored fallback of
+ * planner.py:241,245 -- and runs the speculative steer of the whole wave on every rank.  No record exchange:
+ * lqrrt_wave_commit follows directly and the replicas stay bit-identical. */
+int lqrrt_wave_scan_nodes(lqrrt_engine* e, int W, int node_lo, int node_hi, double* best_dev, void* stream);
+int lqrrt_wave_steer_candidates(lqrrt_engine* e, int W, int parts, const double* best_dev, void* stream);
+
 /* Phase B (replicated): exact-mode validation/repair of the W records in sample order,
  * then append.  max_commit caps the attempts committed from this wave; node_limit is the
  * reference's max_nodes (stop once size > max_nodes, planner.py:311).  Advances the sample

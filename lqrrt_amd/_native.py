@@ -98,6 +98,8 @@ SIGNATURES = {
     "lqrrt_wave_records": (_I, [_P, C.POINTER(_P)]),
     "lqrrt_wave_suggest": (_I, [_P, _I]),
     "lqrrt_wave_speculate": (_I, [_P, _I, _I, _I, _P]),
+    "lqrrt_wave_scan_nodes": (_I, [_P, _I, _I, _I, _P, _P]),
+    "lqrrt_wave_steer_candidates": (_I, [_P, _I, _I, _P, _P]),
     "lqrrt_wave_commit": (_I, [_P, _I, _I64, _I64, _I, C.POINTER(ExtendStats), _P]),
     "lqrrt_engine_extend": (_I, [_P, _I, _I64, _I64, _I, _I, _I, C.POINTER(ExtendStats), _P]),
     "lqrrt_plan_best": (_I, [_P, C.POINTER(C.c_int32), C.POINTER(_I64), C.POINTER(_I64)]),

@@ -273,7 +273,7 @@ static NodeView tree_view(const lqrrt_engine* e, bool use_ignore) {
     v.len = nullptr;
     v.werr = (e->fix.on && e->werr_valid) ? e->tv.werr : nullptr; v.wk = e->cap;
     for (int j = 0; j < 4; ++j) v.wtrig[j] = e->fix.t[j];
-    v.count = e->N; v.pad = 0;
+    v.count = e->N; v.first = 0;
     return v;
 }
 
@@ -285,7 +285,7 @@ static NodeView record_view(const lqrrt_engine* e, int W) {
     v.werr = nullptr; v.wk = 0;
     for (int j = 0; j < 4; ++j) v.wtrig[j] = 0.0;
     v.len = e->d_rec + e->L.off_len;
-    v.count = W; v.pad = 0;
+    v.count = W; v.first = 0;
     return v;
 }
 
@@ -362,7 +362,7 @@ static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
 static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int W, const double* Sd,
                      bool tri, int* out_id, double* out_cost, double* rec, hipStream_t st,
                      bool profile, int* n_chunks_out = nullptr, int wave_lo = -1, bool defer_reduce = false,
-                     const double* xtrig = nullptr, const double* Spers = nullptr) {
+                     const double* xtrig = nullptr, const double* Spers = nullptr, bool range_candidates = false) {
     // Spers: one dense S per sample, [W][n*n] (Riccati systems: S = lqr(sample, 0)[0], planner.py:344-345); else Sd (one
     // matrix for all samples) or the system's constant S
     if (W <= 0) return 0;
@@ -401,8 +401,12 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
 #undef NN_LAUNCH
     if (profile) prof_end(e, st, &ev, 0, (double)W * (double)nv.count * (8.0 * e->n + 1.0));
     if (tri || defer_reduce) { HIPCHK(hipGetLastError()); return 0; }     // deferred: the steer launch reduces (SteerFuse)
+    NodeView nvr = nv;
+    // candidates of a node RANGE (tree-sharded waves): "nothing eligible here" is an answer; the every-node-ignored
+    // fallback of planner.py:241,245 is decided later, over the candidates of all ranges (k_steer prologue)
+    if (range_candidates) nvr.ignore = nullptr;
 #define RED_LAUNCH(DENSE)                                                                                 \
-    DISPATCH(e, hipLaunchKernelGGL((k_nn_reduce<S, DENSE>), dim3(W), dim3(64), 0, st, e->d_pcost, e->d_pidx, W, n_chunks, nv, \
+    DISPATCH(e, hipLaunchKernelGGL((k_nn_reduce<S, DENSE>), dim3(W), dim3(64), 0, st, e->d_pcost, e->d_pidx, W, n_chunks, nvr, \
                                    xs, S_use, s_stride, out_id, out_cost, rec, e->L.R, e->L.off_cost, e->L.off_parent,     \
                                    wave_lo >= 0 ? e->d_par_done + wave_lo : nullptr,                                      \
                                    wave_lo >= 0 ? e->d_changed + wave_lo : nullptr,                                       \
@@ -1424,6 +1428,59 @@ extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void
     HIPCHK(hipGetLastError());
     e->wave_complete = whole;
     e->tot.speculated += cnt;
+    return 0;
+}
+
+extern "C" int lqrrt_wave_scan_nodes(lqrrt_engine* e, int W, int node_lo, int node_hi, double* best_dev, void* stream) {
+    if (!e || !best_dev) return fail(LQRRT_E_ARG, "null argument");
+    if (W < 1 || W > e->maxW) return fail(LQRRT_E_ARG, "bad wave size");
+    if (!e->has_res) return fail(LQRRT_E_STATE, "set_resolution first");
+    if (e->N < 1) return fail(LQRRT_E_STATE, "no tree: call lqrrt_tree_reset");
+    if (node_lo < 0 || node_hi < node_lo || node_hi > e->N || (node_hi > node_lo && (node_lo & 63)))
+        return fail(LQRRT_E_ARG, "bad node range (node_lo must be a multiple of 64)");
+    if (e->N + W > e->cap) return fail(LQRRT_E_CAPACITY, "tree capacity %d too small for size %d + wave %d", e->cap, e->N, W);
+    TRY(use_device(e));
+    hipStream_t st = (hipStream_t)stream;
+    TRY(ensure_samples(e, e->cursor + W, st));
+    TRY(flush_ignore(e, st, false));
+    TRY(ensure_werr(e, st));
+    int* ids = e->d_par_want;                                 // scratch: W ints (k_decide rewrites it every round)
+    double* costs = e->d_M;                                   // scratch: W doubles (the in-wave matrix is rebuilt by the steer)
+    if (node_hi > node_lo) {
+        NodeView nv = tree_view(e, true);
+        nv.first = node_lo; nv.count = node_hi - node_lo;
+        TRY(launch_nn(e, nv, wave_samples(e), W, nullptr, false, ids, costs, nullptr, st, true, nullptr, -1, false,
+                      wave_sample_trig(e), wave_sample_S(e), true));
+    } else {
+        HIPCHK(hipMemsetAsync(ids, 0xff, sizeof(int) * W, st));       // id -1: nothing in an empty range
+        HIPCHK(hipMemsetAsync(costs, 0, sizeof(double) * W, st));
+    }
+    hipLaunchKernelGGL(k_best_pack, dim3((W + 255) / 256), dim3(256), 0, st, costs, ids, W, best_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lqrrt_wave_steer_candidates(lqrrt_engine* e, int W, int parts, const double* best_dev, void* stream) {
+    if (!e || !best_dev) return fail(LQRRT_E_ARG, "null argument");
+    if (W < 1 || W > e->maxW || parts < 1 || parts > lqrrt_engine::MAXCH) return fail(LQRRT_E_ARG, "bad wave size / part count");
+    if (e->N < 1 || !e->has_res) return fail(LQRRT_E_STATE, "no tree / resolution");
+    TRY(use_device(e));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_best_unpack, dim3((W * parts + 255) / 256), dim3(256), 0, st, best_dev, W, parts, e->d_pcost, e->d_pidx);
+    static const int matrix_max = getenv("LQRRT_MATRIX_MAX_W") ? std::min(atoi(getenv("LQRRT_MATRIX_MAX_W")), (int)lqrrt_engine::MATRIX_MAX_W)
+                                                                : (int)lqrrt_engine::MATRIX_MAX_W;
+    e->wave_matrix = W <= matrix_max && !e->sync_mode && !e->riccati;
+    const double* xtr = wave_sample_trig(e);
+    SteerFuse f;
+    memset(&f, 0, sizeof f);
+    f.pcost = e->d_pcost; f.pidx = e->d_pidx; f.n_chunks = parts; f.nv = tree_view(e, true);
+    f.changed = e->d_changed; f.stale = e->d_stale; f.par_out = e->d_par_done;
+    f.M = e->wave_matrix ? e->d_M : nullptr; f.W = W;
+    f.xtrig = xtr;
+    if (e->riccati) { f.Sd = wave_sample_S(e); f.s_stride = (long long)e->n * e->n; }
+    TRY(launch_steer(e, wave_samples(e), nullptr, 0, W, e->d_par_done, st, nullptr, &f));
+    e->wave_complete = true;
+    e->tot.speculated += W;
     return 0;
 }
 

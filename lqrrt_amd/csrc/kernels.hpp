@@ -47,7 +47,7 @@ struct NodeView {
     const double* werr;
     long long wk;
     double wtrig[4];
-    int count, pad;
+    int count, first;       // nodes first .. first + count - 1 are scanned (first = 0 except for tree-sharded scans)
 };
 
 struct TreeView {
@@ -203,9 +203,9 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
     }
     const int t = bx * 64 + lane;
     const int ts = t < W ? t : W - 1;
-    const int i0 = by * chunk;
+    const int i0 = nv.first + by * chunk;
     int i1 = i0 + chunk;
-    if (i1 > nv.count) i1 = nv.count;
+    if (i1 > nv.first + nv.count) i1 = nv.first + nv.count;
     if constexpr (TRI) {
         const int tmax = bx * 64 + 63;
         if (i1 > tmax) i1 = tmax;
@@ -440,6 +440,21 @@ __global__ __launch_bounds__(64) void k_nn_reduce(const double* __restrict__ pco
         }
         if (par_done) { par_done[t] = bi; changed[t] = 0; stale[t] = 0; }   // wave bookkeeping starts here
     }
+}
+
+// Tree-sharded waves: (cost, id) candidate of every sample from one rank's node range, as W pairs of doubles (the
+// all-gather payload), and back into the partial-minima layout the steer prologue reduces ([sample][part]).
+__global__ void k_best_pack(const double* __restrict__ cost, const int* __restrict__ id, int W, double* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < W) { out[2 * t] = cost[t]; out[2 * t + 1] = (double)id[t]; }
+}
+__global__ void k_best_unpack(const double* __restrict__ in, int W, int parts, double* __restrict__ pcost, int* __restrict__ pidx) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= W * parts) return;
+    const int t = q / parts, p = q - t * parts;
+    const double* src = in + ((size_t)p * W + t) * 2;
+    pcost[q] = src[0];
+    pidx[q] = (int)src[1];
 }
 
 // Full cost vector of one sample (planner.py:340-350); thread per node.

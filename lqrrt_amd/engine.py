@@ -357,6 +357,14 @@ class Engine(object):
     def wave_speculate(self, W, lo, hi):
         nat.check(nat.lib().lqrrt_wave_speculate(self.h, W, lo, hi, self._stream()))
 
+    def wave_scan_nodes(self, W, node_lo, node_hi, best_ptr):
+        """Tree-sharded wave, phase 1: this rank's (cost, id) candidates [W][2] over nodes [node_lo, node_hi)."""
+        nat.check(nat.lib().lqrrt_wave_scan_nodes(self.h, int(W), int(node_lo), int(node_hi), best_ptr, self._stream()))
+
+    def wave_steer_candidates(self, W, parts, best_ptr):
+        """Tree-sharded wave, phase 2: nearest node per sample from the gathered candidates [parts][W][2], then the steer."""
+        nat.check(nat.lib().lqrrt_wave_steer_candidates(self.h, int(W), int(parts), best_ptr, self._stream()))
+
     def wave_commit(self, W, max_commit, node_limit, pruning=True):
         st = nat.ExtendStats()
         nat.check(nat.lib().lqrrt_wave_commit(self.h, W, int(max_commit), int(node_limit), 1 if pruning else 0,

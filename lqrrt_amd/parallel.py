@@ -11,8 +11,14 @@ replicas stay bit-identical without further traffic.  The collective is the only
 of the path; payload = W * record_doubles * 8 B (boat: 1712 B/record, 1.75 MB per 1024-wave),
 latency- rather than bandwidth-bound on 7 x 153 GB/s xGMI links.
 
-The class is engine-agnostic (anything with wave_speculate / wave_commit / a records tensor),
-which is how tests/test_parallel_cpu.py drives it with gloo on CPU.
+ShardedWave is the sample-sharded scheme above.  TreeShardedWave is SURVEY 8(e)'s alternative for large trees
+(BASELINE config 5, where the nearest-neighbour scan over 50k nodes dominates a wave): every rank scans only its 1/G of
+the NODES for all W samples, the per-sample (cost, id) candidates -- 16*W bytes per rank -- are all-gathered, and every
+rank then steers and commits the whole wave itself.  No records travel at all; the replicas stay bit-identical because
+the winner by (cost, id) over ascending node ranges is exactly the node a single scan returns.
+
+Both classes are engine-agnostic (anything with the wave_* methods and the buffers), which is how
+tests/test_parallel_cpu.py drives them with gloo on CPU.
 """
 import numpy as np
 
@@ -55,6 +61,7 @@ class ShardedWave(object):
         self.e, self.dist, self.rank, self.world = engine, dist, rank, world
         self.rec = records_tensor(engine) if records is None else records
         self.max_wave = self.rec.shape[0]
+        self.in_place = dist.get_backend() == "nccl" if hasattr(dist, "get_backend") else False
 
     def wave(self, want, max_commit, node_limit=-1, pruning=True):
         """One wave of up to `want` samples; returns the commit's ExtendStats."""
@@ -66,6 +73,40 @@ class ShardedWave(object):
             per, lo, hi = shard_bounds(W, self.rank, self.world)
         self.e.wave_speculate(W, lo, hi)
         full = self.rec[: per * self.world]
-        send = self.rec[self.rank * per: (self.rank + 1) * per].clone()
+        send = self.rec[self.rank * per: (self.rank + 1) * per]
+        if not self.in_place:
+            send = send.clone()                     # (gloo: no aliasing of input and output)
+        # RCCL gathers IN PLACE when the input is the rank's own chunk of the output buffer: no staging copy
         self.dist.all_gather_into_tensor(full.view(-1), send.view(-1))
+        return self.e.wave_commit(W, max_commit, node_limit, pruning)
+
+
+def node_range(size, rank, world):
+    """Rank `rank`'s slice [lo, hi) of `size` nodes, boundaries on multiples of 64 (aligned scalar loads of the scan)."""
+    per = ((size + world - 1) // world + 63) // 64 * 64
+    lo = min(size, rank * per)
+    return lo, min(size, lo + per)
+
+
+class TreeShardedWave(object):
+    def __init__(self, engine, dist, rank, world, best=None):
+        self.e, self.dist, self.rank, self.world = engine, dist, rank, world
+        if best is None:
+            import torch
+            best = torch.empty((world, engine.max_wave, 2), dtype=torch.float64, device="cuda:%d" % engine.device)
+        self.best = best                          # [world][max_wave][2] (cost, id) candidates; rank r's chunk is row r
+        self.max_wave = best.shape[1]
+        self.in_place = dist.get_backend() == "nccl" if hasattr(dist, "get_backend") else False
+
+    def wave(self, want, max_commit, node_limit=-1, pruning=True):
+        """One wave of up to `want` samples, all of them steered and committed on every rank."""
+        suggest = getattr(self.e, "wave_suggest", None)
+        W = min(suggest(self.max_wave) if suggest else pick_wave(self.e.size, self.max_wave), want)
+        lo, hi = node_range(self.e.size, self.rank, self.world)
+        buf = self.best[:, :W, :] if W == self.max_wave else self.best.view(-1)[: self.world * W * 2].view(self.world, W, 2)
+        mine = buf[self.rank]
+        self.e.wave_scan_nodes(W, lo, hi, mine.data_ptr())
+        send = mine if self.in_place else mine.clone()
+        self.dist.all_gather_into_tensor(buf.view(-1), send.view(-1))      # 16 * W bytes per rank: the one collective
+        self.e.wave_steer_candidates(W, self.world, buf.data_ptr())
         return self.e.wave_commit(W, max_commit, node_limit, pruning)

@@ -34,6 +34,8 @@ def test_bench_line_fields():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["launches"] > 0 and r["avg_launch_us"] > 0
+    assert 0 < r["compute"]["frac"] < 1 and 0 < r["compute"]["frac_of_non_fma_peak"] < 1      # the binding resource: fp64 issue
+    assert d["timed_region_s"] > 0.05
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["sample"]
     assert d["synchronous_mode"]["value"] > d["value"]             # the optional mode is an extra, never the metric
@@ -42,3 +44,15 @@ def test_bench_line_fields():
 def test_bench_sharded_code_path_world_of_one():
     d = _run(["--no-cpu", "--no-extras"], env={"LQRRT_FORCE_SHARDED": "1"})
     assert d["value"] > 1e4 and "cpu_baseline" not in d
+    d = _run(["--no-cpu", "--no-extras", "--shard", "tree"], env={"LQRRT_FORCE_SHARDED": "1"})
+    assert d["value"] > 1e4
+
+
+def test_bench_config5_workload():
+    """BASELINE config 5 (100k boxes, 50k-node window) through the same harness, single GPU and the tree-sharded
+    N>1 code path in a world of one."""
+    d = _run(["--workload", "cfg5", "--units", "4", "--cpu-seconds", "3"])
+    assert d["config"]["workload"] == "double_integrator_100k_boxes_50k" and d["config"]["nodes_window"] == [47500, 52500]
+    assert d["value"] > 1e4 and d["cpu_baseline"]["c_oracle_value"] > 0
+    d = _run(["--workload", "cfg5", "--units", "4", "--no-cpu", "--no-extras"], env={"LQRRT_FORCE_SHARDED": "1"})
+    assert d["value"] > 1e4

@@ -1,5 +1,5 @@
 """
-world_size-2 gloo test of the sample-sharded wave logic (lqrrt_amd/parallel.py) on CPU.
+world_size-2 and -4 gloo tests of the sample-sharded and the tree-sharded wave logic (lqrrt_amd/parallel.py) on CPU.
 
 There is no GPU here, so the engine is replaced by a stand-in that fills its slice of the record
 buffer with a deterministic function of (sample index, tree size) and "commits" by hashing the
@@ -29,8 +29,9 @@ class FakeStats(object):
 
 
 class FakeEngine(object):
-    """Mimics Engine.wave_speculate / wave_commit / size on a torch CPU tensor."""
-    R = 7
+    """Mimics Engine.wave_speculate / wave_commit / size on a torch CPU tensor, with the boat's real record width
+    (csrc make_layout: 4 + n + 2*nw + m*n + H*(n+m) = 210 doubles for n=6, m=3, nw=1, H=20)."""
+    R = 210
 
     def __init__(self, max_wave):
         import torch
@@ -58,6 +59,63 @@ class FakeEngine(object):
         acc = C // 3
         self.size += acc
         return FakeStats(C, acc)
+
+
+class FakeTreeEngine(object):
+    """Stand-in for the tree-sharded wave: node i has cost f(sample, i); every rank must end up steering each sample
+    from the global arg-min over ALL nodes although it only scanned its own range."""
+
+    def __init__(self, max_wave, size=1000):
+        self.max_wave, self.size, self.cursor, self.device = max_wave, size, 0, 0
+        self.digest = hashlib.sha1()
+        self.seen = []
+
+    @staticmethod
+    def cost(k, i):
+        return float((k * 7919 + i * 104729) % 1000003)
+
+    def wave_scan_nodes(self, W, lo, hi, best_ptr):
+        import ctypes
+        assert lo % 64 == 0 and 0 <= lo <= hi <= self.size
+        out = np.frombuffer((ctypes.c_double * (2 * W)).from_address(best_ptr), dtype=np.float64).reshape(W, 2)
+        for t in range(W):
+            k = self.cursor + t
+            c = [self.cost(k, i) for i in range(lo, hi)]
+            j = int(np.argmin(c)) if c else -1
+            out[t] = (c[j], lo + j) if c else (0.0, -1.0)
+
+    def wave_steer_candidates(self, W, parts, best_ptr):
+        import ctypes
+        buf = np.frombuffer((ctypes.c_double * (2 * W * parts)).from_address(best_ptr), dtype=np.float64).reshape(parts, W, 2)
+        self.parents = []
+        for t in range(W):
+            cand = [(buf[p, t, 0], int(buf[p, t, 1])) for p in range(parts) if buf[p, t, 1] >= 0]
+            self.parents.append(min(cand)[1])
+        want = [int(np.argmin([self.cost(self.cursor + t, i) for i in range(self.size)])) for t in range(W)]
+        assert self.parents == want, "the gathered candidates do not reproduce the global arg-min"
+
+    def wave_commit(self, W, max_commit, node_limit, pruning=True):
+        self.digest.update(np.array(self.parents, dtype=np.int64).tobytes())
+        C = min(W, max_commit)
+        self.cursor += C
+        self.size += C // 3
+        return FakeStats(C, C // 3)
+
+
+def _tree_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lqrrt_amd.parallel import TreeShardedWave
+    eng = FakeTreeEngine(64)
+    sw = TreeShardedWave(eng, dist, rank, world, best=torch.zeros((world, 64, 2), dtype=torch.float64))
+    total = 0
+    for want in (64, 40, 7, 64):
+        total += sw.wave(want, max_commit=want).attempts
+    out.put((rank, total, eng.size, eng.digest.hexdigest()))
+    dist.destroy_process_group()
 
 
 def _worker(rank, world, port, out):
@@ -90,7 +148,20 @@ def test_shard_bounds_cover_wave():
     assert pick_wave(10000, 1024) == 1024 and pick_wave(600, 1024) == 64 and pick_wave(10, 1024) == 8
 
 
-def test_sharded_wave_two_ranks_gloo():
+def test_node_ranges_cover_tree():
+    from lqrrt_amd.parallel import node_range
+    for size in (1, 63, 64, 65, 1000, 50000):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                lo, hi = node_range(size, r, world)
+                assert lo % 64 == 0 or lo == size
+                seen.extend(range(lo, hi))
+            assert seen == list(range(size))
+
+
+@pytest.mark.parametrize("world,worker", [(2, "_worker"), (4, "_worker"), (4, "_tree_worker")])
+def test_sharded_wave_gloo(world, worker):
     torch = pytest.importorskip("torch")
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -99,7 +170,7 @@ def test_sharded_wave_two_ranks_gloo():
     with socket.socket() as sk:                       # a port nobody holds right now
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=globals()[worker], args=(r, world, port, out)) for r in range(world)]
     for p in procs:
         p.start()
     # generous: a spawned interpreter has to import torch, which takes minutes in a cold container
@@ -108,4 +179,4 @@ def test_sharded_wave_two_ranks_gloo():
         p.join(timeout=120)
         assert p.exitcode == 0
     res.sort()
-    assert res[0][1:] == res[1][1:], "replicas diverged: %r" % (res,)
+    assert all(r[1:] == res[0][1:] for r in res), "replicas diverged: %r" % (res,)
