@@ -1,6 +1,7 @@
 """CPU-side checks of the C-ABI boundary: the library loads, exports every symbol that
 include/lqrrt_hip.h declares, and refuses to compute without a GPU (no CPU fallback)."""
 import os
+import sys
 import re
 
 import numpy as np
@@ -155,3 +156,19 @@ def test_reference_package_name_and_tree_constructor():
         t.add_node(3, [0, 0, 0], None, [], [])                    # tree.py:83-84
     with pytest.raises(ValueError, match="doesn't exist"):
         t.climb(9)                                                 # tree.py:109-110
+
+
+def test_steer_kernels_use_no_scratch():
+    """the rollout kernels must not spill to scratch memory.  hipcc cross-compiles for gfx950 here and
+    reports the private segment size of every kernel (-Rpass-analysis=kernel-resource-usage)."""
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+    if not shutil.which(kr.HIPCC) and not os.path.exists(kr.HIPCC):
+        pytest.skip("hipcc not available")
+    rows = kr.parse(kr.remarks())
+    steer = [r for r in rows if "k_steer<" in r["name"]]
+    scan = [r for r in rows if "k_nn_scan<" in r["name"]]
+    assert len(steer) >= 14 and len(scan) >= 20
+    assert all(r["scratch"] == 0 for r in steer), [(r["name"][:60], r["scratch"]) for r in steer if r["scratch"]]
+    assert all(r["scratch"] == 0 and r["lds"] == 0 for r in scan)          # the scan is fed by the scalar unit: no LDS at all

@@ -1,6 +1,6 @@
 """
-Pins the C oracle (oracle/lqrrt_oracle.c) against the fixtures generated from the unmodified
-reference.  CPU only.
+Pins the C oracle (oracle/lqrrt_oracle.c) against the fixtures generated from the reference (tie order
+stabilised for car / pendulum; the untouched reference: tests/test_teacher_cpu.py).  CPU only.
 
 Exact: iterations, sampler rows consumed, parent arrays, edge lengths, per-iteration nearest ids
 and edge lengths.  Floating point: 1e-9 absolute -- except on demo_boat_advanced, whose dynamics

@@ -1,6 +1,7 @@
 """
 GPU parity tests: the HIP path (through the C ABI) against
-  (a) the golden fixtures generated from the unmodified reference (tests/golden/), and
+  (a) the golden fixtures generated from the reference (tests/golden/; tie order stabilised for car / pendulum,
+      DESIGN 5.3), and
   (b) the NumPy oracle (oracle/) on seeded inputs.
 
 Bars: parent indices, edge lengths, iteration / RNG-consumption counts, feasibility bits and
@@ -12,10 +13,12 @@ demo_boat_advanced is the exception that needs a weaker statement: its dynamics 
 differences by orders of magnitude per step when the boat is nearly stopped with saturated
 thrusters (DESIGN.md "Conditioning"), so NO implementation with a different libm reproduces the
 reference run beyond the first such edge -- NumPy itself differs between CPUs.  For that problem
-the fixtures pin the tree up to the first chaotic divergence (parents exact for the 200-node
-fixture, >= 150 nodes of common prefix on the 3000-node one, unaffected nodes to 1e-9), and the
-bit-exact comparison against the sequential C oracle (tests/test_hip_vs_coracle.py, same
-portable libm) carries the full-size parity claim.
+the FREE-RUNNING fixtures pin the tree up to the first chaotic divergence (parents exact for the 200-node
+fixture, >= 150 nodes of common prefix on the longer ones, unaffected nodes to 1e-9); the full-size claim
+against the reference itself is teacher-forced -- every one of the 36,936 decisions of the reference's
+10k-node run replayed from the reference's own tree (tests/test_teacher_gpu.py) -- and the bit-exact
+comparison against the sequential C oracle (tests/test_hip_vs_coracle.py, same portable libm) covers the
+wave machinery.
 """
 import hashlib
 import os
@@ -91,21 +94,6 @@ def test_feasibility_golden(sys_ops):
     ok = s._engine(float(g["dt"])).feasible_batch(g["feas_x"], g["feas_u"])
     np.testing.assert_array_equal(ok, g["feas_ok"])
     assert bool(s.is_feasible(g["feas_x"][0], g["feas_u"][0])) == bool(g["feas_ok"][0])
-
-
-def test_costs_to_go_golden(sys_ops):
-    """Cost vector + arg-min against a frozen node table: grow nothing, inject nodes via steer-free path."""
-    name, s, g = sys_ops
-    # the engine only holds trees it grew itself; compare costs through erf+S on the same data instead,
-    # and the nearest-neighbour kernel through the grown-tree tests below.
-    eng = s._engine(float(g["dt"]))
-    nodes, qs = g["ctg_nodes"], g["ctg_x"]
-    for q, want in zip(qs, g["ctg_costs"]):
-        e = eng.erf_batch(np.repeat(q[None, :], len(nodes), 0), nodes)
-        S = s.Smatrix()
-        got = np.sum(np.tensordot(e, S, axes=1) * e, axis=1)
-        np.testing.assert_allclose(got, want, rtol=1e-12, atol=ATOL)
-        assert int(np.argmin(got)) == int(np.argmin(want))
 
 
 TRAJ = [("boat_intermediate", "300", 256), ("boat_novice", "300", 256), ("car", "500", 256), ("pendulum", "150", 64),

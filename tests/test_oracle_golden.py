@@ -1,6 +1,6 @@
 """
 Pins the oracle (oracle/lqrrt_oracle.py + oracle/systems_np.py) against the fixtures generated
-from the unmodified reference by tools/gen_golden.py.  CPU only.
+from the reference by tools/gen_golden.py (tie order stabilised for car / pendulum).  CPU only.
 
 Tolerances: parent arrays / nearest ids / edge lengths / iteration and RNG-consumption counts
 are compared EXACTLY.  Floating-point values are compared at 1e-9 absolute (they are bit-equal

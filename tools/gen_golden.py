@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """
-Generate the golden fixtures under tests/golden/ by importing and running the UNMODIFIED
-reference planner (jnez71/lqRRT, /root/reference) in the build container.
+Generate the golden fixtures under tests/golden/ by importing and running the reference planner
+(jnez71/lqRRT, /root/reference; no file of it is modified) in the build container.
 
 The reference itself ships no tests or golden vectors, so these
 fixtures are the parity pin for the oracle (oracle/) and, through it, for the HIP path.
@@ -11,7 +11,12 @@ Only DATA is written (inputs + expected outputs); no reference source text is st
   python tools/gen_golden.py --long     # additionally the 10k-node boat_advanced run (~20 min)
 
 Tie order: the reference's np.argsort(costs) leaves the order of exactly-equal costs
-unspecified; the fixtures pin it to "lowest node id first" (see ref_loader._StableSortNumpy).
+unspecified; the trajectory fixtures pin it to "lowest node id first" by rebinding the name `np` inside
+the reference's planner module to a proxy with a stable argsort (ref_loader._StableSortNumpy).  This
+changes the car / pendulum trees (car-500: 0c64b54cdd315792 instead of the untouched reference's
+219124599a587d8c) and nothing else; the `*_unpatched` fixtures (--job car500u, car2000u, pend150u) come
+from the reference with nothing rebound, and tests/test_teacher_cpu.py proves the two differ only between
+nodes of bit-equal cost.
 
 Determinism recipe: obstacle seed 0 before the demo's definition section,
 np.random.seed(1) right before update_plan, fake clock, xrand_gen=10, exit on max_nodes.

@@ -1,5 +1,9 @@
 """
-Load the *unmodified* reference (jnez71/lqRRT at /root/reference) in this build container.
+Load the reference (jnez71/lqRRT at /root/reference) in this build container.  No reference file is modified.  By
+default ONE name is rebound after import: `np` inside the reference's `planner` module becomes a proxy whose argsort is
+stable (_StableSortNumpy below), which only decides between nodes of bit-equal cost (tests/test_teacher_cpu.py
+test_tie_audit_unpatched_reference); TIES_STABLE = False / import_reference(stable_ties=False) leaves everything untouched
+(the `*_unpatched` fixtures).
 
 This module is test-infrastructure tooling: it only works where /root/reference exists
 (the build container) and is used by tools/gen_golden.py to produce the committed fixtures
