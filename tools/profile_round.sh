@@ -7,6 +7,7 @@
 #   5. PMC pass SQ instruction counters (own run)            -> gpurun_out/prof/sq_a.csv.json
 #   6. PMC pass SQ wait / active counters (own run)          -> gpurun_out/prof/sq_b.csv.json
 #   7. launch floor micro-benchmark                          -> gpurun_out/prof/launch_floor.txt
+#   7b. dependent-kernel boundary without events (stream / hipGraph) -> gpurun_out/prof/launch_chain.txt
 #   8. NN-scan micro-benchmark                               -> gpurun_out/prof/nn_bench.txt
 # then, back in the container: python tools/summarize_profiles.py rNN
 R=/root/repo
@@ -60,6 +61,7 @@ agg write WRITE_SIZE
 agg sq_a SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 agg sq_b SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS
 $R/tools/micro/launch_floor.bin > $O/launch_floor.txt 2>&1
+$R/tools/micro/launch_chain.bin > $O/launch_chain.txt 2>&1
 timeout 200 python $R/tools/nn_bench.py --reps 200 > $O/nn_bench.txt 2>&1
 ls -la $O
 tail -c 400 $O/bench_plain.json

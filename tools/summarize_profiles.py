@@ -61,7 +61,7 @@ def main():
     os.makedirs(out, exist_ok=True)
     shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(out, "%s_kernel_stats.csv" % rnd))
     for a, b in (("bench_plain.json", "bench.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"),
-                 ("launch_floor.txt", "launch_floor.txt"), ("nn_bench.txt", "nn_bench.txt")):
+                 ("launch_floor.txt", "launch_floor.txt"), ("launch_chain.txt", "launch_chain.txt"), ("nn_bench.txt", "nn_bench.txt")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(out, "%s_%s" % (rnd, b)))
     for f in glob.glob(os.path.join(ROOT, "gpurun_out", "teacher_*.json")):
