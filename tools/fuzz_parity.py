@@ -14,7 +14,7 @@ import numpy as np
 NAMES = ["boat_advanced", "boat_intermediate", "boat_novice", "car", "double_integrator", "ros_boat", "pendulum"]
 
 
-def draw_case(rng, rng2, names=None):
+def draw_case(rng, rng2, names=None, rng3=None):
     """One random configuration; consumes a fixed pattern of draws so that case k is reproducible (rng2 is a second
     stream for dimensions added later, so that earlier case numbers keep their meaning)."""
     import lqrrt_amd
@@ -58,6 +58,16 @@ def draw_case(rng, rng2, names=None):
             grid[max(rr - k, 0):rr + k, max(cc - k, 0):cc + k] = 0
         s.set_occupancy_grid(grid, origin, cpm=cpm, threshold=float(rng2.choice([50.0, 90.0])))
         c["ogrid"] = True
+    # round-2 dimensions on a third stream: the Riccati pendulum (per-step DARE gains, S per sample) in a share of the
+    # cases, and tree-sharded instead of sample-sharded waves for half of the multi-rank ones
+    c["shard"] = "sample"
+    if rng3 is not None:
+        if rng3.rand() < 0.08:
+            c["name"], c["system"] = "pendulum_lqr", lqrrt_amd.systems.PendulumLqr(0)
+            c["nodes"] = min(c["nodes"], 150)
+            c["adaptive"], c["horizon"], c["ogrid"] = False, c["system"].plan_kwargs["horizon"], False
+        if rng3.rand() < 0.5 and c["world"] > 1 and not c["sync"]:
+            c["shard"] = "tree"
     return c
 
 
@@ -92,10 +102,28 @@ def run_case(c, verbose=False):
         stats = eng.extend(wave, max_attempts=budget, node_limit=nodes, pruning=c["pruning"], stop_on_goal=c["stop_goal"])
     else:
         import torch
-        from lqrrt_amd.parallel import records_tensor, shard_bounds
+        from lqrrt_amd.parallel import node_range, records_tensor, shard_bounds
         ranks = [make_engine() for _ in range(world)]
         recs = [records_tensor(e) for e in ranks]
+        bufs = [torch.empty((world, wave, 2), dtype=torch.float64, device="cuda") for _ in range(world)]
         attempts = 0
+        while ranks[0].size <= nodes and attempts < budget and c.get("shard") == "tree":
+            # tree-sharded: every rank scans its node range for all samples, candidates exchanged, everybody steers
+            W = min(ranks[0].wave_suggest(wave), budget - attempts)
+            views = [b.view(-1)[: world * W * 2].view(world, W, 2) for b in bufs]
+            for r, e in enumerate(ranks):
+                lo, hi = node_range(e.size, r, world)
+                e.wave_scan_nodes(W, lo, hi, views[r][r].data_ptr())
+            torch.cuda.synchronize()
+            for r in range(world):
+                for q in range(world):
+                    if q != r:
+                        views[q][r].copy_(views[r][r])
+            torch.cuda.synchronize()
+            for r, e in enumerate(ranks):
+                e.wave_steer_candidates(W, world, views[r].data_ptr())
+            sts = [e.wave_commit(W, budget - attempts, nodes, c["pruning"]) for e in ranks]
+            attempts += sts[0].attempts
         while ranks[0].size <= nodes and attempts < budget:
             W = min(wave, budget - attempts) if c.get("sync") else ranks[0].wave_suggest(wave)
             bounds = [shard_bounds(W, r, world) for r in range(world)]
@@ -149,15 +177,15 @@ def run_case(c, verbose=False):
 
 
 def describe(c):
-    return " ".join("%s=%s" % (k, c[k]) for k in ("name", "nodes", "wave", "seed", "tries", "pruning", "stop_goal", "adaptive", "world", "ogrid", "sync")) \
+    return " ".join("%s=%s" % (k, c[k]) for k in ("name", "nodes", "wave", "seed", "tries", "pruning", "stop_goal", "adaptive", "world", "shard", "ogrid", "sync")) \
         + (" behavior=%s" % c["system"].behavior if hasattr(c["system"], "behavior") else "")
 
 
 def run(cases, seed, only=-1, wave_override=None, names=None):
-    rng, rng2 = np.random.RandomState(seed), np.random.RandomState(seed + 7919)
+    rng, rng2, rng3 = np.random.RandomState(seed), np.random.RandomState(seed + 7919), np.random.RandomState(seed + 104729)
     bad = []
     for k in range(cases):
-        c = draw_case(rng, rng2, names)
+        c = draw_case(rng, rng2, names, rng3)
         if wave_override:
             c["wave"] = int(wave_override)
         if only >= 0 and k != only:
