@@ -678,6 +678,7 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     if (!rc) rc = dalloc(&e->tv.pID, (size_t)e->cap);
     if (!rc) rc = dalloc(&e->tv.elen, (size_t)e->cap);
     if (!rc) rc = dalloc(&e->tv.ignore, (size_t)e->cap / 64 + 1);
+    if (!rc && hipMemset(e->tv.ignore, 0, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1)) != hipSuccess) rc = fail(LQRRT_E_HIP, "hipMemset failed");
     const size_t pw = (size_t)lqrrt_engine::MAXCH * e->maxW;
     if (!rc) rc = dalloc(&e->d_pcost, pw);
     if (!rc) rc = dalloc(&e->d_pidx, pw);
@@ -1030,6 +1031,8 @@ extern "C" int lqrrt_tree_load(lqrrt_engine* e, int count, const double* states,
     if (ignored)
         for (int i = 0; i < count; ++i)
             if (ignored[i]) e->h_ign[i >> 6] |= 1ull << (i & 63);
+    // the whole device bitmap, not only the words of the loaded nodes: nodes appended later must start un-ignored
+    HIPCHK(hipMemsetAsync(e->tv.ignore, 0, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1), st));
     e->ign_hi = std::max(e->ign_hi, std::max(e->N, count));
     e->ign_dirty = true;
     e->N = count;

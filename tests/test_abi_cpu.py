@@ -172,3 +172,21 @@ def test_steer_kernels_use_no_scratch():
     assert len(steer) >= 14 and len(scan) >= 20
     assert all(r["scratch"] == 0 for r in steer), [(r["name"][:60], r["scratch"]) for r in steer if r["scratch"]]
     assert all(r["scratch"] == 0 and r["lds"] == 0 for r in scan)          # the scan is fed by the scalar unit: no LDS at all
+
+
+def test_planner_call_budget_follows_the_clock():
+    """Host logic of the time budget: a native call commits at most four waves, at most what fits in half of
+    the time left at the measured rate, at least a small wave; synchronous mode only whole waves."""
+    boat = lqrrt_amd.systems.BoatAdvanced(0)
+    cons = lqrrt_amd.Constraints(6, 3, boat.goal_buffer, boat.is_feasible)
+    p = lqrrt_amd.Planner(boat.dynamics, boat.lqr, cons, error_tol=boat.error_tol, erf=boat.erf, goal0=boat.goal,
+                          printing=False, wave_size=256, **boat.plan_kwargs)
+    assert p._attempt_budget(None, 1.0) == 256                         # no rate yet: one wave
+    assert p._attempt_budget(4e5, np.inf) == 1024                      # no deadline: four waves
+    assert p._attempt_budget(4e5, 1.0) == 1024                         # plenty of time
+    assert p._attempt_budget(4e5, 1e-3) == 200                         # 0.5 * 4e5/s * 1 ms
+    assert p._attempt_budget(4e5, 0.0) == 32 and p._attempt_budget(4e5, -1.0) == 32
+    q = lqrrt_amd.Planner(boat.dynamics, boat.lqr, cons, error_tol=boat.error_tol, erf=boat.erf, goal0=boat.goal,
+                          printing=False, wave_size=256, wave_mode="synchronous", **boat.plan_kwargs)
+    assert q._attempt_budget(4e5, 1e-3) == 256 and q._attempt_budget(4e5, 2e-3) == 256 and q._attempt_budget(4e5, 1.0) == 1024
+    assert p.tree is None and p._engine is None                         # no GPU here: nothing was created, nothing raised

@@ -147,3 +147,52 @@ def test_costs_to_go_fixture_through_the_scan_kernels(golden_dir):
         np.testing.assert_array_equal(ids, np.argmin(want, axis=1))
         np.testing.assert_allclose(cost, want.min(axis=1), rtol=1e-12, atol=1e-9)
         eng.close()
+
+
+@pytest.mark.parametrize("name,tag,keep", [("boat_advanced", "3000", 1200), ("car", "2000", 700)])
+def test_warm_start_from_a_loaded_tree(golden_dir, name, tag, keep):
+    """lqrrt_tree_load as a warm start (lqrrt_node.py:389-500 keeps growing what it has): the first `keep` nodes of the
+    reference's tree, with the ignore set they had, go onto the device and into the C oracle; both then grow 400 more
+    nodes from the same sample stream and must agree bit for bit -- and so must a tree that was loaded whole and
+    truncated back to `keep` nodes (lqrrt_tree_truncate)."""
+    import coracle
+    import lqrrt_amd
+    from lqrrt_amd.engine import Engine
+    g = _load(golden_dir, "traj_%s_%s.npz" % (name, tag))
+    s = lqrrt_amd.systems.SYSTEMS[name](0)
+    sch = teacher.Schedule(g, s.goal, s.goal_buffer)
+    ign = sch.ignored_at(keep)[:keep]
+    kw = s.plan_kwargs
+    H = int(kw["horizon"] / kw["dt"])
+    wave, more = 256, 400
+
+    def engine():
+        eng = Engine(s, capacity=len(sch.state) + wave + 8, max_wave=wave)
+        eng.set_resolution(kw["dt"], kw["FPR"], H, np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer))
+        space = np.array(s.sample_space, dtype=np.float64)
+        eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), np.array(s.goal_bias, dtype=np.float64), 10)
+        st = np.random.RandomState(9).get_state()
+        eng.set_mt19937(st[1], st[2])
+        return eng
+    a = engine()
+    a.tree_load(sch.state[:keep], sch.K[:keep], sch.pID[:keep], ignored=ign)
+    b = engine()
+    b.tree_load(sch.state, sch.K, sch.pID)                     # everything, then back to the same prefix
+    b.tree_truncate(keep)
+    b.set_ignored(ign)
+    o = coracle.make(s, len(sch.state) + wave + 8, seed=9)
+    o.load_tree(sch.state[:keep], sch.K[:keep], sch.pID[:keep], ign)
+    sa = a.extend(wave, node_limit=keep + more - 1)
+    sb = b.extend(wave, node_limit=keep + more - 1)
+    o.extend(max_nodes=keep + more - 1)
+    assert a.size == b.size == o.size == keep + more
+    assert sa.attempts == sb.attempts == o.iterations
+    for e in (a, b):
+        np.testing.assert_array_equal(e.parents(), o.parents())
+        np.testing.assert_array_equal(e.states(), o.states())
+        np.testing.assert_array_equal(e.gains(), o.gains())
+        np.testing.assert_array_equal(e.edge_lengths()[keep:], o.edge_lengths()[keep:])
+        np.testing.assert_array_equal(e.ignored(), o.ignored())
+    np.testing.assert_array_equal(a.states()[:keep], sch.state[:keep])          # the loaded part is untouched
+    x, u = a.edge(5)
+    assert len(x) == 1 and np.array_equal(x[0], sch.state[5]) and not u.any()   # no edges given: the node's own state
