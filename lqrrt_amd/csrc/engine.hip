@@ -262,6 +262,10 @@ static int dalloc(T** p, size_t count) {
     *p = nullptr;
     if (count == 0) count = 1;
     HIPCHK(hipMalloc((void**)p, count * sizeof(T)));
+    // LQRRT_POISON=1 (test runs): fresh device memory is usually zero, recycled memory is not -- fill every allocation
+    // with 0xff (NaNs, set bits, negative ints) so that a read of something never written shows up at once
+    static const bool poison = getenv("LQRRT_POISON") != nullptr;
+    if (poison) HIPCHK(hipMemset(*p, 0xff, count * sizeof(T)));
     return 0;
 }
 

@@ -27,3 +27,17 @@ def test_vanishing_goal_hit_regression(wave):
     it had been steered from an in-wave parent's superseded end state."""
     import fuzz_parity
     assert not fuzz_parity.run(323, 3, only=322, wave_override=wave, names=fuzz_parity.NAMES[:6])
+
+
+def test_poisoned_allocations():
+    """LQRRT_POISON=1 fills every device allocation of the engine with 0xff: a kernel that reads something it (or the
+    host) never wrote -- harmless on a fresh process where new memory is zero, wrong when memory is recycled, as an
+    uninitialised ignore bitmap after lqrrt_tree_load once was -- fails here.  Own process: the switch is read once."""
+    import subprocess
+    env = dict(os.environ, LQRRT_POISON="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "60", "31"], capture_output=True,
+                         text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-k", "warm_start or teacher_forced",
+                          os.path.join(ROOT, "tests", "test_teacher_gpu.py")], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
