@@ -178,17 +178,32 @@ __device__ __forceinline__ bool grid_hits(const Geo& g, const GeoL& gl, double p
     }
     bool hit = false;
     const double ms = -s;
-#pragma unroll 4
-    for (int v = lane; v < g.V; v += 64) {
-        const double bx = gl.vps[v], by = gl.vps[g.V + v];
-        const double vx = px + (c * bx + ms * by);
-        const double vy = py + (s * bx + c * by);
-        long long ix = (long long)(g.og_cpm * (vx - g.og_ox));
-        long long iy = (long long)(g.og_cpm * (vy - g.og_oy));
-        if (ix < 0) ix += g.og_cols;
-        if (iy < 0) iy += g.og_rows;
-        if (ix < 0 || ix >= g.og_cols || iy < 0 || iy >= g.og_rows) hit = true;
-        else hit |= !((double)g.og[iy * g.og_cols + ix] < g.og_thr);
+    // Eight hull points per lane at a time: the cell addresses of all eight are formed first and the eight byte loads
+    // are in flight together (the map lives in L2; one dependent load per point would cost its latency 22 times for
+    // the ROS package's 1400-point hull).  Points outside the map read cell 0 and count as a hit, as before.
+    for (int v0 = lane; v0 < g.V; v0 += 8 * 64) {
+        long long cell[8];
+        bool oob[8], live[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int v = v0 + 64 * k;
+            live[k] = v < g.V;
+            const int vv = live[k] ? v : lane;
+            const double bx = gl.vps[vv], by = gl.vps[g.V + vv];
+            const double vx = px + (c * bx + ms * by);
+            const double vy = py + (s * bx + c * by);
+            long long ix = (long long)(g.og_cpm * (vx - g.og_ox));
+            long long iy = (long long)(g.og_cpm * (vy - g.og_oy));
+            if (ix < 0) ix += g.og_cols;
+            if (iy < 0) iy += g.og_rows;
+            oob[k] = ix < 0 || ix >= g.og_cols || iy < 0 || iy >= g.og_rows;
+            cell[k] = oob[k] ? 0 : iy * g.og_cols + ix;
+        }
+        signed char val[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) val[k] = g.og[cell[k]];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hit |= live[k] && (oob[k] || !((double)val[k] < g.og_thr));
     }
     return __any(hit) != 0;
 }
