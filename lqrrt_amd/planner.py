@@ -167,8 +167,8 @@ class Planner:
         rate = None                                                 # attempts per second of real time, measured
         adopted = False
 
-        # Each native call grows the tree by a few waves and returns at every goal hit.  The clock and the kill flag
-        # are looked at between calls, so a call is sized to what the time budget still allows.
+        # Each native call grows the tree by a few waves.  The clock and the kill flag are looked at between calls, so a
+        # call is sized to what the time budget still allows.
         while True:
             exit_at = min_time if self.plan_reached_goal else max_time
             budget = self._attempt_budget(rate, exit_at - time_elapsed)
@@ -176,9 +176,11 @@ class Planner:
                 missing = budget - eng.queued_samples()
                 if missing > 0:
                     eng.push_samples(np.array([np.array(xrand_gen(self), dtype=np.float64) for _ in range(missing)]))
+            # The call only has to come back AT a goal hit when that hit can end the plan (min_time already elapsed,
+            # planner.py:293); before that, hits are bookkept by the engine (lqrrt_plan_best) and reported with the call.
             t_call = time.perf_counter()
             st = eng.extend(self.wave_size, max_attempts=budget, node_limit=int(self.max_nodes),
-                            pruning=pruning, stop_on_goal=True)
+                            pruning=pruning, stop_on_goal=bool(time_elapsed >= min_time))
             dt_call = time.perf_counter() - t_call
             if st.attempts > 0 and dt_call > 0:
                 rate = st.attempts / dt_call if rate is None else 0.5 * rate + 0.5 * st.attempts / dt_call
