@@ -74,11 +74,20 @@ class ShardedWave(object):
         self.e.wave_speculate(W, lo, hi)
         full = self.rec[: per * self.world]
         send = self.rec[self.rank * per: (self.rank + 1) * per]
-        if not self.in_place:
-            send = send.clone()                     # (gloo: no aliasing of input and output)
-        # RCCL gathers IN PLACE when the input is the rank's own chunk of the output buffer: no staging copy
-        self.dist.all_gather_into_tensor(full.view(-1), send.view(-1))
+        _gather(self, full.view(-1), send.view(-1))
         return self.e.wave_commit(W, max_commit, node_limit, pruning)
+
+
+def _gather(sw, out, chunk):
+    """all_gather_into_tensor with `chunk` = this rank's own slice of `out`.  RCCL gathers IN PLACE in that case (no
+    staging copy); backends or versions that refuse aliased buffers get a clone, once and for all."""
+    if sw.in_place:
+        try:
+            sw.dist.all_gather_into_tensor(out, chunk)
+            return
+        except (RuntimeError, ValueError):
+            sw.in_place = False
+    sw.dist.all_gather_into_tensor(out, chunk.clone())
 
 
 def node_range(size, rank, world):
@@ -106,7 +115,6 @@ class TreeShardedWave(object):
         buf = self.best[:, :W, :] if W == self.max_wave else self.best.view(-1)[: self.world * W * 2].view(self.world, W, 2)
         mine = buf[self.rank]
         self.e.wave_scan_nodes(W, lo, hi, mine.data_ptr())
-        send = mine if self.in_place else mine.clone()
-        self.dist.all_gather_into_tensor(buf.view(-1), send.view(-1))      # 16 * W bytes per rank: the one collective
+        _gather(self, buf.view(-1), mine.view(-1))                          # 16 * W bytes per rank: the one collective
         self.e.wave_steer_candidates(W, self.world, buf.data_ptr())
         return self.e.wave_commit(W, max_commit, node_limit, pruning)
