@@ -61,8 +61,8 @@ def replay_c(name, g):
     return sch, teacher.summarize("c-oracle/%s" % name, sch, near, ln, xe, gap)
 
 
-@pytest.mark.parametrize("name,tag", [("boat_advanced", "3000"), ("boat_advanced", "10k"), ("car", "500"),
-                                       ("car", "2000"), ("pendulum", "150")])
+@pytest.mark.parametrize("name,tag", [("boat_advanced", "3000"), ("boat_advanced", "10k"), ("boat_intermediate", "300"),
+                                       ("boat_novice", "300"), ("car", "500"), ("car", "2000"), ("pendulum", "150")])
 def test_c_oracle_teacher_forced(golden_dir, name, tag):
     g = _load(golden_dir, name, tag)
     sch, r = replay_c(name, g)

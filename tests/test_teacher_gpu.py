@@ -107,7 +107,8 @@ def test_boat_advanced_teacher_forced(golden_dir, tag):
     assert r["gain_max_err"] < 1e-8
 
 
-@pytest.mark.parametrize("name,tag,exact", [("car", "500", True), ("car", "2000", True), ("pendulum", "150", True),
+@pytest.mark.parametrize("name,tag,exact", [("boat_intermediate", "300", True), ("boat_novice", "300", True),
+                                            ("car", "500", True), ("car", "2000", True), ("pendulum", "150", True),
                                             ("car", "2000_unpatched", False), ("pendulum", "150_unpatched", False)])
 def test_demo_teacher_forced(golden_dir, name, tag, exact):
     """Car / pendulum, both the tie-stabilised and the untouched reference (the latter: other node only on bit-equal cost)."""

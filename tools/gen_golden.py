@@ -504,6 +504,8 @@ def main():
         "car500t": lambda: run_traj("car", 500, teacher=True),
         "car2000t": lambda: run_traj("car", 2000, keep_xrand=64, teacher=True),
         "pend150t": lambda: run_traj("pendulum", 150, teacher=True),
+        "int300t": lambda: run_traj("boat_intermediate", 300, teacher=True),
+        "nov300t": lambda: run_traj("boat_novice", 300, teacher=True),
         # the reference with NOTHING patched (numpy's own argsort tie order): the tie audit
         "car500u": lambda: run_traj("car", 500, keep_xrand=64, tag="500_unpatched", teacher=True, stable_ties=False),
         "car2000u": lambda: run_traj("car", 2000, keep_xrand=64, tag="2000_unpatched", teacher=True, stable_ties=False),
