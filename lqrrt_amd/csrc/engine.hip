@@ -149,6 +149,16 @@ struct lqrrt_engine {
     int* h_summary_dev = nullptr; // device address of h_summary
     int* h_rank = nullptr;        // pinned + mapped [maxW]
     int* h_rank_dev = nullptr;
+    // fused repair rounds (kernels.hpp RoundArgs): second parity of the double-buffered wave state, control block
+    double* d_M2 = nullptr;
+    int* d_lf[2] = {nullptr, nullptr};
+    int* d_par2 = nullptr;
+    unsigned char *d_stale2 = nullptr, *d_changed2 = nullptr;
+    int* d_rctl = nullptr;        // [16]
+    int* d_rank = nullptr;        // [maxW]
+    int* h_round = nullptr;       // pinned + mapped [8 + 3*maxW]: hz, round words (2 parities), summary
+    int* h_round_dev = nullptr;
+    bool spec_fusable = false;    // the last speculative launch prepared buffer 0 of the fused rounds
     int seq = 0;                  // sequence number of the last k_decide
     bool wave_complete = false;   // the last speculate covered the whole wave (single-GPU path)
     static constexpr int MAXCH = 1024;
@@ -424,8 +434,12 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
 }
 
 static int launch_steer(lqrrt_engine* e, const double* xs, const int* list, int lo, int count,
-                        const int* par, hipStream_t st, const int* list_count = nullptr, const SteerFuse* fuse = nullptr) {
+                        const int* par, hipStream_t st, const int* list_count = nullptr, const SteerFuse* fuse = nullptr,
+                        const RoundArgs* round = nullptr) {
     if (count <= 0) return 0;
+    RoundArgs ra;
+    memset(&ra, 0, sizeof ra);
+    if (round) ra = *round;
     const size_t lds = (size_t)e->H * (e->n + e->m) * sizeof(double) + geo_lds_bytes(e);
     SteerFuse f;
     memset(&f, 0, sizeof f);
@@ -435,10 +449,10 @@ static int launch_steer(lqrrt_engine* e, const double* xs, const int* list, int 
     prof_begin(e, st, &ev, 1);
     if (f.Sd) {
         DISPATCH(e, hipExtLaunchKernelGGL((k_steer<S, true>), dim3(count), dim3(64), lds, st, ev.a, ev.b, 0, e->P, e->geo, e->res, e->tv,
-                                           e->d_rec, e->L, xs, list, lo, par, list_count, f));
+                                           e->d_rec, e->L, xs, list, lo, par, list_count, f, ra));
     } else {
         DISPATCH(e, hipExtLaunchKernelGGL((k_steer<S, false>), dim3(count), dim3(64), lds, st, ev.a, ev.b, 0, e->P, e->geo, e->res, e->tv,
-                                           e->d_rec, e->L, xs, list, lo, par, list_count, f));
+                                           e->d_rec, e->L, xs, list, lo, par, list_count, f, ra));
     }
     prof_end(e, st, &ev, 1, 0.0);
     HIPCHK(hipGetLastError());
@@ -469,12 +483,14 @@ static void free_all(lqrrt_engine* e) {
     void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_og, e->d_ogc, e->d_cell_start, e->d_cell_items, e->d_S, e->tv.state, e->tv.trig, e->tv.werr, e->tv.K, e->tv.pID, e->tv.elen,
                     e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_M,
                     e->d_pidx, e->d_par_done, e->d_par_want, e->d_list,
-                    e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_pool_trig, e->d_pool_S, e->d_QR, e->d_Sop, e->d_cand, e->d_flags};
+                    e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_pool_trig, e->d_pool_S, e->d_QR, e->d_Sop, e->d_cand, e->d_flags,
+                    e->d_M2, e->d_lf[0], e->d_lf[1], e->d_par2, e->d_stale2, e->d_changed2, e->d_rctl, e->d_rank};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_ign_pin) (void)hipHostFree(e->h_ign_pin);
     if (e->h_summary) (void)hipHostFree(e->h_summary);
     if (e->h_rank) (void)hipHostFree(e->h_rank);
+    if (e->h_round) (void)hipHostFree(e->h_round);
 }
 
 static int alloc_wave(lqrrt_engine* e) {
@@ -694,6 +710,15 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     if (!rc) rc = dalloc(&e->d_stale, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_need, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_summary, (size_t)4);
+    if (!rc) rc = dalloc(&e->d_M2, (size_t)lqrrt_engine::MATRIX_MAX_W * lqrrt_engine::MATRIX_MAX_W);
+    if (!rc) rc = dalloc(&e->d_lf[0], (size_t)2 * e->maxW);
+    if (!rc) rc = dalloc(&e->d_lf[1], (size_t)2 * e->maxW);
+    if (!rc) rc = dalloc(&e->d_par2, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_stale2, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_changed2, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_rctl, (size_t)16);
+    if (!rc) rc = dalloc(&e->d_rank, (size_t)e->maxW);
+    if (!rc && hipMemset(e->d_rctl, 0, sizeof(int) * 16) != hipSuccess) rc = fail(LQRRT_E_HIP, "hipMemset failed");
     const unsigned hflags = hipHostMallocMapped | hipHostMallocCoherent;
     if (!rc && hipHostMalloc((void**)&e->h_summary, sizeof(int) * (4 + 3 * (size_t)e->maxW), hflags) != hipSuccess)
         rc = fail(LQRRT_E_HIP, "hipHostMalloc failed");
@@ -703,6 +728,10 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
                 hipHostGetDevicePointer((void**)&e->h_rank_dev, e->h_rank, 0) != hipSuccess))
         rc = fail(LQRRT_E_HIP, "hipHostGetDevicePointer failed");
     if (!rc) memset(e->h_summary, 0, sizeof(int) * 4);
+    if (!rc && hipHostMalloc((void**)&e->h_round, sizeof(int) * (8 + 3 * (size_t)e->maxW), hflags) != hipSuccess)
+        rc = fail(LQRRT_E_HIP, "hipHostMalloc failed");
+    if (!rc && hipHostGetDevicePointer((void**)&e->h_round_dev, e->h_round, 0) != hipSuccess) rc = fail(LQRRT_E_HIP, "hipHostGetDevicePointer failed");
+    if (!rc) memset(e->h_round, 0, sizeof(int) * 8);
     if (!rc && hipHostMalloc((void**)&e->h_ign_pin, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1), hipHostMallocDefault) != hipSuccess)
         rc = fail(LQRRT_E_HIP, "hipHostMalloc failed");
     if (!rc) rc = alloc_wave(e);
@@ -1432,7 +1461,11 @@ extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void
         f.M = (e->wave_matrix && whole) ? e->d_M : nullptr; f.W = W;
         f.xtrig = xtr;
         if (e->riccati) { f.Sd = wave_sample_S(e); f.s_stride = (long long)e->n * e->n; }
+        e->spec_fusable = f.M != nullptr;
+        if (e->spec_fusable) { f.lf0 = e->d_lf[0]; f.round_ctl = e->d_rctl; }
         TRY(launch_steer(e, xs, nullptr, lo, cnt, e->d_par_done, st, nullptr, &f));
+    } else {
+        e->spec_fusable = false;
     }
     HIPCHK(hipGetLastError());
     e->wave_complete = whole;
@@ -1487,6 +1520,8 @@ extern "C" int lqrrt_wave_steer_candidates(lqrrt_engine* e, int W, int parts, co
     f.M = e->wave_matrix ? e->d_M : nullptr; f.W = W;
     f.xtrig = xtr;
     if (e->riccati) { f.Sd = wave_sample_S(e); f.s_stride = (long long)e->n * e->n; }
+    e->spec_fusable = f.M != nullptr;
+    if (e->spec_fusable) { f.lf0 = e->d_lf[0]; f.round_ctl = e->d_rctl; }
     TRY(launch_steer(e, wave_samples(e), nullptr, 0, W, e->d_par_done, st, nullptr, &f));
     e->wave_complete = true;
     e->tot.speculated += W;
@@ -1530,19 +1565,27 @@ static void tune_wave(lqrrt_engine* e, int W, const lqrrt_extend_stats& ws, int 
 
 // Waits until k_decide number e->seq has published ctrl/summary into pinned host memory.  Spinning on
 // the sequence word costs ~2 us; a hipMemcpyAsync + hipStreamSynchronize round trip costs ~25 us.
-static int wait_summary(lqrrt_engine* e, hipStream_t st) {
-    volatile int* flag = e->h_summary + 3;
+static bool fused_rounds_enabled() {
+    static const bool on = [] { const char* v = getenv("LQRRT_FUSED_ROUNDS"); return !(v && atoi(v) == 0); }();
+    return on;
+}
+static int wait_word(lqrrt_engine* e, hipStream_t st, int* word, int seq);
+static int wait_summary(lqrrt_engine* e, hipStream_t st) { return wait_word(e, st, e->h_summary + 2, e->seq); }
+// word[0] = counts, word[1] = sequence number (one aligned 64-bit store on the device side)
+static int wait_word(lqrrt_engine* e, hipStream_t st, int* word, int seq) {
+    volatile int* flag = word + 1;
+    (void)e;
     const auto t_start = std::chrono::steady_clock::now();
     for (long spin = 0;; ++spin) {
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == e->seq) return 0;
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
         if ((spin & 0xfffff) == 0xfffff) {                     // every ~1M polls: make sure the stream is still alive
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 120.0)
-                return fail(LQRRT_E_HIP, "no wave summary after 120 s (sequence %d): device hung?", e->seq);
+                return fail(LQRRT_E_HIP, "no wave summary after 120 s (sequence %d): device hung?", seq);
             hipError_t q = hipStreamQuery(st);
             if (q != hipSuccess && q != hipErrorNotReady)
                 return fail(LQRRT_E_HIP, "stream failed while waiting for the wave summary: %s", hipGetErrorString(q));
-            if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != e->seq)
-                return fail(LQRRT_E_HIP, "wave summary was not published (sequence %d)", e->seq);
+            if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
+                return fail(LQRRT_E_HIP, "wave summary was not published (sequence %d)", seq);
         }
     }
 }
@@ -1581,6 +1624,12 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     // Small waves keep an in-wave cost matrix that the steer launches maintain row by row (SteerFuse), so a repair
     // round is decide + re-steer; larger waves scan the wave records with k_nn_scan<TRI> every round.
     const bool mat = e->wave_matrix;
+    // Fused repair rounds (RoundArgs in kernels.hpp): whole waves speculated here in matrix mode; the append is the
+    // launch after the converged round, so there must be room for every sample (otherwise the legacy path reports
+    // LQRRT_E_CAPACITY before anything is written).
+    const bool fused = mat && e->wave_complete && e->spec_fusable && !e->sync_mode && fused_rounds_enabled() &&
+                       (int64_t)e->N + W <= (int64_t)e->cap;
+    e->spec_fusable = false;
     if (mat && !e->wave_complete) {
         if (e->d_S) { DISPATCH(e, hipLaunchKernelGGL((k_wave_rows<S, true>), dim3(W), dim3(64), 0, st, e->d_rec, e->L, xs, e->d_S, e->d_M, W)); }
         else { DISPATCH(e, hipLaunchKernelGGL((k_wave_rows<S, false>), dim3(W), dim3(64), 0, st, e->d_rec, e->L, xs, nullptr, e->d_M, W)); }
@@ -1593,7 +1642,46 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
 
     const int guard = 4 * W + 8;
     int rounds = 0;
-    while (!e->sync_mode) {
+    if (fused) {
+        RoundArgs ra;
+        memset(&ra, 0, sizeof ra);
+        ra.on = 1; ra.W = W; ra.base = e->N;
+        ra.max_commit = max_commit;
+        ra.room = node_limit >= 0 ? node_limit + 1 - (int64_t)e->N : -1;
+        ra.M[0] = e->d_M; ra.M[1] = e->d_M2;
+        ra.lf[0] = e->d_lf[0]; ra.lf[1] = e->d_lf[1];
+        ra.par[0] = e->d_par_done; ra.par[1] = e->d_par2;
+        ra.stale[0] = e->d_stale; ra.stale[1] = e->d_stale2;
+        ra.changed[0] = e->d_changed; ra.changed[1] = e->d_changed2;
+        ra.ctl = e->d_rctl; ra.rank = e->d_rank;
+        ra.host_ctrl = e->h_round_dev; ra.host_summary = e->h_round_dev + 8;
+        ra.fx = e->fix;
+        SteerFuse qf = rf;
+        qf.M = nullptr;
+        auto enqueue = [&](int r) -> int {
+            ra.round = r; ra.seq = ++e->seq;
+            return launch_steer(e, xs, nullptr, 0, W, nullptr, st, nullptr, &qf, &ra);
+        };
+        TRY(enqueue(0));
+        int seq_r = e->seq;
+        for (int r = 0;; ++r) {
+            // round r + 1 goes behind round r before the host has seen r's counts: if r converged it is the append
+            TRY(enqueue(r + 1));
+            const int seq_next = e->seq;
+            int* word = e->h_round + 2 + 2 * (r & 1);
+            TRY(wait_word(e, st, word, seq_r));
+            const unsigned counts = (unsigned)__atomic_load_n(&word[0], __ATOMIC_RELAXED);
+            const int n_list = (int)(counts >> 16), n_defer = (int)(counts & 0xffffu);
+            if (trace_on()) fprintf(stderr, "[wave N=%d W=%d] fused round %d: list=%d defer=%d\n", e->N, W, r, n_list, n_defer);
+            if (n_list == 0 && n_defer == 0) break;
+            if (n_list == 0) return fail(LQRRT_E_STATE, "exact-mode repair made no progress (deferred=%d)", n_defer);
+            ws.fix_rounds++;
+            ws.resteers += n_list;
+            if (++rounds > guard) return fail(LQRRT_E_STATE, "exact-mode repair did not converge");
+            seq_r = seq_next;
+        }
+    }
+    while (!e->sync_mode && !fused) {
         // one thread per sample (rounded up to whole wavefronts): a small wave does not pay 16-wavefront barriers
         const int dthreads = std::min(1024, ((W + 63) / 64) * 64);
         if (mat) {
@@ -1627,9 +1715,10 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     }
 
     // commit prefix: stop after the first goal hit, the node limit, or max_commit attempts
-    const int* len = e->h_summary + 4;
-    const int* flg = e->h_summary + 4 + W;
-    const int* par = e->h_summary + 4 + 2 * W;
+    const int* sum = fused ? e->h_round + 8 : e->h_summary + 4;
+    const int* len = sum;
+    const int* flg = sum + W;
+    const int* par = sum + 2 * W;
     int C = 0, acc = 0;
     bool hit = false;
     std::vector<int> sync_hits;
@@ -1651,7 +1740,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     for (int t = C; t < W; ++t) e->h_rank[t] = acc;
     if (e->N + acc > e->cap) return fail(LQRRT_E_CAPACITY, "tree capacity exceeded");
     const int base = e->N;
-    if (acc > 0) {
+    if (acc > 0 && !fused) {
         // ranks are read by the kernel straight from pinned host memory (written before the launch)
         DISPATCH(e, hipLaunchKernelGGL((k_append<S>), dim3(C), dim3(64), 0, st, e->tv, e->d_rec, e->L, C, base, e->h_rank_dev, e->d_par_done, e->fix));
         HIPCHK(hipGetLastError());

@@ -572,7 +572,61 @@ struct SteerFuse {
     unsigned char* changed; unsigned char* stale; int* par_out;   // wave bookkeeping initialised by the prologue
     double* M; int W;                                        // M != null: row epilogue, leading dimension W
     const double* xtrig;                                     // cos/sin of the samples' angular coordinates [..][2*NW], or null
+    int* lf0; int* round_ctl;                                // fused repair rounds: {len, flags} buffer 0, control block to clear (or null)
 };
+
+// Fused repair rounds (small waves, exact mode).  One launch of k_steer with W workgroups is one round: every
+// wavefront first makes the decision k_decide makes for ITS sample (column minimum of the in-wave cost matrix against
+// the snapshot parent, then the redo / defer rules, evaluating its in-wave parent's decision a second time instead of
+// waiting for it), re-steers if it has to, and the last wavefront to finish publishes the round's counts.  State that one
+// workgroup reads while another may be rewriting it (matrix rows, len/flags, parent-in-use, stale, changed) is
+// double-buffered by round parity: round r reads [r & 1] and writes [1 - (r & 1)], unchanged samples copy theirs.  The
+// launch that follows a converged round finds the flag set and is the append (tree.py:77-96): one kernel boundary per
+// round instead of two, none for the commit.  Same decisions as k_decide by construction; lqrrt_wave_commit chooses.
+struct RoundArgs {
+    int on, round, W, base, seq, pad;
+    long long max_commit, room;          // commit limits of lqrrt_wave_commit (room < 0: no node limit)
+    double* M[2];                        // in-wave cost matrices [W][W]
+    int* lf[2];                          // {len, flags} per sample
+    int* par[2];                         // parent in use per sample
+    unsigned char* stale[2];
+    unsigned char* changed[2];
+    int* ctl;                            // device: n_list[2], n_defer[2], ticket[2], converged[2], C, acc
+    int* rank;                           // device [W]: accepted samples before t (written at convergence)
+    int* host_ctrl;                      // pinned: as k_decide's ctrl
+    int* host_summary;                   // pinned: len, flags, parent per sample (converged round only)
+    FixedAngles fx;
+};
+enum { RC_LIST = 0, RC_DEFER = 2, RC_TICKET = 4, RC_CONV = 6, RC_C = 8, RC_ACC = 9 };
+
+// wave-cooperative: first goal hit among the current records (or W - 1)
+__device__ __forceinline__ int round_horizon(const int* __restrict__ lf, int W, int lane) {
+    int hz = W - 1;
+    for (int t = lane; t < W; t += 64) {
+        if (lf[2 * t] > 0 && (lf[2 * t + 1] & 1)) { hz = t; break; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) hz = min(hz, __shfl_xor(hz, off));
+    return hz;
+}
+
+// wave-cooperative: k_decide's phase 1 for sample t (t <= horizon): the parent it wants and whether it must be redone
+__device__ __forceinline__ void round_decide(const RoundArgs& ra, int cur, const double* __restrict__ rec, const RecLayout& L,
+                                             int t, int lane, int& want, bool& need) {
+    const double* M = ra.M[cur];
+    double wc = INFINITY;
+    int s = -1;
+    for (int c = lane; c < t; c += 64) {                      // ascending per lane, strict '<': lowest record on ties
+        const double v = M[(size_t)c * ra.W + t];
+        if (v < wc) { wc = v; s = c; }
+    }
+    lexmin_wave(wc, s);
+    const double csnap = rec[(size_t)t * L.R + L.off_cost];
+    const int psnap = (int)rec[(size_t)t * L.R + L.off_parent];
+    want = (s >= 0 && wc < csnap) ? ~s : psnap;
+    need = (want != ra.par[cur][t]) || (ra.stale[cur][t] != 0);
+    if (want < 0 && ra.changed[cur][~want]) need = true;
+}
 
 #ifdef STEER_TIMING
 __device__ unsigned long long g_steer_ts[8];
@@ -591,7 +645,9 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
                                               RecLayout L, const double* __restrict__ xs,
                                               const int* __restrict__ list, int lo,
                                               const int* __restrict__ par, const int* __restrict__ list_count,
-                                              SteerFuse f) {
+                                              SteerFuse f, RoundArgs ra) {
+    // fused rounds need the in-wave matrix, which waves of Riccati-gain systems never use (per-sample S): compiled out
+    const bool ron = has_dare_gain<S>::value ? false : ra.on != 0;
     // list mode with a device-side count: the launch is enqueued before the host knows how many samples
     // k_decide listed, so surplus workgroups simply leave (and a converged round costs one empty launch)
     if (list_count && (int)blockIdx.x + lo >= list_count[0]) return;
@@ -647,11 +703,78 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
             my[L.off_cost] = fallback ? INFINITY : b;
             my[L.off_parent] = (double)bi;
             f.par_out[t] = bi; f.changed[t] = 0; f.stale[t] = 0;
+            if (f.round_ctl && blockIdx.x == 0) {
+#pragma unroll
+                for (int q = 0; q < 10; ++q) f.round_ctl[q] = 0;
+            }
         }
         pref = bi;
+    } else if (ron) {
+        const int cur = ra.round & 1, nxt = cur ^ 1;
+        if (ra.ctl[RC_CONV + cur]) {
+            // the previous round converged: this launch is the commit.  Sample t's record becomes tree node
+            // base + rank[t] if it lies in the committed prefix (tree.py:77-96; what k_append does).
+            const int C = ra.ctl[RC_C];
+            const int len = ra.lf[cur][2 * t];
+            if (t < C && len > 0) {
+                const int id = ra.base + ra.rank[t];
+                if (lane < S::N) tv.state[(size_t)lane * tv.cap + id] = my[L.off_xend + lane];
+                if (lane < 2 * S::NW) tv.trig[(size_t)lane * tv.cap + id] = my[L.off_trig + lane];
+                if constexpr (S::NW > 0) {
+                    if (ra.fx.on && lane >= 32 && lane < 32 + S::NW) {
+                        const int kk = lane - 32;
+                        tv.werr[(size_t)kk * tv.cap + id] = wrap_err(ra.fx.t[2 * kk], ra.fx.t[2 * kk + 1], my[L.off_trig + 2 * kk], my[L.off_trig + 2 * kk + 1]);
+                    }
+                }
+                for (int q = lane; q < S::M * S::N; q += 64) tv.K[(size_t)id * S::M * S::N + q] = my[L.off_K + q];
+                if (lane == 0) {
+                    const int p = ra.par[cur][t];
+                    tv.pID[id] = p >= 0 ? p : ra.base + ra.rank[~p];
+                    tv.elen[id] = len;
+                }
+                double* xe = tv.xedge + (size_t)id * tv.H * S::N;
+                double* ue = tv.uedge + (size_t)id * tv.H * S::M;
+                for (int q = lane; q < len * S::N; q += 64) xe[q] = my[L.off_xseq + q];
+                for (int q = lane; q < len * S::M; q += 64) ue[q] = my[L.off_useq + q];
+            }
+            return;                                             // (the flag is cleared by the next wave's speculative launch)
+        }
+        // ---- this sample's decision (k_decide's rules)
+        const int hz = round_horizon(ra.lf[cur], ra.W, lane);
+        int want = ra.par[cur][t];
+        bool need = false, defer = false, mark_stale = false;
+        if (t <= hz) {
+            round_decide(ra, cur, rec, L, t, lane, want, need);
+            if (need && want < 0) {
+                // the in-wave parent's own decision, evaluated here instead of waited for: redone this round -> defer
+                int want_s; bool need_s;
+                round_decide(ra, cur, rec, L, ~want, lane, want_s, need_s);   // (~want < t <= hz)
+                defer = need_s;
+            }
+        } else if (want < 0 && ra.changed[cur][~want]) {
+            mark_stale = true;        // beyond the horizon, but its in-wave parent just moved (see k_decide)
+        }
+        const bool redo = need && !defer;
+        if (lane == 0) {
+            ra.par[nxt][t] = redo ? want : ra.par[cur][t];
+            ra.stale[nxt][t] = redo ? 0 : ((need && defer) || mark_stale ? 1 : ra.stale[cur][t]);
+            ra.changed[nxt][t] = redo ? 1 : 0;
+            if (redo) atomicAdd(&ra.ctl[RC_LIST + cur], 1);
+            else if (need) atomicAdd(&ra.ctl[RC_DEFER + cur], 1);
+        }
+        if (!redo) {
+            // nothing to recompute: this sample's row and len/flags move on unchanged
+            for (int u = t + 1 + lane; u < ra.W; u += 64) ra.M[nxt][(size_t)t * ra.W + u] = ra.M[cur][(size_t)t * ra.W + u];
+            if (lane < 2) ra.lf[nxt][2 * t + lane] = ra.lf[cur][2 * t + lane];
+            pref = 0x7fffffff;                                  // (marker: skip the rollout, go to the ticket)
+        } else {
+            pref = want;
+        }
     } else {
         pref = par[t];
     }
+    const bool round_skip = ron && pref == 0x7fffffff;
+    if (!round_skip) {
     if (pref >= 0) {
 #pragma unroll
         for (int d = 0; d < S::N; ++d) x[d] = tv.state[(size_t)d * tv.cap + pref];
@@ -782,13 +905,18 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         my[L.off_len] = (double)cnt;
         // flags: bit 0 = end state in the goal region, bit 1 = stopped by error growth,
         //        bits 8.. = number of completed steps (for the horizon_iters replay on the host)
-        my[L.off_flags] = (double)(flags | (grew ? 2 : 0) | (steps << 8));
+        const int fw = flags | (grew ? 2 : 0) | (steps << 8);
+        my[L.off_flags] = (double)fw;
+        int* lfo = ron ? ra.lf[(ra.round & 1) ^ 1] : f.lf0;
+        if (lfo) { lfo[2 * t] = cnt; lfo[2 * t + 1] = fw; }
     }
     STEER_TS(4);
-    if (f.M) {
+    double* Mout = ron ? ra.M[(ra.round & 1) ^ 1] : f.M;
+    const int Wm = ron ? ra.W : f.W;
+    if (Mout) {
         // row t of the in-wave cost matrix: cost of this record's end state for every later sample u (the
         // arithmetic of k_nn_scan<TRI>: erf about the sample, quad_cost); +inf when the record adds no node
-        for (int u = t + 1 + lane; u < f.W; u += 64) {
+        for (int u = t + 1 + lane; u < Wm; u += 64) {
             double xu[S::N], tu[2 * S::NW + 1], e[S::N];
 #pragma unroll
             for (int d = 0; d < S::N; ++d) xu[d] = xs[(size_t)u * S::N + d];
@@ -803,10 +931,74 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
                 erf_cached<S>(xu, tu, x, trig, e);
                 c = quad_cost<S, DENSE>(e, f.Sd);
             }
-            f.M[(size_t)t * f.W + u] = c;
+            Mout[(size_t)t * Wm + u] = c;
         }
     }
     STEER_TS(5);
+    }   // !round_skip
+    if (!ron) return;
+    // ---- end of a fused round: the last wavefront to get here closes it
+    {
+        const int cur = ra.round & 1, nxt = cur ^ 1;
+        __threadfence();                                        // this workgroup's writes, before its ticket
+        int ticket = 0;
+        if (lane == 0) ticket = atomicAdd(&ra.ctl[RC_TICKET + cur], 1);
+        ticket = __shfl(ticket, 0);
+        if (ticket != ra.W - 1) return;
+        __threadfence();                                        // everybody else's writes, after the last ticket
+        const int n_list = __hip_atomic_load(&ra.ctl[RC_LIST + cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int n_defer = __hip_atomic_load(&ra.ctl[RC_DEFER + cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool converged = n_list == 0 && n_defer == 0;
+        if (converged) {
+            // commit rules of lqrrt_wave_commit (planner.py:311 node limit, :270 the wave ends at a goal hit), on the
+            // final records: accepted-before counts, committed prefix C
+            const int* lfn = ra.lf[nxt];
+            int before = 0, first_hit = ra.W, t_room = ra.W, total = 0;
+            for (int c0 = 0; c0 < ra.W; c0 += 64) {
+                const int tt = c0 + lane;
+                const bool in = tt < ra.W;
+                const int len = in ? lfn[2 * tt] : 0, flg = in ? lfn[2 * tt + 1] : 0;
+                const bool a = len > 0;
+                const unsigned long long A = __ballot(a);
+                const int mine = before + __popcll(A & ((1ull << lane) - 1ull));      // accepted before sample tt
+                if (in) {
+                    ra.rank[tt] = mine;
+                    ra.host_summary[tt] = len; ra.host_summary[ra.W + tt] = flg; ra.host_summary[2 * ra.W + tt] = ra.par[nxt][tt];
+                    if (a && (flg & 1)) first_hit = min(first_hit, tt);
+                    if (ra.room >= 0 && (long long)mine >= ra.room) t_room = min(t_room, tt);
+                }
+                before += __popcll(A);
+            }
+            total = before;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                first_hit = min(first_hit, __shfl_xor(first_hit, off));
+                t_room = min(t_room, __shfl_xor(t_room, off));
+            }
+            long long Cl = ra.W;
+            if (ra.max_commit < Cl) Cl = ra.max_commit;
+            if (t_room < Cl) Cl = t_room;
+            if (first_hit + 1 < Cl) Cl = first_hit + 1;
+            const int C = (int)(Cl < 0 ? 0 : Cl);
+            // ranks of samples at or beyond C are never used by the append (parents point backwards)
+            (void)total;
+            if (lane == 0) {
+                ra.ctl[RC_C] = C;
+                ra.ctl[RC_CONV + nxt] = 1;
+                ra.host_ctrl[0] = first_hit < ra.W ? first_hit : ra.W - 1;
+            }
+        }
+        if (lane == 0) {
+            ra.ctl[RC_LIST + cur] = 0; ra.ctl[RC_DEFER + cur] = 0; ra.ctl[RC_TICKET + cur] = 0;     // for round + 2
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (lane == 0) {
+            if (converged) { __threadfence_system(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            const unsigned long long word = ((unsigned long long)(unsigned)ra.seq << 32) | (unsigned)((n_list << 16) | (n_defer & 0xffff));
+            __hip_atomic_store((unsigned long long*)(ra.host_ctrl + 2 + 2 * cur), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // Rows of the in-wave cost matrix straight from the records (sharded waves: records of other ranks arrive by

@@ -41,3 +41,15 @@ def test_poisoned_allocations():
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-k", "warm_start or teacher_forced",
                           os.path.join(ROOT, "tests", "test_teacher_gpu.py")], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_legacy_repair_rounds_still_match():
+    """Whole waves of <= 256 samples repair themselves with fused rounds (RoundArgs, kernels.hpp: decision, re-steer and
+    append in one launch per round).  LQRRT_FUSED_ROUNDS=0 selects the k_decide + re-steer + k_append sequence that
+    sharded waves, larger waves and Riccati systems still use; it has to give the same trees.  Own process: the switch
+    is read once."""
+    import subprocess
+    env = dict(os.environ, LQRRT_FUSED_ROUNDS="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "60", "41"], capture_output=True,
+                         text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
