@@ -440,7 +440,8 @@ static int launch_steer(lqrrt_engine* e, const double* xs, const int* list, int 
     RoundArgs ra;
     memset(&ra, 0, sizeof ra);
     if (round) ra = *round;
-    const size_t lds = (size_t)e->H * (e->n + e->m) * sizeof(double) + geo_lds_bytes(e);
+    // (+ cos/sin of every recorded state: the two-wavefront rollout of the boats keeps them with the history)
+    const size_t lds = (size_t)e->H * (e->n + e->m + 2) * sizeof(double) + geo_lds_bytes(e);
     SteerFuse f;
     memset(&f, 0, sizeof f);
     if (fuse) f = *fuse;
@@ -448,10 +449,10 @@ static int launch_steer(lqrrt_engine* e, const double* xs, const int* list, int 
     EvPair ev;
     prof_begin(e, st, &ev, 1);
     if (f.Sd) {
-        DISPATCH(e, hipExtLaunchKernelGGL((k_steer<S, true>), dim3(count), dim3(64), lds, st, ev.a, ev.b, 0, e->P, e->geo, e->res, e->tv,
+        DISPATCH(e, hipExtLaunchKernelGGL((k_steer<S, true>), dim3(count), dim3(steer_threads<S>()), lds, st, ev.a, ev.b, 0, e->P, e->geo, e->res, e->tv,
                                            e->d_rec, e->L, xs, list, lo, par, list_count, f, ra));
     } else {
-        DISPATCH(e, hipExtLaunchKernelGGL((k_steer<S, false>), dim3(count), dim3(64), lds, st, ev.a, ev.b, 0, e->P, e->geo, e->res, e->tv,
+        DISPATCH(e, hipExtLaunchKernelGGL((k_steer<S, false>), dim3(count), dim3(steer_threads<S>()), lds, st, ev.a, ev.b, 0, e->P, e->geo, e->res, e->tv,
                                            e->d_rec, e->L, xs, list, lo, par, list_count, f, ra));
     }
     prof_end(e, st, &ev, 1, 0.0);

@@ -628,12 +628,33 @@ __device__ __forceinline__ void round_decide(const RoundArgs& ra, int cur, const
     if (want < 0 && ra.changed[cur][~want]) need = true;
 }
 
+// Two wavefronts per rollout for the boats with the heading torque (S::PACKED; pieces in systems.hpp "duo_"):
+//   main wavefront (0)              helper wavefront (1)
+//   prologue (nearest / decision)   stages parameters, tolerances and geometry into LDS
+//   ---------------------------- barrier S ----------------------------------------------
+//   step k, phase 1: erf, K e,      reads packet k-1 (state x_k, its trig, e and u of the step that produced it);
+//     trig and gain of x_k+1          the heading-torque chain atan2 -> sincos -> atan2 on x_k  -> rud
+//   ---------------------------- barrier Y_k ------------------------------------------------
+//   phase 2: + rud, thrusters,      checks packet k-1 exactly like the sequential loop: feasibility, error growth,
+//     integration -> packet k         convergence, horizon; records it in the edge history or raises `stop`
+//   ---------------------------- barrier X_k+1: both read `stop` ---------------------------
+// The main wavefront runs one step ahead of the verdict; it applies the convergence / horizon test itself (`fin`) so that
+// the common ending does not cost a thrown-away step, only the helper's last check.  A barrier
+// hand-off costs ~50 ns (tools/micro/barrier.hip), a step ~800 instructions of ~2.6 ns: 2.1 -> ~1.3 us per step.
+template <class S> constexpr int steer_threads() { return is_packed<S>::value ? 128 : 64; }
+struct DuoLds {
+    double pk[2 * MAXN + 4 + MAXM];      // xn | trn | e | u   of the newest step
+    double rud;
+    int go, stop, cnt, steps, grew, truncated;
+    int fin;                             // the newest step ends the edge by convergence or horizon if it is feasible at all
+};
+
 #ifdef STEER_TIMING
 __device__ unsigned long long g_steer_ts[8];
 #define STEER_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_steer_ts[i] = wall_clock64(); } while (0)
 __device__ unsigned long long g_step_acc[8];        // per-phase ticks of the rollout loop of block 0, + step count
 #define STEP_TS(v) const unsigned long long v = wall_clock64()
-#define STEP_ACC(i, a, b) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_step_acc[i] += (b) - (a); } while (0)
+#define STEP_ACC(i, a, b) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_step_acc[i] += (b) - (a); } while (0)
 #else
 #define STEER_TS(i) do {} while (0)
 #define STEP_TS(v) do {} while (0)
@@ -641,7 +662,7 @@ __device__ unsigned long long g_step_acc[8];        // per-phase ticks of the ro
 #endif
 
 template <class S, int DENSE>
-__global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView tv, double* __restrict__ rec,
+__global__ __launch_bounds__(steer_threads<S>()) void k_steer(Params P, Geo g, Res r, TreeView tv, double* __restrict__ rec,
                                               RecLayout L, const double* __restrict__ xs,
                                               const int* __restrict__ list, int lo,
                                               const int* __restrict__ par, const int* __restrict__ list_count,
@@ -652,14 +673,86 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
     // k_decide listed, so surplus workgroups simply leave (and a converged round costs one empty launch)
     if (list_count && (int)blockIdx.x + lo >= list_count[0]) return;
     STEER_TS(0);
+    constexpr bool DUO = is_packed<S>::value;
     extern __shared__ double hist[];
     double* hx = hist;
     double* hu = hist + (size_t)r.H * S::N;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     __shared__ double Pl[MAXP];
     __shared__ double tol_l[MAXN], glo_l[MAXN], ghi_l[MAXN];
     __shared__ double node_l[MAXN + 4 + MAXM * MAXN];        // the new node on its way out: xend | trig | K
     __shared__ GainLds<S> gl_lds;                            // work space of a Riccati gain (empty for analytic gains)
+    __shared__ DuoLds duo;
+    double* htr = hist + (size_t)r.H * (S::N + S::M) + geo_lds_doubles(g);   // DUO: cos/sin of every recorded state
+    if constexpr (DUO) {
+        if (threadIdx.x >= 64) {
+            // ---------------- helper wavefront
+            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
+            for (int i = lane; i < MAXP; i += 64) Pl[i] = P.p[i];
+            if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
+            const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
+            __syncthreads();                                                // S
+            if (!duo.go) return;
+            double tolr[S::N], last[S::N];
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) { tolr[d] = tol_l[d]; last[d] = INFINITY; }           // planner.py:377
+            int cnt = 0, steps = 0;
+            for (int k = 0;; ++k) {
+                double xn[S::N], trn[2], e[S::N], u[S::M];
+                STEP_TS(hs0);
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) { xn[d] = duo.pk[d]; e[d] = duo.pk[S::N + 2 + d]; }
+                trn[0] = duo.pk[S::N]; trn[1] = duo.pk[S::N + 1];
+#pragma unroll
+                for (int j = 0; j < S::M; ++j) u[j] = duo.pk[2 * S::N + 2 + j];
+                if (!duo.fin) duo.rud = S::duo_chain(Pl, xn, trn);
+                STEP_TS(hs1);
+                __syncthreads();                                            // Y_k
+                STEP_TS(hs2);
+                if (k >= 1) {
+                    // the sequential loop's tests on the step that produced xn (planner.py:393-433)
+                    bool stop = false;
+                    const bool feas_ok = uniform_true(S::feasible(Pl, g, gl, xn, u, trn, lane));
+                    if (!feas_ok) {                                         // planner.py:393-396
+                        cnt = (int)(r.FPR * (double)cnt);
+                        duo.truncated = 1;
+                        stop = true;
+                    } else {
+                        ++steps;                                            // planner.py:414
+                        if (r.adaptive) {                                   // planner.py:418-425
+                            bool all_grew = true;
+#pragma unroll
+                            for (int d = 0; d < S::N; ++d) all_grew = all_grew && (fabs(e[d]) >= last[d]);
+                            if (uniform_true(all_grew)) { cnt = 0; duo.grew = 1; stop = true; }
+#pragma unroll
+                            for (int d = 0; d < S::N; ++d) last[d] = fabs(e[d]);
+                        }
+                        if (!stop) {
+                            bool conv = true;
+#pragma unroll
+                            for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= tolr[d]);
+                            if (steps > r.H || uniform_true(conv)) {        // planner.py:428
+                                stop = true;
+                            } else {                                        // record (planner.py:432-433)
+#pragma unroll
+                                for (int d = 0; d < S::N; ++d) hx[cnt * S::N + d] = xn[d];
+#pragma unroll
+                                for (int j = 0; j < S::M; ++j) hu[cnt * S::M + j] = u[j];
+                                htr[2 * cnt] = trn[0]; htr[2 * cnt + 1] = trn[1];
+                                ++cnt;
+                            }
+                        }
+                    }
+                    if (stop) { duo.cnt = cnt; duo.steps = steps; duo.stop = 1; }
+                }
+                STEP_TS(hs3);
+                __syncthreads();                                            // X_k+1
+                STEP_TS(hs4);
+                STEP_ACC(0, hs0, hs1); STEP_ACC(1, hs1, hs2); STEP_ACC(2, hs2, hs3); STEP_ACC(4, hs3, hs4); STEP_ACC(3, hs0, hs0 + 1);
+                if (duo.stop) return;
+            }
+        }
+    }
     const int t = list ? list[blockIdx.x + (list_count ? lo : 0)] : lo + (int)blockIdx.x;
     double* my = rec + (size_t)t * L.R;
 
@@ -774,6 +867,9 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         pref = par[t];
     }
     const bool round_skip = ron && pref == 0x7fffffff;
+    if constexpr (DUO) {
+        if (round_skip) { duo.go = 0; __syncthreads(); }         // S: the helper leaves
+    }
     if (!round_skip) {
     if (pref >= 0) {
 #pragma unroll
@@ -793,6 +889,49 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
     }
 
     STEER_TS(1);
+    int cnt = 0, steps = 0;
+    bool grew = false, truncated = false;
+    if constexpr (DUO) {
+        // main wavefront of a two-wavefront rollout (scheme above DuoLds); the helper has staged the LDS tables meanwhile
+        duo.go = 1; duo.stop = 0; duo.cnt = 0; duo.steps = 0; duo.grew = 0; duo.truncated = 0; duo.fin = 0;
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) duo.pk[d] = x[d];
+        duo.pk[S::N] = trig[0]; duo.pk[S::N + 1] = trig[1];
+        __syncthreads();                                             // S
+        double tolr[S::N];
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) tolr[d] = tol_l[d];
+        bool live = true;
+        for (int k = 0;; ++k) {
+            double e[S::N], u[S::M], xn[S::N], trn[2], Kn[S::M * S::N];
+            if (live) {
+                S::duo_effort(xt, ttrig, x, trig, K, r.dt, e, u, trn);            // planner.py:386-387
+                S::gain(Pl, x, trn, u, Kn);                                        // planner.py:436 (these gains read the heading only)
+            }
+            __syncthreads();                                         // Y_k: the heading torque of this step is there
+            if (live) {
+                const double rud = duo.rud;
+                S::duo_finish(Pl, x, trig, u, rud, r.dt, xn);                     // planner.py:390
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) { duo.pk[d] = xn[d]; duo.pk[S::N + 2 + d] = e[d]; x[d] = xn[d]; }
+                duo.pk[S::N] = trn[0]; duo.pk[S::N + 1] = trn[1];
+                trig[0] = trn[0]; trig[1] = trn[1];
+#pragma unroll
+                for (int j = 0; j < S::M; ++j) duo.pk[2 * S::N + 2 + j] = u[j];
+#pragma unroll
+                for (int j = 0; j < S::M * S::N; ++j) K[j] = Kn[j];
+                // planner.py:428 as the helper will apply it to this step if every step so far is feasible: steps = k + 1
+                bool conv = true;
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= tolr[d]);
+                if (k + 1 > r.H || uniform_true(conv)) { duo.fin = 1; live = false; }
+            }
+            __syncthreads();                                         // X_k+1: the verdict on step k-1 is there
+            if (duo.stop) break;
+        }
+        cnt = duo.cnt; steps = duo.steps; grew = duo.grew != 0;
+        truncated = true;                                            // x / trig / K ran ahead: the node comes from the history
+    } else {
     // Model constants and tolerances are read every step: keep them in LDS (broadcast reads into VGPRs)
     // rather than in SGPRs, where ~100 live doubles spill through v_writelane/v_readlane and every
     // reload is a dependent scalar-cache round trip on the critical path of the rollout.  Staged AFTER the
@@ -802,8 +941,6 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
     const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
     __syncthreads();
     STEER_TS(2);
-    int cnt = 0, steps = 0;
-    bool grew = false, truncated = false;
     double tolr[S::N];                                           // loop-invariant: keep the tolerances out of the per-step LDS traffic
 #pragma unroll
     for (int d = 0; d < S::N; ++d) tolr[d] = tol_l[d];
@@ -866,6 +1003,7 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
         STEP_TS(ts3);
         STEP_ACC(2, ts2, ts3); STEP_ACC(3, ts0, ts0 + 1);
     }
+    }   // single-wavefront rollout
     STEER_TS(3);
     __syncthreads();
 
@@ -880,7 +1018,8 @@ __global__ __launch_bounds__(64) void k_steer(Params P, Geo g, Res r, TreeView t
             for (int d = 0; d < S::N; ++d) x[d] = hx[(cnt - 1) * S::N + d];
 #pragma unroll
             for (int j = 0; j < S::M; ++j) ul[j] = hu[(cnt - 1) * S::M + j];
-            trig_of<S>(x, trig);
+            if constexpr (DUO) { trig[0] = htr[2 * (cnt - 1)]; trig[1] = htr[2 * (cnt - 1) + 1]; }     // recorded with the state
+            else trig_of<S>(x, trig);
             system_gain<S>(Pl, x, trig, ul, r.dt, gl_lds, lane, K);   // planner.py:257: lqr(xnew, u_last)
         }
         bool in = true;                                          // planner.py:442-447 (strict)

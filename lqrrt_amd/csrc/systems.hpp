@@ -324,6 +324,35 @@ struct BoatCommon {
         }
     }
 
+    // ---- Two-wavefront rollout (k_steer, DUO): step_packed cut into pieces that run on two SIMDs at once.  A rollout
+    // owns its SIMD alone, where every instruction costs an issue slot of ~3 ns whatever it is
+    // (tools/micro/issue.hip), so a step is as long as its instruction count -- unless a second wavefront takes a share.
+    // Each piece performs exactly the arithmetic of the sequential code on the same arguments: bits unchanged.
+    // Main wavefront, while the helper works on the heading torque: erf (planner.py:386), u = K e (:387) and the
+    // cos/sin of the next heading (h' = h + vh dt only needs the old state).
+    __device__ static void duo_effort(const double* xt, const double* ttrig, const double* x, const double* trig,
+                                      const double* K, double dt, double* e, double* u, double* trn) {
+        const double c = trig[0], s = trig[1];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) e[d] = xt[d] - x[d];
+        e[2] = lq_atan2(ttrig[1] * c - ttrig[0] * s, ttrig[0] * c + ttrig[1] * s);     // wrap_err(target, x)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double a = K[i * 6] * e[0];
+#pragma unroll
+            for (int j = 1; j < 6; ++j) a += K[i * 6 + j] * e[j];
+            u[i] = a;
+        }
+        lq_sincos(x[2] + x[5] * dt, &trn[1], &trn[0]);           // euler(): xn[2] = x[2] + xdot[2]*dt, xdot[2] = x[5]
+    }
+    // Helper wavefront: gain * heading error of the direction (yb, xb) -- atan2, sincos, atan2 in a row
+    __device__ static double duo_rudder(double gainv, double yb, double xb, double c, double s) {
+        const double ang = lq_atan2(yb, xb);
+        double cg, sg;
+        lq_sincos(ang, &sg, &cg);
+        return gainv * wrap_err(cg, sg, c, s);
+    }
+
     // xdot = [R v ; invM*(u - D*v)], xnext = x + xdot*dt  (demo_boat_advanced.py:114-117)
     __device__ static void euler(const double* invM, const double* Dpos, const double* Dneg,
                                  const double* x, double c, double s, const double* u, double dt, double* xn) {
@@ -370,6 +399,16 @@ struct BoatAdvanced : BoatCommon {
         const double vw1 = s * x[3] + c * x[4];
         double rud;
         packed_erf_effort(P[37], xt, ttrig, x, trig, K, dt, lane, vw1, vw0, e, u, rud, trn);
+        double uc[3] = {u[0], u[1], u[2] + rud};
+        thrust_and_integrate(P, x, trig, uc, dt, xn);
+    }
+    __device__ static double duo_chain(const double* P, const double* x, const double* trig) {
+        const double c = trig[0], s = trig[1];
+        const double vw0 = c * x[3] + (-s) * x[4];
+        const double vw1 = s * x[3] + c * x[4];
+        return duo_rudder(P[37], vw1, vw0, c, s);
+    }
+    __device__ static void duo_finish(const double* P, const double* x, const double* trig, const double* u, double rud, double dt, double* xn) {
         double uc[3] = {u[0], u[1], u[2] + rud};
         thrust_and_integrate(P, x, trig, uc, dt, xn);
     }
@@ -425,6 +464,16 @@ struct BoatIntermediate : BoatCommon {
         const double vw1 = s * x[3] + c * x[4];
         double rud;
         packed_erf_effort(P[12], xt, ttrig, x, trig, K, dt, lane, vw1, vw0, e, u, rud, trn);
+        double uc[3] = {u[0], u[1], u[2] + rud};
+        saturate_and_integrate(P, x, trig, uc, dt, xn);
+    }
+    __device__ static double duo_chain(const double* P, const double* x, const double* trig) {
+        const double c = trig[0], s = trig[1];
+        const double vw0 = c * x[3] + (-s) * x[4];
+        const double vw1 = s * x[3] + c * x[4];
+        return duo_rudder(P[12], vw1, vw0, c, s);
+    }
+    __device__ static void duo_finish(const double* P, const double* x, const double* trig, const double* u, double rud, double dt, double* xn) {
         double uc[3] = {u[0], u[1], u[2] + rud};
         saturate_and_integrate(P, x, trig, uc, dt, xn);
     }
@@ -515,6 +564,19 @@ struct RosBoat : BoatCommon {
         double rud;
         packed_erf_effort(P[37], xt, ttrig, x, trig, K, dt, lane, yb, xb, e, u, rud, trn);
         double uc[3] = {u[0], u[1], rud};           // both behaviours REPLACE the yaw effort (boat.py:42, car.py:43)
+        thrust_and_integrate(P, x, trig, uc, dt, xn);
+    }
+    __device__ static double duo_chain(const double* P, const double* x, const double* trig) {
+        const int rmode = (int)P[38];
+        if (rmode == 0) return 0.0;                 // no heading term
+        const double c = trig[0], s = trig[1];
+        double yb, xb;
+        if (rmode == 1) { yb = P[40] - x[1]; xb = P[39] - x[0]; }
+        else { xb = c * x[3] + (-s) * x[4]; yb = s * x[3] + c * x[4]; }
+        return duo_rudder(P[37], yb, xb, c, s);
+    }
+    __device__ static void duo_finish(const double* P, const double* x, const double* trig, const double* u, double rud, double dt, double* xn) {
+        double uc[3] = {u[0], u[1], (int)P[38] == 0 ? u[2] : rud};
         thrust_and_integrate(P, x, trig, uc, dt, xn);
     }
     __device__ static void thrust_and_integrate(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
