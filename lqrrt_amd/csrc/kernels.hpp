@@ -903,11 +903,11 @@ __global__ __launch_bounds__(steer_threads<S>()) void k_steer(Params P, Geo g, R
         for (int d = 0; d < S::N; ++d) tolr[d] = tol_l[d];
         bool live = true;
         for (int k = 0;; ++k) {
-            double e[S::N], u[S::M], xn[S::N], trn[2], Kn[S::M * S::N];
+            double e[S::N], u[S::M], xn[S::N], trn[2];
             if (live) {
                 S::duo_effort(xt, ttrig, x, trig, K, r.dt, e, u, trn);            // planner.py:386-387
-                S::gain(Pl, x, trn, u, Kn);                                        // planner.py:436 (these gains read the heading only)
-            }
+                S::gain(Pl, x, trn, u, K);                                         // planner.py:436 (these gains read the heading only;
+            }                                                                      //  K is not needed again in this step)
             __syncthreads();                                         // Y_k: the heading torque of this step is there
             if (live) {
                 const double rud = duo.rud;
@@ -918,8 +918,6 @@ __global__ __launch_bounds__(steer_threads<S>()) void k_steer(Params P, Geo g, R
                 trig[0] = trn[0]; trig[1] = trn[1];
 #pragma unroll
                 for (int j = 0; j < S::M; ++j) duo.pk[2 * S::N + 2 + j] = u[j];
-#pragma unroll
-                for (int j = 0; j < S::M * S::N; ++j) K[j] = Kn[j];
                 // planner.py:428 as the helper will apply it to this step if every step so far is feasible: steps = k + 1
                 bool conv = true;
 #pragma unroll

@@ -65,3 +65,6 @@ $R/tools/micro/launch_chain.bin > $O/launch_chain.txt 2>&1
 timeout 200 python $R/tools/nn_bench.py --reps 200 > $O/nn_bench.txt 2>&1
 ls -la $O
 tail -c 400 $O/bench_plain.json
+# 9. what an instruction costs when a wavefront has a SIMD to itself; cost of a workgroup barrier hand-off
+$R/tools/micro/issue.bin > $O/issue.txt 2>&1
+$R/tools/micro/barrier.bin > $O/barrier.txt 2>&1

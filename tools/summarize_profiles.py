@@ -11,6 +11,8 @@ committed summaries under profiles/:
   profiles/rNN_decide_pmc.json       the same for k_decide
   profiles/rNN_launch_floor.txt      duration an EMPTY kernel shows under the same dispatch-attached events
   profiles/rNN_nn_bench.txt          NN-scan micro-benchmark (tools/nn_bench.py)
+  profiles/rNN_issue.txt             what one instruction costs a wavefront that has a SIMD to itself (tools/micro/issue.hip)
+  profiles/rNN_barrier.txt           workgroup barrier / LDS hand-off between wavefronts (tools/micro/barrier.hip)
   profiles/rNN_teacher_*.json        teacher-forced parity results written by tests/test_teacher_gpu.py on the GPU box
 
 Units.  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x
@@ -61,7 +63,8 @@ def main():
     os.makedirs(out, exist_ok=True)
     shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(out, "%s_kernel_stats.csv" % rnd))
     for a, b in (("bench_plain.json", "bench.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"),
-                 ("launch_floor.txt", "launch_floor.txt"), ("launch_chain.txt", "launch_chain.txt"), ("nn_bench.txt", "nn_bench.txt")):
+                 ("launch_floor.txt", "launch_floor.txt"), ("launch_chain.txt", "launch_chain.txt"), ("nn_bench.txt", "nn_bench.txt"),
+                 ("issue.txt", "issue.txt"), ("barrier.txt", "barrier.txt")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(out, "%s_%s" % (rnd, b)))
     for f in glob.glob(os.path.join(ROOT, "gpurun_out", "teacher_*.json")):
