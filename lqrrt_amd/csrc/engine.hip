@@ -433,6 +433,36 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     return 0;
 }
 
+// Wavefronts per rollout (kernels.hpp, DuoLds): the boats with the heading torque use three while every wavefront of the
+// launch can have a SIMD of its own (1024 SIMDs), two beyond that; other systems use one.
+template <class S> static int steer_wavefronts(int count) {
+    if (steer_wavefronts_max<S>() == 1) return 1;
+    static const int forced = getenv("LQRRT_STEER_WAVEFRONTS") ? atoi(getenv("LQRRT_STEER_WAVEFRONTS")) : 0;
+    if (forced == 2 || forced == 3) return forced;
+    return 3 * count <= 1024 ? 3 : 2;
+}
+template <class S, bool DENSE, int NWF>
+static void launch_steer_nwf(lqrrt_engine* e, int count, size_t lds, hipStream_t st, const EvPair& ev, const double* xs, const int* list,
+                             int lo, const int* par, const int* list_count, const SteerFuse& f, const RoundArgs& ra) {
+    hipExtLaunchKernelGGL((k_steer<S, DENSE, NWF>), dim3(count), dim3(64 * NWF), lds, st, ev.a, ev.b, 0, e->P, e->geo, e->res, e->tv,
+                          e->d_rec, e->L, xs, list, lo, par, list_count, f, ra);
+}
+template <class S>
+static void launch_steer_kernel(lqrrt_engine* e, int count, size_t lds, hipStream_t st, const EvPair& ev, const double* xs, const int* list,
+                                int lo, const int* par, const int* list_count, const SteerFuse& f, const RoundArgs& ra) {
+    const int nwf = steer_wavefronts<S>(count);
+    if constexpr (steer_wavefronts_max<S>() == 1) {
+        if (f.Sd) launch_steer_nwf<S, true, 1>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
+        else launch_steer_nwf<S, false, 1>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
+    } else if (nwf == 3) {
+        if (f.Sd) launch_steer_nwf<S, true, 3>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
+        else launch_steer_nwf<S, false, 3>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
+    } else {
+        if (f.Sd) launch_steer_nwf<S, true, 2>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
+        else launch_steer_nwf<S, false, 2>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
+    }
+}
+
 static int launch_steer(lqrrt_engine* e, const double* xs, const int* list, int lo, int count,
                         const int* par, hipStream_t st, const int* list_count = nullptr, const SteerFuse* fuse = nullptr,
                         const RoundArgs* round = nullptr) {
@@ -448,13 +478,7 @@ static int launch_steer(lqrrt_engine* e, const double* xs, const int* list, int 
     if (!f.Sd) { f.Sd = e->d_S; f.s_stride = 0; }
     EvPair ev;
     prof_begin(e, st, &ev, 1);
-    if (f.Sd) {
-        DISPATCH(e, hipExtLaunchKernelGGL((k_steer<S, true>), dim3(count), dim3(steer_threads<S>()), lds, st, ev.a, ev.b, 0, e->P, e->geo, e->res, e->tv,
-                                           e->d_rec, e->L, xs, list, lo, par, list_count, f, ra));
-    } else {
-        DISPATCH(e, hipExtLaunchKernelGGL((k_steer<S, false>), dim3(count), dim3(steer_threads<S>()), lds, st, ev.a, ev.b, 0, e->P, e->geo, e->res, e->tv,
-                                           e->d_rec, e->L, xs, list, lo, par, list_count, f, ra));
-    }
+    DISPATCH(e, (launch_steer_kernel<S>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra)));
     prof_end(e, st, &ev, 1, 0.0);
     HIPCHK(hipGetLastError());
     return 0;

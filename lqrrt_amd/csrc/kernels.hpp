@@ -641,13 +641,66 @@ __device__ __forceinline__ void round_decide(const RoundArgs& ra, int cur, const
 // The main wavefront runs one step ahead of the verdict; it applies the convergence / horizon test itself (`fin`) so that
 // the common ending does not cost a thrown-away step, only the helper's last check.  A barrier
 // hand-off costs ~50 ns (tools/micro/barrier.hip), a step ~800 instructions of ~2.6 ns: 2.1 -> ~1.3 us per step.
-template <class S> constexpr int steer_threads() { return is_packed<S>::value ? 128 : 64; }
+// With three wavefronts (NWF = 3, used while every wavefront of the launch can have a SIMD of its own: two wavefronts on one
+// SIMD slow each other down by ~40 %) the helper's two jobs are separated and the checker also takes the cos/sin of the
+// next heading and the gain off the main wavefront:
+//   main (0): erf, K e | + rud, thrusters, integration      torque (1): the chain | -
+//   checker (2): the tests on step k-1 | cos/sin of heading k+1 and K_k+1 (they only need x_k), handed over in tr / Kb
+template <class S> constexpr int steer_wavefronts_max() { return is_packed<S>::value ? 3 : 1; }
 struct DuoLds {
     double pk[2 * MAXN + 4 + MAXM];      // xn | trn | e | u   of the newest step
     double rud;
     int go, stop, cnt, steps, grew, truncated;
     int fin;                             // the newest step ends the edge by convergence or horizon if it is feasible at all
+    double tr[2][2];                     // NWF = 3: cos/sin of heading k in tr[k & 1]
+    double Kb[2][MAXM * MAXN];           // NWF = 3: gain K_k in Kb[k & 1]
+    double eu[2][MAXN + MAXM];           // NWF = 3: e | u of step k in eu[k & 1] (written before the torque is known)
+    int finp[2];                         // NWF = 3: step k is not computed (`fin` of step k-1), in finp[k & 1]
 };
+struct NoSplit { struct TrioPre {}; };
+template <class S, class = void> struct has_trio_split : std::false_type {};
+template <class S> struct has_trio_split<S, std::enable_if_t<S::TRIO_SPLIT>> : std::true_type {};
+
+// The sequential loop's tests on the step that produced xn (planner.py:393-433); true when the edge ends here
+template <class S>
+__device__ __forceinline__ bool rollout_check(const double* Pl, const Geo& g, const GeoL& gl, const Res& r, const double* xn,
+                                              const double* trn, const double* e, const double* u, int lane, int& cnt, int& steps,
+                                              double* last, const double* tolr, double* hx, double* hu, double* htr, DuoLds& duo) {
+    bool stop = false;
+    const bool feas_ok = uniform_true(S::feasible(Pl, g, gl, xn, u, trn, lane));
+    if (!feas_ok) {                                             // planner.py:393-396
+        cnt = (int)(r.FPR * (double)cnt);
+        duo.truncated = 1;
+        stop = true;
+    } else {
+        ++steps;                                                // planner.py:414
+        if (r.adaptive) {                                       // planner.py:418-425
+            bool all_grew = true;
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) all_grew = all_grew && (fabs(e[d]) >= last[d]);
+            if (uniform_true(all_grew)) { cnt = 0; duo.grew = 1; stop = true; }
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) last[d] = fabs(e[d]);
+        }
+        if (!stop) {
+            bool conv = true;
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= tolr[d]);
+            if (steps > r.H || uniform_true(conv)) {            // planner.py:428
+                stop = true;
+            } else {                                            // record (planner.py:432-433)
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) hx[cnt * S::N + d] = xn[d];
+#pragma unroll
+                for (int j = 0; j < S::M; ++j) hu[cnt * S::M + j] = u[j];
+                htr[2 * cnt] = trn[0]; htr[2 * cnt + 1] = trn[1];
+                ++cnt;
+            }
+        }
+    }
+    if (stop) { duo.cnt = cnt; duo.steps = steps; duo.stop = 1; }
+    return stop;
+}
 
 #ifdef STEER_TIMING
 __device__ unsigned long long g_steer_ts[8];
@@ -661,8 +714,8 @@ __device__ unsigned long long g_step_acc[8];        // per-phase ticks of the ro
 #define STEP_ACC(i, a, b) do {} while (0)
 #endif
 
-template <class S, int DENSE>
-__global__ __launch_bounds__(steer_threads<S>()) void k_steer(Params P, Geo g, Res r, TreeView tv, double* __restrict__ rec,
+template <class S, int DENSE, int NWF>
+__global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, TreeView tv, double* __restrict__ rec,
                                               RecLayout L, const double* __restrict__ xs,
                                               const int* __restrict__ list, int lo,
                                               const int* __restrict__ par, const int* __restrict__ list_count,
@@ -673,7 +726,8 @@ __global__ __launch_bounds__(steer_threads<S>()) void k_steer(Params P, Geo g, R
     // k_decide listed, so surplus workgroups simply leave (and a converged round costs one empty launch)
     if (list_count && (int)blockIdx.x + lo >= list_count[0]) return;
     STEER_TS(0);
-    constexpr bool DUO = is_packed<S>::value;
+    constexpr bool DUO = NWF >= 2;
+    static_assert(NWF == 1 || is_packed<S>::value, "helper wavefronts need the duo_* pieces of the system");
     extern __shared__ double hist[];
     double* hx = hist;
     double* hu = hist + (size_t)r.H * S::N;
@@ -684,7 +738,64 @@ __global__ __launch_bounds__(steer_threads<S>()) void k_steer(Params P, Geo g, R
     __shared__ GainLds<S> gl_lds;                            // work space of a Riccati gain (empty for analytic gains)
     __shared__ DuoLds duo;
     double* htr = hist + (size_t)r.H * (S::N + S::M) + geo_lds_doubles(g);   // DUO: cos/sin of every recorded state
-    if constexpr (DUO) {
+    if constexpr (NWF == 3) {
+        if (threadIdx.x >= 128) {
+            // ---------------- checking wavefront
+            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
+            for (int i = lane; i < MAXP; i += 64) Pl[i] = P.p[i];
+            if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
+            const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
+            __syncthreads();                                                // S
+            if (!duo.go) return;
+            double tolr[S::N], last[S::N];
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) { tolr[d] = tol_l[d]; last[d] = INFINITY; }           // planner.py:377
+            int cnt = 0, steps = 0;
+            for (int k = 0;; ++k) {
+                double xn[S::N], trn[2], e[S::N], u[S::M];
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) { xn[d] = duo.pk[d]; e[d] = duo.eu[(k + 1) & 1][d]; }
+                trn[0] = duo.tr[k & 1][0]; trn[1] = duo.tr[k & 1][1];
+#pragma unroll
+                for (int j = 0; j < S::M; ++j) u[j] = duo.eu[(k + 1) & 1][S::N + j];
+                const bool fin = duo.finp[k & 1] != 0;
+                bool stop = false;
+                if (k >= 1) stop = rollout_check<S>(Pl, g, gl, r, xn, trn, e, u, lane, cnt, steps, last, tolr, hx, hu, htr, duo);
+                __syncthreads();                                            // Y_k
+                if (duo.stop) return;
+                if (!fin && !stop) {
+                    // what the main wavefront needs for step k + 1 and only depends on x_k: cos/sin of the next heading
+                    // (euler(): xn[2] = x[2] + x[5] dt) and the gain there (planner.py:436)
+                    double tn[2], Kn[S::M * S::N];
+                    lq_sincos(xn[2] + xn[5] * r.dt, &tn[1], &tn[0]);
+                    S::gain(Pl, xn, tn, u, Kn);
+                    duo.tr[(k + 1) & 1][0] = tn[0]; duo.tr[(k + 1) & 1][1] = tn[1];
+#pragma unroll
+                    for (int j = 0; j < S::M * S::N; ++j) duo.Kb[(k + 1) & 1][j] = Kn[j];
+                }
+                __syncthreads();                                            // X_k+1
+            }
+        }
+        if (threadIdx.x >= 64) {
+            // ---------------- torque wavefront
+            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;
+            __syncthreads();                                                // S
+            if (!duo.go) return;
+            for (int k = 0;; ++k) {
+                if (!duo.finp[k & 1]) {
+                    double xk[S::N], tk[2];
+#pragma unroll
+                    for (int d = 0; d < S::N; ++d) xk[d] = duo.pk[d];
+                    tk[0] = duo.tr[k & 1][0]; tk[1] = duo.tr[k & 1][1];
+                    duo.rud = S::duo_chain(Pl, xk, tk);
+                }
+                __syncthreads();                                            // Y_k
+                if (duo.stop) return;
+                __syncthreads();                                            // X_k+1
+            }
+        }
+    }
+    if constexpr (NWF == 2) {
         if (threadIdx.x >= 64) {
             // ---------------- helper wavefront
             if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
@@ -891,7 +1002,59 @@ __global__ __launch_bounds__(steer_threads<S>()) void k_steer(Params P, Geo g, R
     STEER_TS(1);
     int cnt = 0, steps = 0;
     bool grew = false, truncated = false;
-    if constexpr (DUO) {
+    if constexpr (NWF == 3) {
+        duo.go = 1; duo.stop = 0; duo.cnt = 0; duo.steps = 0; duo.grew = 0; duo.truncated = 0; duo.finp[0] = 0; duo.finp[1] = 0;
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) duo.pk[d] = x[d];
+        duo.tr[0][0] = trig[0]; duo.tr[0][1] = trig[1];
+        __syncthreads();                                             // S
+        double tolr[S::N];
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) tolr[d] = tol_l[d];
+        bool live = true;
+        for (int k = 0;; ++k) {
+            double e[S::N], u[S::M], xn[S::N];
+            bool live_next = live;
+            [[maybe_unused]] typename std::conditional_t<has_trio_split<S>::value, S, NoSplit>::TrioPre pre;
+            STEP_TS(ms0);
+            if (live) {
+                if (k >= 1) {                                        // from the checker: cos/sin of this heading, K = lqr(x_k)
+                    trig[0] = duo.tr[k & 1][0]; trig[1] = duo.tr[k & 1][1];
+#pragma unroll
+                    for (int j = 0; j < S::M * S::N; ++j) K[j] = duo.Kb[k & 1][j];
+                }
+                S::trio_effort(xt, ttrig, x, trig, K, e, u);                       // planner.py:386-387
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) duo.eu[k & 1][d] = e[d];
+#pragma unroll
+                for (int j = 0; j < S::M; ++j) duo.eu[k & 1][S::N + j] = u[j];
+                // planner.py:428 as the checker will apply it to this step if every step so far is feasible: steps = k + 1
+                bool conv = true;
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= tolr[d]);
+                if (k + 1 > r.H || uniform_true(conv)) { duo.finp[(k + 1) & 1] = 1; live_next = false; }
+                if constexpr (has_trio_split<S>::value) S::trio_pre(Pl, x, trig, u, r.dt, pre);
+            }
+            STEP_TS(ms1);
+            __syncthreads();                                         // Y_k: the heading torque of this step and the verdict on
+            if (duo.stop) break;                                     //      step k-1 are there
+            STEP_TS(ms2);
+            if (live) {
+                const double rud = duo.rud;
+                if constexpr (has_trio_split<S>::value) S::trio_post(pre, x, u, rud, r.dt, xn);
+                else S::duo_finish(Pl, x, trig, u, rud, r.dt, xn);                // planner.py:390
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) { duo.pk[d] = xn[d]; x[d] = xn[d]; }
+            }
+            STEP_TS(ms3);
+            __syncthreads();                                         // X_k+1: state, cos/sin and gain of x_k+1 are there
+            STEP_TS(ms4);
+            STEP_ACC(0, ms0, ms1); STEP_ACC(1, ms1, ms2); STEP_ACC(2, ms2, ms3); STEP_ACC(4, ms3, ms4); STEP_ACC(3, ms0, ms0 + 1);
+            live = live_next;
+        }
+        cnt = duo.cnt; steps = duo.steps; grew = duo.grew != 0;
+        truncated = true;                                            // x / trig / K ran ahead: the node comes from the history
+    } else if constexpr (NWF == 2) {
         // main wavefront of a two-wavefront rollout (scheme above DuoLds); the helper has staged the LDS tables meanwhile
         duo.go = 1; duo.stop = 0; duo.cnt = 0; duo.steps = 0; duo.grew = 0; duo.truncated = 0; duo.fin = 0;
 #pragma unroll

@@ -39,7 +39,7 @@ for cnt, far in ((64, 0.0), (64, 11.0), (64, 30.0), (1024, 30.0)):
         n = max(1, acc[3])
         print('   per step (block 0, accumulated over all launches so far, ns): dynamics+trig %.0f | feasibility %.0f | checks/record/gain %.0f   [%d steps; each timestamp read costs ~100 ns itself]' % (
             acc[0] * 10.0 / n, acc[1] * 10.0 / n, acc[2] * 10.0 / n, n))
-        print('   two-wavefront boats, helper wavefront per step (ns): read + chain %.0f | wait Y %.0f | checks %.0f | wait X %.0f' % (
+        print('   multi-wavefront boats, per step (ns; 3 wavefronts: main, 2: helper): phase 1 %.0f | wait Y %.0f | phase 2 %.0f | wait X %.0f' % (
             acc[0] * 10.0 / n, acc[1] * 10.0 / n, acc[2] * 10.0 / n, acc[4] * 10.0 / n))
         print('   phases (block 0, us): loads+reduce %.2f | stage %.2f | rollout %.2f | record %.2f | rows %.2f | total %.2f' % (
             t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]))
