@@ -433,13 +433,15 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     return 0;
 }
 
-// Wavefronts per rollout (kernels.hpp, DuoLds): the boats with the heading torque use three while every wavefront of the
-// launch can have a SIMD of its own (1024 SIMDs), two beyond that; other systems use one.
+// Wavefronts per rollout (kernels.hpp, DuoLds): the boats with the heading torque use three up to 512 problems per launch
+// (1024 SIMDs: beyond 341 some wavefronts share a SIMD, which still pays up to ~600 on the bench, tools/ab_bench.sh), two
+// beyond that; other systems use one.
 template <class S> static int steer_wavefronts(int count) {
     if (steer_wavefronts_max<S>() == 1) return 1;
     static const int forced = getenv("LQRRT_STEER_WAVEFRONTS") ? atoi(getenv("LQRRT_STEER_WAVEFRONTS")) : 0;
     if (forced == 2 || forced == 3) return forced;
-    return 3 * count <= 1024 ? 3 : 2;
+    static const int trio_max = getenv("LQRRT_STEER_TRIO_MAX") ? atoi(getenv("LQRRT_STEER_TRIO_MAX")) : 512;
+    return count <= trio_max ? 3 : 2;
 }
 template <class S, bool DENSE, int NWF>
 static void launch_steer_nwf(lqrrt_engine* e, int count, size_t lds, hipStream_t st, const EvPair& ev, const double* xs, const int* list,
