@@ -352,6 +352,12 @@ static bool trace_on() {
     return on;
 }
 
+// LQRRT_HOSTPROF=1: where the host's time goes per wave (printed when the engine is destroyed)
+struct HostProf { double wait = 0, book = 0, flush = 0, nn = 0, steer = 0, other = 0; long waves = 0; };
+static HostProf g_hp;
+static bool hostprof_on() { static const bool on = getenv("LQRRT_HOSTPROF") != nullptr; return on; }
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 static int tri_chunk() {
     static const int c = getenv("LQRRT_TRI_CHUNK") ? atoi(getenv("LQRRT_TRI_CHUNK")) : 32;
     return c;
@@ -773,6 +779,9 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
 }
 
 extern "C" int lqrrt_engine_destroy(lqrrt_engine* e) {
+    if (hostprof_on() && g_hp.waves > 0)
+        fprintf(stderr, "[hostprof] per wave over %ld waves (us): sampler+ignore upload %.1f | scan launch %.1f | steer launch %.1f | waiting for rounds %.1f | commit bookkeeping %.1f\n",
+                g_hp.waves, g_hp.flush / g_hp.waves, g_hp.nn / g_hp.waves, g_hp.steer / g_hp.waves, g_hp.wait / g_hp.waves, g_hp.book / g_hp.waves);
     if (!e) return 0;
     (void)hipSetDevice(e->device);
     prof_flush(e);
@@ -1460,9 +1469,11 @@ extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void
     if (e->N + W > e->cap) return fail(LQRRT_E_CAPACITY, "tree capacity %d too small for size %d + wave %d", e->cap, e->N, W);
     TRY(use_device(e));
     hipStream_t st = (hipStream_t)stream;
+    const double hp0 = hostprof_on() ? now_us() : 0.0;
     TRY(ensure_samples(e, e->cursor + W, st));
     TRY(flush_ignore(e, st, false));
     TRY(ensure_werr(e, st));
+    const double hp1 = hostprof_on() ? now_us() : 0.0;
     const double* xs = wave_samples(e);
     const int cnt = hi - lo;
     const bool whole = (lo == 0 && hi == W);
@@ -1481,6 +1492,7 @@ extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void
         TRY(launch_nn(e, nv, xs + (size_t)lo * e->n, cnt, nullptr, false, nullptr, nullptr,
                       e->d_rec + (size_t)lo * e->L.R, st, true, &n_chunks, lo, true, xtr ? xtr + (size_t)lo * 2 * e->nw : nullptr,
                       e->riccati ? wave_sample_S(e) + (size_t)lo * e->n * e->n : nullptr));
+        const double hp2 = hostprof_on() ? now_us() : 0.0;
         SteerFuse f;
         memset(&f, 0, sizeof f);
         f.pcost = e->d_pcost; f.pidx = e->d_pidx; f.n_chunks = n_chunks; f.nv = nv;
@@ -1491,6 +1503,7 @@ extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void
         e->spec_fusable = f.M != nullptr;
         if (e->spec_fusable) { f.lf0 = e->d_lf[0]; f.round_ctl = e->d_rctl; }
         TRY(launch_steer(e, xs, nullptr, lo, cnt, e->d_par_done, st, nullptr, &f));
+        if (hostprof_on()) { const double hp3 = now_us(); g_hp.flush += hp1 - hp0; g_hp.nn += hp2 - hp1; g_hp.steer += hp3 - hp2; g_hp.waves++; }
     } else {
         e->spec_fusable = false;
     }
@@ -1697,7 +1710,9 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
             TRY(enqueue(r + 1));
             const int seq_next = e->seq;
             int* word = e->h_round + 2 + 2 * (r & 1);
+            const double hw0 = hostprof_on() ? now_us() : 0.0;
             TRY(wait_word(e, st, word, seq_r));
+            if (hostprof_on()) g_hp.wait += now_us() - hw0;
             const unsigned counts = (unsigned)__atomic_load_n(&word[0], __ATOMIC_RELAXED);
             const int n_list = (int)(counts >> 16), n_defer = (int)(counts & 0xffffu);
             if (trace_on()) fprintf(stderr, "[wave N=%d W=%d] fused round %d: list=%d defer=%d\n", e->N, W, r, n_list, n_defer);
@@ -1742,6 +1757,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
         if (++rounds > guard) return fail(LQRRT_E_STATE, "exact-mode repair did not converge");
     }
 
+    const double hb0 = hostprof_on() ? now_us() : 0.0;
     // commit prefix: stop after the first goal hit, the node limit, or max_commit attempts
     const int* sum = fused ? e->h_round + 8 : e->h_summary + 4;
     const int* len = sum;
@@ -1811,7 +1827,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
             ws.goal_hits++;
             if (e->best_end < 0 || steps < e->best_steps) { e->best_end = id; e->best_steps = steps; }  // planner.py:276 (T < self.T)
         }
-        e->ign_dirty = pruning != 0;
+        if (pruning) e->ign_dirty = true;
     }
     if (trace_on()) fprintf(stderr, "[wave N=%d W=%d] commit C=%d acc=%d hit=%d rounds=%d\n", base, W, C, acc, (int)hit, rounds);
     // advance the stream
@@ -1824,6 +1840,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     e->tot.resteers += ws.resteers; e->tot.goal_hits += ws.goal_hits; e->tot.tree_size = e->N;
     e->tot.candidates = e->committed_row;
     if (!e->sync_mode) tune_wave(e, W, ws, e->maxW);
+    if (hostprof_on()) g_hp.book += now_us() - hb0;
     if (out) *out = ws;
     return 0;
 }
