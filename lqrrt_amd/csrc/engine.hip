@@ -445,9 +445,10 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
 template <class S> static int steer_wavefronts(int count) {
     if (steer_wavefronts_max<S>() == 1) return 1;
     static const int forced = getenv("LQRRT_STEER_WAVEFRONTS") ? atoi(getenv("LQRRT_STEER_WAVEFRONTS")) : 0;
-    if (forced == 2 || forced == 3) return forced;
+    if (forced >= 2 && forced <= 4) return forced;
     static const int trio_max = getenv("LQRRT_STEER_TRIO_MAX") ? atoi(getenv("LQRRT_STEER_TRIO_MAX")) : 512;
-    return count <= trio_max ? 3 : 2;
+    static const int quad_max = getenv("LQRRT_STEER_QUAD_MAX") ? atoi(getenv("LQRRT_STEER_QUAD_MAX")) : 256;
+    return count <= quad_max ? 4 : count <= trio_max ? 3 : 2;
 }
 template <class S, bool DENSE, int NWF>
 static void launch_steer_nwf(lqrrt_engine* e, int count, size_t lds, hipStream_t st, const EvPair& ev, const double* xs, const int* list,
@@ -462,6 +463,9 @@ static void launch_steer_kernel(lqrrt_engine* e, int count, size_t lds, hipStrea
     if constexpr (steer_wavefronts_max<S>() == 1) {
         if (f.Sd) launch_steer_nwf<S, true, 1>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
         else launch_steer_nwf<S, false, 1>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
+    } else if (nwf == 4) {
+        if (f.Sd) launch_steer_nwf<S, true, 4>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
+        else launch_steer_nwf<S, false, 4>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
     } else if (nwf == 3) {
         if (f.Sd) launch_steer_nwf<S, true, 3>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
         else launch_steer_nwf<S, false, 3>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);

@@ -646,7 +646,10 @@ __device__ __forceinline__ void round_decide(const RoundArgs& ra, int cur, const
 // next heading and the gain off the main wavefront:
 //   main (0): erf, K e | + rud, thrusters, integration      torque (1): the chain | -
 //   checker (2): the tests on step k-1 | cos/sin of heading k+1 and K_k+1 (they only need x_k), handed over in tr / Kb
-template <class S> constexpr int steer_wavefronts_max() { return is_packed<S>::value ? 3 : 1; }
+// With four (NWF = 4, launches small enough for 4 SIMDs per problem) a fourth wavefront takes the cos/sin of the next heading
+// and the gain from the checker and also the erf angle of the next step (atan2 of target vs next heading: it needs nothing
+// but x_k either), so that the main wavefront's phase 1 is K e and the torque-independent half of the finish step.
+template <class S> constexpr int steer_wavefronts_max() { return is_packed<S>::value ? 4 : 1; }
 struct DuoLds {
     double pk[2 * MAXN + 4 + MAXM];      // xn | trn | e | u   of the newest step
     double rud;
@@ -656,6 +659,8 @@ struct DuoLds {
     double Kb[2][MAXM * MAXN];           // NWF = 3: gain K_k in Kb[k & 1]
     double eu[2][MAXN + MAXM];           // NWF = 3: e | u of step k in eu[k & 1] (written before the torque is known)
     int finp[2];                         // NWF = 3: step k is not computed (`fin` of step k-1), in finp[k & 1]
+    double e2b[2];                       // NWF = 4: erf angle of step k in e2b[k & 1]
+    double tt[2];                        // NWF = 4: cos/sin of the target's heading
 };
 struct NoSplit { struct TrioPre {}; };
 template <class S, class = void> struct has_trio_split : std::false_type {};
@@ -738,7 +743,36 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     __shared__ GainLds<S> gl_lds;                            // work space of a Riccati gain (empty for analytic gains)
     __shared__ DuoLds duo;
     double* htr = hist + (size_t)r.H * (S::N + S::M) + geo_lds_doubles(g);   // DUO: cos/sin of every recorded state
-    if constexpr (NWF == 3) {
+    if constexpr (NWF == 4) {
+        if (threadIdx.x >= 192) {
+            // ---------------- next-heading wavefront: what step k + 1 needs and only depends on x_k
+            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;
+            __syncthreads();                                                // S
+            if (!duo.go) return;
+            const double tt0 = duo.tt[0], tt1 = duo.tt[1];
+            for (int k = 0;; ++k) {
+                const bool alive = !duo.finp[k & 1];
+                double tn[2];
+                if (alive) {
+                    // cos/sin of the next heading (euler(): xn[2] = x[2] + x[5] dt) and the gain there (planner.py:436)
+                    double Kn[S::M * S::N], xk[S::N];
+#pragma unroll
+                    for (int d = 0; d < S::N; ++d) xk[d] = duo.pk[d];
+                    lq_sincos(xk[2] + xk[5] * r.dt, &tn[1], &tn[0]);
+                    S::gain(Pl, xk, tn, xk, Kn);
+                    duo.tr[(k + 1) & 1][0] = tn[0]; duo.tr[(k + 1) & 1][1] = tn[1];
+#pragma unroll
+                    for (int j = 0; j < S::M * S::N; ++j) duo.Kb[(k + 1) & 1][j] = Kn[j];
+                }
+                __syncthreads();                                            // Y_k
+                if (duo.stop) return;
+                // erf's angle error of step k + 1 (planner.py:386): wrap_err(target, next heading)
+                if (alive) duo.e2b[(k + 1) & 1] = lq_atan2(tt1 * tn[0] - tt0 * tn[1], tt0 * tn[0] + tt1 * tn[1]);
+                __syncthreads();                                            // X_k+1
+            }
+        }
+    }
+    if constexpr (NWF >= 3) {
         if (threadIdx.x >= 128) {
             // ---------------- checking wavefront
             if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
@@ -763,7 +797,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
                 if (k >= 1) stop = rollout_check<S>(Pl, g, gl, r, xn, trn, e, u, lane, cnt, steps, last, tolr, hx, hu, htr, duo);
                 __syncthreads();                                            // Y_k
                 if (duo.stop) return;
-                if (!fin && !stop) {
+                if (NWF == 3 && !fin && !stop) {
                     // what the main wavefront needs for step k + 1 and only depends on x_k: cos/sin of the next heading
                     // (euler(): xn[2] = x[2] + x[5] dt) and the gain there (planner.py:436)
                     double tn[2], Kn[S::M * S::N];
@@ -1002,11 +1036,12 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     STEER_TS(1);
     int cnt = 0, steps = 0;
     bool grew = false, truncated = false;
-    if constexpr (NWF == 3) {
+    if constexpr (NWF >= 3) {
         duo.go = 1; duo.stop = 0; duo.cnt = 0; duo.steps = 0; duo.grew = 0; duo.truncated = 0; duo.finp[0] = 0; duo.finp[1] = 0;
 #pragma unroll
         for (int d = 0; d < S::N; ++d) duo.pk[d] = x[d];
         duo.tr[0][0] = trig[0]; duo.tr[0][1] = trig[1];
+        if constexpr (NWF == 4) { duo.tt[0] = ttrig[0]; duo.tt[1] = ttrig[1]; }
         __syncthreads();                                             // S
         double tolr[S::N];
 #pragma unroll
@@ -1023,7 +1058,8 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
 #pragma unroll
                     for (int j = 0; j < S::M * S::N; ++j) K[j] = duo.Kb[k & 1][j];
                 }
-                S::trio_effort(xt, ttrig, x, trig, K, e, u);                       // planner.py:386-387
+                if (NWF == 4 && k >= 1) S::quad_effort(xt, x, K, duo.e2b[k & 1], e, u);
+                else S::trio_effort(xt, ttrig, x, trig, K, e, u);                  // planner.py:386-387
 #pragma unroll
                 for (int d = 0; d < S::N; ++d) duo.eu[k & 1][d] = e[d];
 #pragma unroll

@@ -360,6 +360,19 @@ struct BoatCommon {
             u[i] = a;
         }
     }
+    // (four wavefronts: the angle error arrives too)
+    __device__ static void quad_effort(const double* xt, const double* x, const double* K, double e2, double* e, double* u) {
+#pragma unroll
+        for (int d = 0; d < 6; ++d) e[d] = xt[d] - x[d];
+        e[2] = e2;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double a = K[i * 6] * e[0];
+#pragma unroll
+            for (int j = 1; j < 6; ++j) a += K[i * 6 + j] * e[j];
+            u[i] = a;
+        }
+    }
     // Helper wavefront: gain * heading error of the direction (yb, xb) -- atan2, sincos, atan2 in a row
     __device__ static double duo_rudder(double gainv, double yb, double xb, double c, double s) {
         const double ang = lq_atan2(yb, xb);
