@@ -1590,8 +1590,8 @@ static int pick_wave(const lqrrt_engine* e, int wave_cap) {
 }
 
 static void tune_wave(lqrrt_engine* e, int W, const lqrrt_extend_stats& ws, int wave_cap) {
-    // (retuned for the two-wavefront rollout, tools/ab_bench.sh: cut 2.0 -> 1.2 and lo 5 -> 2 are worth +2.5 %)
-    static const double k_cut = getenv("LQRRT_CTL_CUT") ? atof(getenv("LQRRT_CTL_CUT")) : 1.2;
+    // (retuned for the multi-wavefront rollouts, tools/ab_bench.sh: cut 2.0 -> 1.0 and lo 5 -> 2 are worth +3 %)
+    static const double k_cut = getenv("LQRRT_CTL_CUT") ? atof(getenv("LQRRT_CTL_CUT")) : 1.0;
     static const double k_min = getenv("LQRRT_CTL_MIN") ? atof(getenv("LQRRT_CTL_MIN")) : 128.0;
     static const int k_hi = getenv("LQRRT_CTL_HI") ? atoi(getenv("LQRRT_CTL_HI")) : 10;
     static const int k_lo = getenv("LQRRT_CTL_LO") ? atoi(getenv("LQRRT_CTL_LO")) : 2;

@@ -53,3 +53,15 @@ def test_legacy_repair_rounds_still_match():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "60", "41"], capture_output=True,
                          text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("wavefronts", [2, 3, 4])
+def test_rollout_wavefront_modes_match(wavefronts):
+    """The boats with the heading torque spread one rollout over 2, 3 or 4 wavefronts depending on the launch size
+    (kernels.hpp, DuoLds; lqrrt_amd/csrc/engine.hip steer_wavefronts).  Every mode has to reproduce the sequential oracle
+    bit for bit; LQRRT_STEER_WAVEFRONTS forces one mode for all launches.  Own process: the switch is read once."""
+    import subprocess
+    env = dict(os.environ, LQRRT_STEER_WAVEFRONTS=str(wavefronts))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "50", str(50 + wavefronts)],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
