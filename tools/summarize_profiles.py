@@ -31,8 +31,20 @@ CLOCK_GHZ, SIMDS = 2.4, 1024
 
 
 def kernel(d, part):
+    """Entry of the kernel whose name contains `part`; several instantiations (k_steer's 2 / 3 / 4-wavefront variants)
+    are merged, weighted by their launch counts."""
     ks = [k for k in d if part in k]
-    return d[ks[0]] if ks else None
+    if not ks:
+        return None
+    if len(ks) == 1:
+        return d[ks[0]]
+    n = sum(d[k]["launches_steady"] for k in ks)
+    out = dict(launches_total=sum(d[k]["launches_total"] for k in ks), launches_steady=n, merged=ks,
+               avg_ns=sum(d[k]["avg_ns"] * d[k]["launches_steady"] for k in ks) / n,
+               avg_grid_threads=sum(d[k].get("avg_grid_threads", 0) * d[k]["launches_steady"] for k in ks) / n)
+    names = sorted({c for k in ks for c in d[k]["per_launch"]})
+    out["per_launch"] = {c: sum(d[k]["per_launch"].get(c, 0.0) * d[k]["launches_steady"] for k in ks) / n for c in names}
+    return out
 
 
 def pmc(a, b, part, note):
@@ -86,8 +98,9 @@ def main():
     json.dump(traffic, open(os.path.join(out, "%s_nn_traffic.json" % rnd), "w"), indent=1)
     for name, part, note in (
             ("nn_pmc", kern, "tree scan, average wave of the bench loop (W ~ 230 samples x 10k nodes)"),
-            ("steer_pmc", "k_steer<lq::BoatAdvanced, 0>", "all steer launches of the loop: speculative (W wavefronts) and repair rounds (a handful), "
-                                                          "incl. pre-enqueued launches whose wavefronts exit at once"),
+            ("steer_pmc", "k_steer<lq::BoatAdvanced, 0,", "all steer launches of the loop (2-, 3- and 4-wavefront instantiations merged by launch count): "
+                                                           "speculative launches and fused repair rounds (W workgroups each; most wavefronts of a round only "
+                                                           "decide and leave), incl. the launch that performs the append"),
             ("decide_pmc", "k_decide", "one workgroup; thread t scans column t of the in-wave cost matrix")):
         r = pmc(sq_a, sq_b, part, note)
         if r is not None:
