@@ -175,6 +175,8 @@ struct lqrrt_engine {
     std::vector<int64_t> pool_rows_end;  // candidate rows consumed through each pooled sample
     bool explicit_samples = false; // samples pushed by the host (callable xrand_gen) instead of the sampler
     int tries_carry = 0;          // tries already spent on the sample under construction
+    std::vector<double> pregen;   // candidate rows generated ahead of the next refill while the host waits for the GPU
+    int pregen_rows = 0;          // (they advance mt_gen exactly as the refill would; dropped whenever mt_gen is replaced)
     double* d_pool_trig = nullptr; // cos/sin of their angular coordinates [count][2*nw] (k_sample_trig)
     double* d_pool = nullptr;     // device mirror of the samples [cursor_at_upload ..)
     int64_t d_pool_base = 0, d_pool_count = 0;
@@ -849,7 +851,7 @@ extern "C" int lqrrt_engine_set_resolution(lqrrt_engine* e, const lqrrt_resoluti
         MT g = e->mt_base;
         for (int64_t i = 0; i < (e->committed_row - e->base_row) * (int64_t)(e->n + 1); ++i) (void)g.next_double();
         e->mt_base = g; e->base_row = e->committed_row;
-        e->mt_gen = g; e->gen_row = e->committed_row;
+        e->mt_gen = g; e->gen_row = e->committed_row; e->pregen_rows = 0;
         e->tries_carry = 0; e->d_pool_count = 0;
     }
     return 0;
@@ -865,7 +867,7 @@ static void invalidate_samples(lqrrt_engine* e) {
     MT g = e->mt_base;
     for (int64_t i = 0; i < (e->committed_row - e->base_row) * (int64_t)(e->n + 1); ++i) (void)g.next_double();
     e->mt_base = g; e->base_row = e->committed_row;
-    e->mt_gen = g; e->gen_row = e->committed_row;
+    e->mt_gen = g; e->gen_row = e->committed_row; e->pregen_rows = 0;
     e->tries_carry = 0; e->d_pool_count = 0;
 }
 
@@ -923,6 +925,7 @@ extern "C" int lqrrt_engine_set_mt19937(lqrrt_engine* e, const uint32_t* key624,
     memcpy(e->mt_gen.key, key624, sizeof(uint32_t) * 624);
     e->mt_gen.pos = pos;
     e->mt_base = e->mt_gen;
+    e->pregen_rows = 0;
     e->base_row = e->gen_row = e->committed_row = 0;
     e->pool.clear(); e->pool_rows_end.clear();
     e->pool_base = e->cursor;
@@ -1344,6 +1347,25 @@ static int upload_pool(lqrrt_engine* e, int64_t off, int64_t cnt, hipStream_t st
     return 0;
 }
 
+// One candidate of the default sampler (planner.py:204-205): uniform in the sample space, goal-biased per dimension
+static inline void candidate_row(lqrrt_engine* e, double* c) {
+    const int n = e->n;
+    for (int d = 0; d < n; ++d) c[d] = e->smp.centers[d] + e->smp.spans[d] * (e->mt_gen.next_double() - 0.5);
+    const double gate = e->mt_gen.next_double();
+    for (int d = 0; d < n; ++d)
+        if (e->smp.goal_bias[d] > gate) c[d] = e->goal[d];
+}
+static const int SAMPLER_BLOCK = 16384;
+// A refill draws ~230k MT19937 numbers (~0.6 ms on the host) while the GPU idles; the host, on the other hand, idles while
+// the GPU works through repair rounds.  This generates up to `rows` candidates of the NEXT refill during such a wait.
+static void pregenerate_candidates(lqrrt_engine* e, int rows) {
+    if (e->explicit_samples || !e->has_sampler || !e->has_goal || e->pregen_rows >= SAMPLER_BLOCK) return;
+    if (e->pregen.size() < (size_t)SAMPLER_BLOCK * e->n) e->pregen.resize((size_t)SAMPLER_BLOCK * e->n);
+    const int end = std::min(SAMPLER_BLOCK, e->pregen_rows + rows);
+    for (int r = e->pregen_rows; r < end; ++r) candidate_row(e, &e->pregen[(size_t)r * e->n]);
+    e->pregen_rows = end;
+}
+
 static int ensure_samples(lqrrt_engine* e, int64_t need_end, hipStream_t st) {
     // makes samples [cursor, need_end) available on the device at d_pool (index - d_pool_base)
     if (e->explicit_samples) {
@@ -1371,7 +1393,7 @@ static int ensure_samples(lqrrt_engine* e, int64_t need_end, hipStream_t st) {
         e->pool_base += drop;
     }
     const int64_t target_end = std::max<int64_t>(need_end, e->cursor + 8 * (int64_t)e->maxW);
-    const int CH = 16384;
+    const int CH = SAMPLER_BLOCK;
     if (e->cand_cap < CH) {
         if (e->d_cand) (void)hipFree(e->d_cand);
         if (e->d_flags) (void)hipFree(e->d_flags);
@@ -1382,13 +1404,11 @@ static int ensure_samples(lqrrt_engine* e, int64_t need_end, hipStream_t st) {
     std::vector<double> cand((size_t)CH * n);
     std::vector<unsigned char> flags(CH);
     while (e->pool_base + (int64_t)e->pool_rows_end.size() < target_end) {
-        for (int r = 0; r < CH; ++r) {
-            double* c = &cand[(size_t)r * n];
-            for (int d = 0; d < n; ++d) c[d] = e->smp.centers[d] + e->smp.spans[d] * (e->mt_gen.next_double() - 0.5);
-            const double gate = e->mt_gen.next_double();
-            for (int d = 0; d < n; ++d)
-                if (e->smp.goal_bias[d] > gate) c[d] = e->goal[d];
-        }
+        // rows generated ahead while the host was waiting for repair rounds come first (same generator, same order)
+        const int ahead = std::min(e->pregen_rows, CH);
+        if (ahead > 0) memcpy(cand.data(), e->pregen.data(), sizeof(double) * (size_t)ahead * n);
+        e->pregen_rows = 0;
+        for (int r = ahead; r < CH; ++r) candidate_row(e, &cand[(size_t)r * n]);
         HIPCHK(hipMemcpyAsync(e->d_cand, cand.data(), sizeof(double) * CH * n, hipMemcpyHostToDevice, st));
         DISPATCH(e, hipLaunchKernelGGL((k_feasible_batch<S>), dim3(CH), dim3(64), geo_lds_bytes(e), st, e->P, e->geo, e->d_cand, nullptr, CH, e->d_flags));
         HIPCHK(hipGetLastError());
@@ -1714,6 +1734,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
             TRY(enqueue(r + 1));
             const int seq_next = e->seq;
             int* word = e->h_round + 2 + 2 * (r & 1);
+            pregenerate_candidates(e, 96);                    // the GPU is busy with round r (and r + 1 is queued)
             const double hw0 = hostprof_on() ? now_us() : 0.0;
             TRY(wait_word(e, st, word, seq_r));
             if (hostprof_on()) g_hp.wait += now_us() - hw0;
