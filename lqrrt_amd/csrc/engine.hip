@@ -445,7 +445,7 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
 // (1024 SIMDs: beyond 341 some wavefronts share a SIMD, which still pays up to ~600 on the bench, tools/ab_bench.sh), two
 // beyond that; other systems use one.
 template <class S> static int steer_wavefronts(int count) {
-    if (steer_wavefronts_max<S>() == 1) return 1;
+    if (steer_wavefronts_max<S>() <= 2) return steer_wavefronts_max<S>();
     static const int forced = getenv("LQRRT_STEER_WAVEFRONTS") ? atoi(getenv("LQRRT_STEER_WAVEFRONTS")) : 0;
     if (forced >= 2 && forced <= 4) return forced;
     static const int trio_max = getenv("LQRRT_STEER_TRIO_MAX") ? atoi(getenv("LQRRT_STEER_TRIO_MAX")) : 512;
@@ -465,6 +465,9 @@ static void launch_steer_kernel(lqrrt_engine* e, int count, size_t lds, hipStrea
     if constexpr (steer_wavefronts_max<S>() == 1) {
         if (f.Sd) launch_steer_nwf<S, true, 1>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
         else launch_steer_nwf<S, false, 1>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
+    } else if constexpr (steer_wavefronts_max<S>() == 2) {
+        if (f.Sd) launch_steer_nwf<S, true, 2>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
+        else launch_steer_nwf<S, false, 2>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
     } else if (nwf == 4) {
         if (f.Sd) launch_steer_nwf<S, true, 4>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
         else launch_steer_nwf<S, false, 4>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
@@ -485,7 +488,7 @@ static int launch_steer(lqrrt_engine* e, const double* xs, const int* list, int 
     memset(&ra, 0, sizeof ra);
     if (round) ra = *round;
     // (+ cos/sin of every recorded state: the two-wavefront rollout of the boats keeps them with the history)
-    const size_t lds = (size_t)e->H * (e->n + e->m + 2) * sizeof(double) + geo_lds_bytes(e);
+    const size_t lds = (size_t)e->H * (e->n + e->m + 2 * std::max(e->nw, 1)) * sizeof(double) + geo_lds_bytes(e);
     SteerFuse f;
     memset(&f, 0, sizeof f);
     if (fuse) f = *fuse;

@@ -649,7 +649,14 @@ __device__ __forceinline__ void round_decide(const RoundArgs& ra, int cur, const
 // With four (NWF = 4, launches small enough for 4 SIMDs per problem) a fourth wavefront takes the cos/sin of the next heading
 // and the gain from the checker and also the erf angle of the next step (atan2 of target vs next heading: it needs nothing
 // but x_k either), so that the main wavefront's phase 1 is K e and the torque-independent half of the finish step.
-template <class S> constexpr int steer_wavefronts_max() { return is_packed<S>::value ? 4 : 1; }
+// Every other system with an analytic gain uses two wavefronts in the plain way: the main wavefront computes the steps
+// (erf, K e, dynamics, cos/sin, gain), the second one runs the sequential loop's tests one step behind (one barrier per
+// step, packets double-buffered by step parity).  Riccati systems keep one wavefront (their gain uses the whole wavefront).
+// Systems opt in (S::TWO_WAVEFRONTS): it pays where the tests are a real share of a step (car +18 %, boat_novice and the
+// 12-state integrator +2 %), not for the pendulum (no obstacles: -4 %).
+template <class S, class = void> struct wants_two : std::false_type {};
+template <class S> struct wants_two<S, std::enable_if_t<S::TWO_WAVEFRONTS>> : std::true_type {};
+template <class S> constexpr int steer_wavefronts_max() { return is_packed<S>::value ? 4 : wants_two<S>::value ? 2 : 1; }
 struct DuoLds {
     double pk[2 * MAXN + 4 + MAXM];      // xn | trn | e | u   of the newest step
     double rud;
@@ -659,6 +666,7 @@ struct DuoLds {
     double Kb[2][MAXM * MAXN];           // NWF = 3: gain K_k in Kb[k & 1]
     double eu[2][MAXN + MAXM];           // NWF = 3: e | u of step k in eu[k & 1] (written before the torque is known)
     int finp[2];                         // NWF = 3: step k is not computed (`fin` of step k-1), in finp[k & 1]
+    double pk2[2][2 * MAXN + 4 + MAXM];  // plain two-wavefront rollout: xn | trn | e | u of step k in pk2[k & 1]
     double e2b[2];                       // NWF = 4: erf angle of step k in e2b[k & 1]
     double tt[2];                        // NWF = 4: cos/sin of the target's heading
 };
@@ -698,7 +706,8 @@ __device__ __forceinline__ bool rollout_check(const double* Pl, const Geo& g, co
                 for (int d = 0; d < S::N; ++d) hx[cnt * S::N + d] = xn[d];
 #pragma unroll
                 for (int j = 0; j < S::M; ++j) hu[cnt * S::M + j] = u[j];
-                htr[2 * cnt] = trn[0]; htr[2 * cnt + 1] = trn[1];
+#pragma unroll
+                for (int j = 0; j < 2 * S::NW; ++j) htr[2 * S::NW * cnt + j] = trn[j];
                 ++cnt;
             }
         }
@@ -732,7 +741,8 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     if (list_count && (int)blockIdx.x + lo >= list_count[0]) return;
     STEER_TS(0);
     constexpr bool DUO = NWF >= 2;
-    static_assert(NWF == 1 || is_packed<S>::value, "helper wavefronts need the duo_* pieces of the system");
+    static_assert(NWF <= 2 || is_packed<S>::value, "the three- and four-wavefront splits need the duo_* pieces of the system");
+    constexpr bool PLAIN2 = NWF == 2 && !is_packed<S>::value;
     extern __shared__ double hist[];
     double* hx = hist;
     double* hu = hist + (size_t)r.H * S::N;
@@ -743,6 +753,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     __shared__ GainLds<S> gl_lds;                            // work space of a Riccati gain (empty for analytic gains)
     __shared__ DuoLds duo;
     double* htr = hist + (size_t)r.H * (S::N + S::M) + geo_lds_doubles(g);   // DUO: cos/sin of every recorded state
+    constexpr int PKN = S::N + 2 * S::NW;                                    // plain two-wavefront packet: offset of e
     if constexpr (NWF == 4) {
         if (threadIdx.x >= 192) {
             // ---------------- next-heading wavefront: what step k + 1 needs and only depends on x_k
@@ -829,7 +840,35 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             }
         }
     }
-    if constexpr (NWF == 2) {
+    if constexpr (PLAIN2) {
+        if (threadIdx.x >= 64) {
+            // ---------------- checking wavefront of the plain two-wavefront rollout
+            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
+            for (int i = lane; i < MAXP; i += 64) Pl[i] = P.p[i];
+            if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
+            const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
+            __syncthreads();                                                // S
+            if (!duo.go) return;
+            double tolr[S::N], last[S::N];
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) { tolr[d] = tol_l[d]; last[d] = INFINITY; }           // planner.py:377
+            int cnt = 0, steps = 0;
+            for (int k = 0;; ++k) {
+                __syncthreads();                                            // B_k: packet k is there
+                if (duo.stop) return;
+                double xn[S::N], trn[2 * S::NW + 1], e[S::N], u[S::M];
+                const double* pk = duo.pk2[k & 1];
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) { xn[d] = pk[d]; e[d] = pk[PKN + d]; }
+#pragma unroll
+                for (int j = 0; j < 2 * S::NW; ++j) trn[j] = pk[S::N + j];
+#pragma unroll
+                for (int j = 0; j < S::M; ++j) u[j] = pk[PKN + S::N + j];
+                rollout_check<S>(Pl, g, gl, r, xn, trn, e, u, lane, cnt, steps, last, tolr, hx, hu, htr, duo);
+            }
+        }
+    }
+    if constexpr (NWF == 2 && !PLAIN2) {
         if (threadIdx.x >= 64) {
             // ---------------- helper wavefront
             if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
@@ -1090,6 +1129,46 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         }
         cnt = duo.cnt; steps = duo.steps; grew = duo.grew != 0;
         truncated = true;                                            // x / trig / K ran ahead: the node comes from the history
+    } else if constexpr (PLAIN2) {
+        // main wavefront of the plain two-wavefront rollout: the steps; the other wavefront checks them one step behind
+        duo.go = 1; duo.stop = 0; duo.cnt = 0; duo.steps = 0; duo.grew = 0; duo.truncated = 0;
+        __syncthreads();                                             // S
+        double tolr[S::N];
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) tolr[d] = tol_l[d];
+        bool live = true;
+        for (int k = 0;; ++k) {
+            if (live) {
+                double e[S::N], u[S::M], uc[S::M], xn[S::N], trn[2 * S::NW + 1];
+                erf_cached<S>(xt, ttrig, x, trig, e);                // planner.py:386
+#pragma unroll
+                for (int i = 0; i < S::M; ++i) {                     // u = K.dot(e), planner.py:387
+                    double a = K[i * S::N] * e[0];
+#pragma unroll
+                    for (int j = 1; j < S::N; ++j) a += K[i * S::N + j] * e[j];
+                    u[i] = a; uc[i] = a;
+                }
+                S::step(Pl, x, trig, uc, r.dt, xn);                 // planner.py:390 (dynamics gets copies)
+                trig_of<S>(xn, trn);
+                double* pk = duo.pk2[k & 1];
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) { pk[d] = xn[d]; pk[PKN + d] = e[d]; x[d] = xn[d]; }
+#pragma unroll
+                for (int j = 0; j < 2 * S::NW; ++j) { pk[S::N + j] = trn[j]; trig[j] = trn[j]; }
+#pragma unroll
+                for (int j = 0; j < S::M; ++j) pk[PKN + S::N + j] = u[j];
+                system_gain<S>(Pl, x, trig, u, r.dt, gl_lds, lane, K);  // planner.py:436
+                // planner.py:428 as the checker will apply it to this step if every step so far is feasible: steps = k + 1
+                bool conv = true;
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= tolr[d]);
+                if (k + 1 > r.H || uniform_true(conv)) live = false;
+            }
+            __syncthreads();                                         // B_k: packet k is there; the verdict on step k-1 too
+            if (duo.stop) break;
+        }
+        cnt = duo.cnt; steps = duo.steps; grew = duo.grew != 0;
+        truncated = true;                                            // x / trig / K ran ahead: the node comes from the history
     } else if constexpr (NWF == 2) {
         // main wavefront of a two-wavefront rollout (scheme above DuoLds); the helper has staged the LDS tables meanwhile
         duo.go = 1; duo.stop = 0; duo.cnt = 0; duo.steps = 0; duo.grew = 0; duo.truncated = 0; duo.fin = 0;
@@ -1215,7 +1294,10 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             for (int d = 0; d < S::N; ++d) x[d] = hx[(cnt - 1) * S::N + d];
 #pragma unroll
             for (int j = 0; j < S::M; ++j) ul[j] = hu[(cnt - 1) * S::M + j];
-            if constexpr (DUO) { trig[0] = htr[2 * (cnt - 1)]; trig[1] = htr[2 * (cnt - 1) + 1]; }     // recorded with the state
+            if constexpr (DUO) {                                                                          // recorded with the state
+#pragma unroll
+                for (int j = 0; j < 2 * S::NW; ++j) trig[j] = htr[2 * S::NW * (cnt - 1) + j];
+            }
             else trig_of<S>(x, trig);
             system_gain<S>(Pl, x, trig, ul, r.dt, gl_lds, lane, K);   // planner.py:257: lqr(xnew, u_last)
         }

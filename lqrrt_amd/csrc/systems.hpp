@@ -568,6 +568,7 @@ struct BoatIntermediate : BoatCommon {
 };
 
 struct BoatNovice : BoatCommon {
+    static constexpr bool TWO_WAVEFRONTS = true;     // k_steer: a second wavefront runs the step tests
     // params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 u_max[3] | 12 kp[3] | 15 kd[3] | 18 boat_length/2
     __device__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
         gain_pd(P + 12, P + 15, trig, K);
@@ -712,6 +713,7 @@ struct RosBoat : BoatCommon {
 // Car: state [x, y, h, vx, vh], effort [ux, uh]  (demos/demo_car.py)
 
 struct Car {
+    static constexpr bool TWO_WAVEFRONTS = true;     // k_steer: a second wavefront runs the step tests
     static constexpr int N = 5, M = 2, NW = 1;
     __device__ static constexpr int wd(int) { return 2; }
     // params: 0 invM[2] | 2 D[2] | 4 u_lo[2] | 6 u_hi[2] | 8 velmax0 | 9 kp[2] | 11 kd[2]
@@ -795,6 +797,7 @@ struct PendulumLqr : Pendulum {
 
 template <int D>
 struct DoubleIntegratorT {
+    static constexpr bool TWO_WAVEFRONTS = true;     // k_steer: a second wavefront runs the step tests
     static constexpr int N = 2 * D, M = D, NW = 0;
     __device__ static constexpr int wd(int) { return 0; }
     // params: 0 dt of the model | 1 K[D][2D] constant DARE gain (row-major)
