@@ -311,6 +311,8 @@ static int ensure_werr(lqrrt_engine* e, hipStream_t st);
 // --------------------------------------------------------------------------------------------
 // profiling helpers
 
+static long g_steer_hist[16];        // LQRRT_HOSTPROF: event-timed steer launches in 4 us buckets
+static bool hostprof_on();
 static hipEvent_t prof_event(lqrrt_engine* e) {
     hipEvent_t ev = nullptr;
     if (!e->ev_free.empty()) { ev = e->ev_free.back(); e->ev_free.pop_back(); }
@@ -323,7 +325,7 @@ static void prof_flush(lqrrt_engine* e) {
         (void)hipEventSynchronize(ev.b);
         (void)hipEventElapsedTime(&ms, ev.a, ev.b);
         if (ev.kind == 0) { e->nn_ms += ms; e->nn_bytes += ev.bytes; e->nn_launches++; }
-        else { e->steer_ms += ms; e->steer_launches++; }
+        else { e->steer_ms += ms; e->steer_launches++; if (hostprof_on()) g_steer_hist[std::min(15, (int)(ms * 1e3 / 4.0))]++; }
         e->ev_free.push_back(ev.a);
         e->ev_free.push_back(ev.b);
     }
@@ -788,6 +790,15 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
 }
 
 extern "C" int lqrrt_engine_destroy(lqrrt_engine* e) {
+    if (hostprof_on()) {
+        long tot = 0;
+        for (long v : g_steer_hist) tot += v;
+        if (tot > 0) {
+            fprintf(stderr, "[hostprof] event-timed steer launches by duration (4 us buckets, incl. the 4.1 us event floor):");
+            for (int i = 0; i < 16; ++i) fprintf(stderr, " %d-%d:%ld", 4 * i, 4 * i + 4, g_steer_hist[i]);
+            fprintf(stderr, "\n");
+        }
+    }
     if (hostprof_on() && g_hp.waves > 0)
         fprintf(stderr, "[hostprof] per wave over %ld waves (us): sampler+ignore upload %.1f | scan launch %.1f | steer launch %.1f | waiting for rounds %.1f | commit bookkeeping %.1f\n",
                 g_hp.waves, g_hp.flush / g_hp.waves, g_hp.nn / g_hp.waves, g_hp.steer / g_hp.waves, g_hp.wait / g_hp.waves, g_hp.book / g_hp.waves);
@@ -1957,6 +1968,14 @@ extern "C" int lqrrt_profile_read(lqrrt_engine* e, double* nn_ms, int64_t* nn_la
 // debug build only (tools/ablate_steer.py): phase timestamps of block 0 of the last steer launch, 100 MHz ticks
 extern "C" int lqrrt_debug_steer_ts(unsigned long long* out8) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lq::g_steer_ts), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    return 0;
+}
+extern "C" int lqrrt_debug_pro_acc(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(lq::g_pro_acc), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    return 0;
+}
+extern "C" int lqrrt_debug_blk_acc(unsigned long long* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lq::g_blk_acc), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
     return 0;
 }
 extern "C" int lqrrt_debug_step_acc(unsigned long long* out8) {

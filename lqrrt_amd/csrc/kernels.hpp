@@ -720,10 +720,14 @@ __device__ __forceinline__ bool rollout_check(const double* Pl, const Geo& g, co
 __device__ unsigned long long g_steer_ts[8];
 #define STEER_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_steer_ts[i] = wall_clock64(); } while (0)
 __device__ unsigned long long g_step_acc[8];        // per-phase ticks of the rollout loop of block 0, + step count
+__device__ unsigned long long g_blk_acc[8];
+__device__ unsigned long long g_pro_acc[16];        // prologue of rolling workgroups: [mode*5 + {to pref, parent loads, to S barrier, count}]         // full-horizon rollouts: sum kernel time, sum loop time, count, max kernel, max loop
+#define BLK_T(v) const unsigned long long v = wall_clock64()
 #define STEP_TS(v) const unsigned long long v = wall_clock64()
 #define STEP_ACC(i, a, b) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_step_acc[i] += (b) - (a); } while (0)
 #else
 #define STEER_TS(i) do {} while (0)
+#define BLK_T(v) const unsigned long long v = 0
 #define STEP_TS(v) do {} while (0)
 #define STEP_ACC(i, a, b) do {} while (0)
 #endif
@@ -740,6 +744,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     // k_decide listed, so surplus workgroups simply leave (and a converged round costs one empty launch)
     if (list_count && (int)blockIdx.x + lo >= list_count[0]) return;
     STEER_TS(0);
+    BLK_T(blk_t0);
     constexpr bool DUO = NWF >= 2;
     static_assert(NWF <= 2 || is_packed<S>::value, "the three- and four-wavefront splits need the duo_* pieces of the system");
     constexpr bool PLAIN2 = NWF == 2 && !is_packed<S>::value;
@@ -949,6 +954,25 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     } else {
         trig_of<S>(xt, ttrig);
     }
+    bool parent_loaded = false;
+    auto load_parent = [&](int p) {                                  // state, cos/sin and gain of tree node p >= 0 / record ~p
+        if (p >= 0) {
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) x[d] = tv.state[(size_t)d * tv.cap + p];
+#pragma unroll
+            for (int j = 0; j < 2 * S::NW; ++j) trig[j] = tv.trig[(size_t)j * tv.cap + p];
+#pragma unroll
+            for (int j = 0; j < S::M * S::N; ++j) K[j] = tv.K[(size_t)p * S::M * S::N + j];
+        } else {
+            const double* pr = rec + (size_t)(~p) * L.R;
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) x[d] = pr[L.off_xend + d];
+#pragma unroll
+            for (int j = 0; j < 2 * S::NW; ++j) trig[j] = pr[L.off_trig + j];
+#pragma unroll
+            for (int j = 0; j < S::M * S::N; ++j) K[j] = pr[L.off_K + j];
+        }
+    };
     int pref;
     if (f.n_chunks > 0) {
         // nearest node of this sample from the scan's partial minima (see k_nn_reduce for the rules)
@@ -956,10 +980,21 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         int bi = -1;
         const double* pc = f.pcost + (size_t)blockIdx.x * f.n_chunks;
         const int* pi = f.pidx + (size_t)blockIdx.x * f.n_chunks;
-        for (int c = lane; c < f.n_chunks; c += 64) {
-            const double v = pc[c];
-            const int vi = pi[c];
-            if (vi >= 0 && (bi < 0 || v < b)) { b = v; bi = vi; }
+        // (eight loads per lane in flight: the partials were written by other workgroups a moment ago, every access is a
+        // ~1 us round trip, and the conditional update below keeps the compiler from overlapping the iterations itself)
+        for (int c0 = lane; c0 < f.n_chunks; c0 += 512) {
+            double v[8];
+            int vi[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c = c0 + 64 * q;
+                const bool in = c < f.n_chunks;
+                v[q] = in ? pc[c] : INFINITY;
+                vi[q] = in ? pi[c] : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)                              // ascending chunks per lane, as before
+                if (vi[q] >= 0 && (bi < 0 || v[q] < b)) { b = v[q]; bi = vi[q]; }
         }
         lexmin_wave(b, bi);
         const bool fallback = bi < 0 && f.nv.ignore != nullptr;
@@ -988,7 +1023,29 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         pref = bi;
     } else if (ron) {
         const int cur = ra.round & 1, nxt = cur ^ 1;
-        if (ra.ctl[RC_CONV + cur]) {
+        // batch A: everything the decision needs that only depends on t (issued before the flag is even tested)
+        const int conv_flag = ra.ctl[RC_CONV + cur];
+        int lf_len[4], lf_flg[4];
+        unsigned char chg[4];
+        double colv[4];
+        {
+            const int* lfc = ra.lf[cur];
+            const double* Mc = ra.M[cur];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int tt = lane + 64 * i;
+                const bool in = tt < ra.W;
+                lf_len[i] = in ? lfc[2 * tt] : 0;
+                lf_flg[i] = in ? lfc[2 * tt + 1] : 0;
+                chg[i] = in ? ra.changed[cur][tt] : 0;
+                colv[i] = (tt < t) ? Mc[(size_t)tt * ra.W + t] : INFINITY;
+            }
+        }
+        const double csnap_t = rec[(size_t)t * L.R + L.off_cost];
+        const int psnap_t = (int)rec[(size_t)t * L.R + L.off_parent];
+        const int par_t = ra.par[cur][t];
+        const int stale_t = ra.stale[cur][t];
+        if (conv_flag) {
             // the previous round converged: this launch is the commit.  Sample t's record becomes tree node
             // base + rank[t] if it lies in the committed prefix (tree.py:77-96; what k_append does).
             const int C = ra.ctl[RC_C];
@@ -1016,19 +1073,57 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             }
             return;                                             // (the flag is cleared by the next wave's speculative launch)
         }
-        // ---- this sample's decision (k_decide's rules)
-        const int hz = round_horizon(ra.lf[cur], ra.W, lane);
-        int want = ra.par[cur][t];
+        // ---- this sample's decision (k_decide's rules).  Everything below was written by other workgroups in the
+        // previous launch, so every dependent access is a ~1 us round trip: the loads are issued in two batches (what only
+        // depends on t; what depends on the wanted parent) instead of eight dependent steps.  W <= 256 here (in-wave matrix).
+        int want = par_t;
         bool need = false, defer = false, mark_stale = false;
+        int hz = ra.W - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)                                // first goal hit among the current records (or W - 1)
+            if (hz == ra.W - 1 && lf_len[i] > 0 && (lf_flg[i] & 1)) hz = lane + 64 * i;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) hz = min(hz, __shfl_xor(hz, off));
+        auto changed_of = [&](int idx) -> bool {                   // changed[cur][idx] from the lanes' prefetched bytes
+            int v = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int w = __shfl((int)chg[i], idx & 63); if ((idx >> 6) == i) v = w; }
+            return v != 0;
+        };
         if (t <= hz) {
-            round_decide(ra, cur, rec, L, t, lane, want, need);
+            double wc = INFINITY;
+            int sm = -1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)                            // ascending per lane, strict '<': lowest record on ties
+                if (lane + 64 * i < t && colv[i] < wc) { wc = colv[i]; sm = lane + 64 * i; }
+            lexmin_wave(wc, sm);
+            want = (sm >= 0 && wc < csnap_t) ? ~sm : psnap_t;
+            need = (want != par_t) || (stale_t != 0);
+            if (want < 0 && changed_of(~want)) need = true;
+            if (need) { load_parent(want); parent_loaded = true; }    // (in flight together with the neighbour's column below)
             if (need && want < 0) {
                 // the in-wave parent's own decision, evaluated here instead of waited for: redone this round -> defer
-                int want_s; bool need_s;
-                round_decide(ra, cur, rec, L, ~want, lane, want_s, need_s);   // (~want < t <= hz)
+                const int sn = ~want;                              // (sn < t <= hz)
+                const double* Mc = ra.M[cur];
+                double cs[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cs[i] = (lane + 64 * i < sn) ? Mc[(size_t)(lane + 64 * i) * ra.W + sn] : INFINITY;
+                const double csnap_s = rec[(size_t)sn * L.R + L.off_cost];
+                const int psnap_s = (int)rec[(size_t)sn * L.R + L.off_parent];
+                const int par_s = ra.par[cur][sn];
+                const int stale_s = ra.stale[cur][sn];
+                double ws = INFINITY;
+                int ss = -1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (lane + 64 * i < sn && cs[i] < ws) { ws = cs[i]; ss = lane + 64 * i; }
+                lexmin_wave(ws, ss);
+                const int want_s = (ss >= 0 && ws < csnap_s) ? ~ss : psnap_s;
+                bool need_s = (want_s != par_s) || (stale_s != 0);
+                if (want_s < 0 && changed_of(~want_s)) need_s = true;
                 defer = need_s;
             }
-        } else if (want < 0 && ra.changed[cur][~want]) {
+        } else if (want < 0 && changed_of(~want)) {
             mark_stale = true;        // beyond the horizon, but its in-wave parent just moved (see k_decide)
         }
         const bool redo = need && !defer;
@@ -1050,29 +1145,16 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     } else {
         pref = par[t];
     }
+    BLK_T(blk_tp);
     const bool round_skip = ron && pref == 0x7fffffff;
     if constexpr (DUO) {
         if (round_skip) { duo.go = 0; __syncthreads(); }         // S: the helper leaves
     }
     if (!round_skip) {
-    if (pref >= 0) {
-#pragma unroll
-        for (int d = 0; d < S::N; ++d) x[d] = tv.state[(size_t)d * tv.cap + pref];
-#pragma unroll
-        for (int j = 0; j < 2 * S::NW; ++j) trig[j] = tv.trig[(size_t)j * tv.cap + pref];
-#pragma unroll
-        for (int j = 0; j < S::M * S::N; ++j) K[j] = tv.K[(size_t)pref * S::M * S::N + j];
-    } else {
-        const double* pr = rec + (size_t)(~pref) * L.R;
-#pragma unroll
-        for (int d = 0; d < S::N; ++d) x[d] = pr[L.off_xend + d];
-#pragma unroll
-        for (int j = 0; j < 2 * S::NW; ++j) trig[j] = pr[L.off_trig + j];
-#pragma unroll
-        for (int j = 0; j < S::M * S::N; ++j) K[j] = pr[L.off_K + j];
-    }
+    if (!parent_loaded) load_parent(pref);
 
     STEER_TS(1);
+    BLK_T(blk_tq);
     int cnt = 0, steps = 0;
     bool grew = false, truncated = false;
     if constexpr (NWF >= 3) {
@@ -1082,6 +1164,14 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         duo.tr[0][0] = trig[0]; duo.tr[0][1] = trig[1];
         if constexpr (NWF == 4) { duo.tt[0] = ttrig[0]; duo.tt[1] = ttrig[1]; }
         __syncthreads();                                             // S
+        BLK_T(blk_t1);
+#ifdef STEER_TIMING
+        if (threadIdx.x == 0) {
+            const int mode = f.n_chunks > 0 ? 0 : (ron ? 1 : 2);
+            atomicAdd(&g_pro_acc[mode * 5 + 0], blk_tp - blk_t0); atomicAdd(&g_pro_acc[mode * 5 + 1], blk_tq - blk_tp);
+            atomicAdd(&g_pro_acc[mode * 5 + 2], blk_t1 - blk_tq); atomicAdd(&g_pro_acc[mode * 5 + 3], 1ull);
+        }
+#endif
         double tolr[S::N];
 #pragma unroll
         for (int d = 0; d < S::N; ++d) tolr[d] = tol_l[d];
@@ -1129,6 +1219,14 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         }
         cnt = duo.cnt; steps = duo.steps; grew = duo.grew != 0;
         truncated = true;                                            // x / trig / K ran ahead: the node comes from the history
+#ifdef STEER_TIMING
+        if (threadIdx.x == 0 && steps >= 20) {
+            const unsigned long long t2 = wall_clock64();
+            atomicAdd(&g_blk_acc[1], t2 - blk_t1); atomicMax(&g_blk_acc[4], t2 - blk_t1);
+            atomicAdd(&g_blk_acc[5], blk_t1 - blk_t0); atomicMax(&g_blk_acc[6], blk_t1 - blk_t0);
+            atomicAdd(&g_blk_acc[2], 1ull);
+        }
+#endif
     } else if constexpr (PLAIN2) {
         // main wavefront of the plain two-wavefront rollout: the steps; the other wavefront checks them one step behind
         duo.go = 1; duo.stop = 0; duo.cnt = 0; duo.steps = 0; duo.grew = 0; duo.truncated = 0;
@@ -1353,6 +1451,12 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         }
     }
     STEER_TS(5);
+#ifdef STEER_TIMING
+    if (threadIdx.x == 0 && steps >= 20) {
+        const unsigned long long t3 = wall_clock64();
+        atomicAdd(&g_blk_acc[0], t3 - blk_t0); atomicMax(&g_blk_acc[3], t3 - blk_t0);
+    }
+#endif
     }   // !round_skip
     if (!ron) return;
     // ---- end of a fused round: the last wavefront to get here closes it
