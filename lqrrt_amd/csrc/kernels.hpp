@@ -720,6 +720,7 @@ __device__ __forceinline__ bool rollout_check(const double* Pl, const Geo& g, co
 __device__ unsigned long long g_steer_ts[8];
 #define STEER_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_steer_ts[i] = wall_clock64(); } while (0)
 __device__ unsigned long long g_step_acc[8];        // per-phase ticks of the rollout loop of block 0, + step count
+__device__ unsigned long long g_loop_hist[32];
 __device__ unsigned long long g_blk_acc[8];
 __device__ unsigned long long g_pro_acc[16];        // prologue of rolling workgroups: [mode*5 + {to pref, parent loads, to S barrier, count}]         // full-horizon rollouts: sum kernel time, sum loop time, count, max kernel, max loop
 #define BLK_T(v) const unsigned long long v = wall_clock64()
@@ -1225,6 +1226,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             atomicAdd(&g_blk_acc[1], t2 - blk_t1); atomicMax(&g_blk_acc[4], t2 - blk_t1);
             atomicAdd(&g_blk_acc[5], blk_t1 - blk_t0); atomicMax(&g_blk_acc[6], blk_t1 - blk_t0);
             atomicAdd(&g_blk_acc[2], 1ull);
+            atomicAdd(&g_loop_hist[min(31, (int)((t2 - blk_t1) / 200))], 1ull);      // 2 us buckets
         }
 #endif
     } else if constexpr (PLAIN2) {

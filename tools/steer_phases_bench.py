@@ -42,3 +42,6 @@ for mode, name in enumerate(("speculative launch", "fused repair round (re-steer
     c = max(1, q[mode * 5 + 3])
     print("prologue, %-40s %6d workgroups: to the parent choice %.2f us | parent loads %.2f | until the helpers' barrier %.2f" % (
         name, q[mode * 5 + 3], q[mode * 5 + 0] * 0.01 / c, q[mode * 5 + 1] * 0.01 / c, q[mode * 5 + 2] * 0.01 / c))
+h = (C.c_ulonglong * 32)()
+nat.lib().lqrrt_debug_loop_hist(h)
+print("loop time of full-horizon rollouts, 2 us buckets:", " ".join("%d-%d:%d" % (2 * i, 2 * i + 2, h[i]) for i in range(32) if h[i]))
