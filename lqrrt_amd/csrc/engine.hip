@@ -611,6 +611,7 @@ static int upload_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys) {
         return 0;
     };
     e->geo.V = sys->n_vertices; e->geo.O = sys->n_obstacles;
+    for (int k = 0; k < 4; ++k) e->geo.hbb[k] = 0.0;
     e->geo.stride = sys->obs_stride > 0 ? sys->obs_stride : 3; e->geo.pad = 0;
     rc = up(&e->d_vps, sys->vps, (size_t)2 * sys->n_vertices);
     if (!rc) rc = up(&e->d_obs, sys->obs, (size_t)sys->n_obstacles * e->geo.stride);
@@ -626,9 +627,20 @@ static int upload_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys) {
             const double r = (sys->model == LQRRT_MODEL_BOAT_NOVICE) ? inflate + sys->obs[3 * o + 2] : sys->obs[3 * o + 2];
             oc[4 * o] = sys->obs[3 * o]; oc[4 * o + 1] = sys->obs[3 * o + 1];
             oc[4 * o + 2] = exact_sq_threshold(r);
-            const double reach = (r + hull_r) * (1.0 + 1e-9) + 1e-9;
-            oc[4 * o + 3] = (r >= 0.0) ? reach * reach : -1.0;
+            oc[4 * o + 3] = (r >= 0.0) ? r * (1.0 + 1e-9) + 1e-9 : -1e300;      // padded radius for the cull (never near if invalid)
         }
+        double bb[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int v = 0; v < sys->n_vertices; ++v) {
+            const double bx = sys->vps[v], by = sys->vps[sys->n_vertices + v];
+            if (v == 0) { bb[0] = bb[1] = bx; bb[2] = bb[3] = by; }
+            bb[0] = std::min(bb[0], bx); bb[1] = std::max(bb[1], bx);
+            bb[2] = std::min(bb[2], by); bb[3] = std::max(bb[3], by);
+        }
+        for (int k = 0; k < 4; ++k) {
+            const double pad = 1e-9 * (1.0 + std::fabs(bb[k]));
+            e->geo.hbb[k] = (k & 1) ? bb[k] + pad : bb[k] - pad;
+        }
+        (void)hull_r;
         rc = up(&e->d_oc, oc.data(), (size_t)4 * sys->n_obstacles);
         e->geo.oc = e->d_oc;
     }

@@ -54,13 +54,15 @@ struct Geo {
     int ogc_rows, ogc_cols, og_lds;      // og_lds: the hull points fit in LDS next to the edge history
     double og_reach;
     double og_bb[4];                     // body-frame bounding box of the hull points: xmin, xmax, ymin, ymax (inflated)
+    double hbb[4];                       // the same box, padded, for the circle sweep's cull (hull_hits)
 };
 constexpr int OG_COARSE_SHIFT = 3;
 
 struct GeoL {            // LDS-resident copy used inside a workgroup
     const double* vps;   // [2][V]
-    const double* oc;    // [O][4]
+    const double* oc;    // [O][4]: centre x, y | exact threshold on the squared distance | padded radius (cull)
     int V, O;
+    double bb[4];        // padded body-frame bounding box of the hull points (cull)
 };
 
 __device__ __forceinline__ size_t geo_lds_doubles(const Geo& g) {
@@ -73,6 +75,8 @@ __device__ __forceinline__ GeoL stage_geo(const Geo& g, double* lds, int tid, in
     GeoL L;
     L.V = g.V; L.O = g.O;
     L.vps = lds; L.oc = lds + 2 * g.V;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) L.bb[k] = g.hbb[k];
     if (g.og) {                                // occupancy-grid model: only the hull points are staged
         if (g.og_lds) { for (int i = tid; i < 2 * g.V; i += nthreads) lds[i] = g.vps[i]; }
         else L.vps = g.vps;
@@ -219,9 +223,13 @@ __device__ __forceinline__ bool hull_hits(const GeoL& g, double px, double py, d
         const int o = o0 + lane;
         bool near = false;
         if (o < g.O) {
-            const double ox = g.oc[4 * o], oy = g.oc[4 * o + 1];
-            const double dx = px - ox, dy = py - oy;
-            near = (dx * dx + dy * dy) <= g.oc[4 * o + 3];
+            // cull: an obstacle can only contain a hull point if its centre, seen from the vehicle's frame, lies within the
+            // hull's bounding box grown by the (padded) radius -- much tighter than a bounding circle for a 2:1 hull, and
+            // conservative (padding 1e-9 >> the rounding of these few operations), so the exact tests below decide as before
+            const double ox = g.oc[4 * o], oy = g.oc[4 * o + 1], rp = g.oc[4 * o + 3];
+            const double dx = ox - px, dy = oy - py;
+            const double cbx = c * dx + s * dy, cby = c * dy + ms * dx;
+            near = (cbx >= g.bb[0] - rp) && (cbx <= g.bb[1] + rp) && (cby >= g.bb[2] - rp) && (cby <= g.bb[3] + rp);
             if (extra2p) {
                 const double ex = (px + px) - ox, ey = (py + py) - oy;
                 hit |= (ex * ex + ey * ey) <= g.oc[4 * o + 2];

@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = "/tmp/liblqrrt_STEER_TIMING.so"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                       "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "lqrrt_amd/csrc/engine.hip"), "-o", so, "-DSTEER_TIMING"])
+                       "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "lqrrt_amd/csrc/engine.hip"), "-o", so, "-DSTEER_TIMING"]
+                      + ["-D" + d for d in os.environ.get("STEER_DEFINES", "").split(",") if d])
 if len(sys.argv) > 1:
     os.environ["LQRRT_STEER_WAVEFRONTS"] = sys.argv[1]
 import lqrrt_amd._native as nat
