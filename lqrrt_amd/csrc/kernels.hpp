@@ -768,6 +768,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             if (!duo.go) return;
             const double tt0 = duo.tt[0], tt1 = duo.tt[1];
             for (int k = 0;; ++k) {
+                STEP_TS(ds0);
                 const bool alive = !duo.finp[k & 1];
                 double tn[2];
                 if (alive) {
@@ -781,6 +782,8 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
 #pragma unroll
                     for (int j = 0; j < S::M * S::N; ++j) duo.Kb[(k + 1) & 1][j] = Kn[j];
                 }
+                STEP_TS(ds1);
+                STEP_ACC(7, ds0, ds1);
                 __syncthreads();                                            // Y_k
                 if (duo.stop) return;
                 // erf's angle error of step k + 1 (planner.py:386): wrap_err(target, next heading)
@@ -804,6 +807,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             int cnt = 0, steps = 0;
             for (int k = 0;; ++k) {
                 double xn[S::N], trn[2], e[S::N], u[S::M];
+                STEP_TS(cs0);
 #pragma unroll
                 for (int d = 0; d < S::N; ++d) { xn[d] = duo.pk[d]; e[d] = duo.eu[(k + 1) & 1][d]; }
                 trn[0] = duo.tr[k & 1][0]; trn[1] = duo.tr[k & 1][1];
@@ -812,6 +816,8 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
                 const bool fin = duo.finp[k & 1] != 0;
                 bool stop = false;
                 if (k >= 1) stop = rollout_check<S>(Pl, g, gl, r, xn, trn, e, u, lane, cnt, steps, last, tolr, hx, hu, htr, duo);
+                STEP_TS(cs1);
+                STEP_ACC(5, cs0, cs1);
                 __syncthreads();                                            // Y_k
                 if (duo.stop) return;
                 if (NWF == 3 && !fin && !stop) {
@@ -833,6 +839,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             __syncthreads();                                                // S
             if (!duo.go) return;
             for (int k = 0;; ++k) {
+                STEP_TS(ps0);
                 if (!duo.finp[k & 1]) {
                     double xk[S::N], tk[2];
 #pragma unroll
@@ -840,6 +847,8 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
                     tk[0] = duo.tr[k & 1][0]; tk[1] = duo.tr[k & 1][1];
                     duo.rud = S::duo_chain(Pl, xk, tk);
                 }
+                STEP_TS(ps1);
+                STEP_ACC(6, ps0, ps1);
                 __syncthreads();                                            // Y_k
                 if (duo.stop) return;
                 __syncthreads();                                            // X_k+1

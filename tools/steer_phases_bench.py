@@ -32,6 +32,8 @@ d = [acc[i] - acc0[i] for i in range(8)]
 n = max(1, d[3])
 print("wavefronts %s: block 0 of every steer launch, %d steps: phase 1 %.0f ns | wait Y %.0f | phase 2 %.0f | wait X %.0f  (each timestamp read adds ~25-50 ns)" % (
     os.environ.get("LQRRT_STEER_WAVEFRONTS", "auto"), n, d[0] * 10.0 / n, d[1] * 10.0 / n, d[2] * 10.0 / n, d[4] * 10.0 / n))
+print("phase 1 of the other wavefronts (block 0, ns per step): checking %.0f | heading torque %.0f | next heading %.0f" % (
+    d[5] * 10.0 / n, d[6] * 10.0 / n, d[7] * 10.0 / n))
 b = (C.c_ulonglong * 8)()
 nat.lib().lqrrt_debug_blk_acc(b)
 m = max(1, b[2])
