@@ -1719,7 +1719,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     // launch after the converged round, so there must be room for every sample (otherwise the legacy path reports
     // LQRRT_E_CAPACITY before anything is written).
     const bool fused = mat && e->wave_complete && e->spec_fusable && !e->sync_mode && fused_rounds_enabled() &&
-                       (int64_t)e->N + W <= (int64_t)e->cap;
+                       (int64_t)e->N + W <= (int64_t)e->cap && W <= 256;      // (the round prologue keeps 4 x 64 samples' flags in registers)
     e->spec_fusable = false;
     if (mat && !e->wave_complete) {
         if (e->d_S) { DISPATCH(e, hipLaunchKernelGGL((k_wave_rows<S, true>), dim3(W), dim3(64), 0, st, e->d_rec, e->L, xs, e->d_S, e->d_M, W)); }
