@@ -208,7 +208,9 @@ int lqrrt_tree_load(lqrrt_engine* e, int count, const double* states_host, const
                     const uint8_t* ignored_host, void* stream);
 
 /* Forgets every node with id >= size (nodes are only ever appended, so the first `size` nodes are exactly the tree
- * as it stood when it had that size).  Ignore bits of the dropped nodes are cleared, those of kept nodes stay. */
+ * as it stood when it had that size).  Ignore bits of the dropped nodes are cleared, those of kept nodes stay: if a
+ * dropped node was a goal hit, the caller restates the ignore set of the kept nodes with lqrrt_tree_set_ignored.  The best
+ * plan is forgotten if its end node was dropped; a mark (lqrrt_tree_mark) beyond the new size becomes void. */
 int lqrrt_tree_truncate(lqrrt_engine* e, int size);
 
 /* Overwrites the ignore bits of nodes [first, first+count) (planner.py:270 `ignores`). */

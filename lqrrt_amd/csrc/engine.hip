@@ -990,6 +990,7 @@ extern "C" int lqrrt_tree_reset(lqrrt_engine* e, const double* x0_host, void* st
     std::fill(e->h_ign.begin(), e->h_ign.end(), 0ull);
     e->ign_dirty = false;
     e->goal_hits = 0; e->best_end = -1; e->best_steps = -1;
+    e->mark_N = 0;                                           // a mark of the previous tree must not be rewound to
     memset(&e->tot, 0, sizeof e->tot);
     e->tot.tree_size = 1;
     e->ctl_w = 0.0;
@@ -1142,6 +1143,7 @@ extern "C" int lqrrt_tree_load(lqrrt_engine* e, int count, const double* states,
     TRY(flush_ignore(e, st, false));
     HIPCHK(hipStreamSynchronize(st));
     e->goal_hits = 0; e->best_end = -1; e->best_steps = -1;
+    e->mark_N = 0;
     e->tot.tree_size = count;
     e->ctl_w = 0.0;
     return 0;
@@ -1156,7 +1158,12 @@ extern "C" int lqrrt_tree_truncate(lqrrt_engine* e, int size) {
     e->ign_dirty = true;
     e->N = size;
     e->h_pid.resize(size); e->h_elen.resize(size);
+    // Goal bookkeeping of the dropped nodes goes with them: the best plan is forgotten if its end node is gone, and a mark
+    // beyond the new size is void.  Which of the KEPT nodes are ignored is the caller's statement (the bits of kept nodes
+    // stay as they are; lqrrt_tree_set_ignored replaces them, which is what the teacher-forced replay does): the engine
+    // cannot tell a goal path whose end was dropped from one that is still there without re-testing every node.
     if (e->best_end >= size) { e->best_end = -1; e->best_steps = -1; e->goal_hits = 0; }
+    if (e->mark_N > size) e->mark_N = 0;
     e->tot.tree_size = size;
     return 0;
 }

@@ -38,6 +38,7 @@ class Engine(object):
             nat.check(nat.lib().lqrrt_engine_set_dense_S(self.h, nat.ptr(S)))
         self.horizon_iters = None
         self.generation = 0           # bumped whenever the tree is replaced (reset / load): Tree views check it
+        self.epoch = 0                # bumped whenever nodes can change behind a view's back (truncate / rewind / re-layout)
 
     def _stream(self):
         """torch's current HIP stream on THIS engine's device."""
@@ -96,7 +97,10 @@ class Engine(object):
                 r.goal_lo[i] = g[i] - b[i]        # planner.py:482-484
                 r.goal_hi[i] = g[i] + b[i]
         nat.check(nat.lib().lqrrt_engine_set_resolution(self.h, C.byref(r)))
+        if self.horizon_iters is not None and int(horizon_iters) != self.horizon_iters:
+            self.generation += 1      # the edge pools were re-laid out and the tree emptied: bound Tree views are dead
         self.horizon_iters = int(horizon_iters)
+        self.epoch += 1
 
     def horizon_iters_state(self):
         return nat.check(nat.lib().lqrrt_engine_horizon_iters(self.h))
@@ -163,6 +167,7 @@ class Engine(object):
 
     def tree_truncate(self, size):
         nat.check(nat.lib().lqrrt_tree_truncate(self.h, int(size)))
+        self.epoch += 1
 
     def set_ignored(self, flags, first=0):
         flags = np.ascontiguousarray(flags, dtype=np.uint8)
@@ -182,6 +187,7 @@ class Engine(object):
 
     def tree_rewind(self):
         nat.check(nat.lib().lqrrt_tree_rewind(self.h))
+        self.epoch += 1
 
     @property
     def size(self):

@@ -391,6 +391,13 @@ class Planner:
         """Withdraws a kill_update that has not been honoured yet."""
         self.killed = False
 
+    def visualize(self, dx, dy, show=True):
+        """Plots the (dx, dy) cross-section of the tree with the current plan highlighted (planner.py:614-624)."""
+        if not hasattr(self, "node_seq"):
+            print("There is no plan to visualize!")
+            return None
+        return self.tree.visualize(dx, dy, node_seq=self.node_seq, show=show)
+
 
 def _add_stats(a, b):
     out = nat.ExtendStats()

@@ -113,9 +113,10 @@ class Tree:
         return self._ndev() + len(self._h_pID)
 
     def _fresh(self):
-        n = self._ndev()
-        if n != self._cache_size:
-            self._cache, self._cache_size = {}, n
+        # keyed on (size, epoch): a truncate or rewind followed by regrowth to the same size must not serve old nodes
+        key = (self._ndev(), getattr(self._e, "epoch", 0))
+        if key != self._cache_size:
+            self._cache, self._cache_size = {}, key
         return self._cache
 
     @property
@@ -191,3 +192,34 @@ class Tree:
             xs += list(ex)
             us += list(eu)
         return (xs, us)
+
+    def visualize(self, dx, dy, node_seq=None, show=True):
+        """
+        Plots the (dx, dy) cross-section of the tree and highlights the path `node_seq` (tree.py:136-171).  Every edge
+        is drawn from its parent's state through its recorded states; the edges come out of HBM in one bulk copy.
+        Returns the matplotlib figure (show=False leaves it open for the caller).
+        """
+        from matplotlib import pyplot as plt
+        from matplotlib.collections import LineCollection
+        state, parents = self.state, self.pID
+        on_path = set(int(i) for i in (node_seq if node_seq is not None else []))
+        plain, marked = [], []
+        for i in range(1, self.size):
+            pts = np.vstack([state[parents[i]][None, :], np.array(self.x_seq[i], dtype=np.float64).reshape(-1, self.nstates)])
+            (marked if i in on_path else plain).append(pts[:, [dx, dy]])
+        fig, ax = plt.subplots()
+        fig.suptitle("Tree")
+        ax.add_collection(LineCollection(plain, colors="0.75", zorder=1))
+        ax.add_collection(LineCollection(marked, colors="r", zorder=2))
+        ax.scatter(state[0, dx], state[0, dy], color="b", s=48)
+        if on_path:
+            last = int(list(node_seq)[-1])
+            ax.scatter(state[last, dx], state[last, dy], color="r", s=48)
+        ax.set_xlabel("- State {} +".format(dx))
+        ax.set_ylabel("- State {} +".format(dy))
+        ax.grid(True)
+        ax.autoscale()
+        ax.set_aspect("equal", adjustable="datalim")
+        if show:
+            plt.show()
+        return fig

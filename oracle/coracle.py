@@ -29,6 +29,7 @@ def lib():
         L.orc_extend_sync.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p]
         L.orc_enable_trace.argtypes = [C.c_void_p, C.c_longlong]
         L.orc_get_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
+        L.orc_get_trace_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
         L.orc_set_resolution.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int] + [C.c_void_p] * 4
         L.orc_set_ogrid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
         L.orc_load_tree.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
@@ -176,6 +177,12 @@ class COracle(object):
         ln = np.empty(k, dtype=np.int32)
         lib().orc_get_trace(self.h, _p(near), _p(ln), k)
         return near, ln
+
+    def trace_samples(self):
+        """the sample of every traced iteration, (iterations, n)"""
+        xs = np.empty((self.iterations, self.n))
+        lib().orc_get_trace_samples(self.h, _p(xs), self.iterations)
+        return xs
 
     def nearest(self, x, S=None, pruning=False):
         x = _f(x)

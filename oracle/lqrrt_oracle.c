@@ -56,6 +56,7 @@ typedef struct {
     int best_end;
     long long best_steps;
     int *trace_near, *trace_len;
+    double* trace_x;                 /* the sample of every traced iteration, [cap][n] */
     long long trace_cap;
 } orc;
 
@@ -477,7 +478,7 @@ void orc_destroy(orc* o) {
     if (!o) return;
     free_tree(o);
     free(o->og);
-    free(o->vps); free(o->obs); free(o->trace_near); free(o->trace_len);
+    free(o->vps); free(o->obs); free(o->trace_near); free(o->trace_len); free(o->trace_x);
     free(o);
 }
 
@@ -525,9 +526,10 @@ void orc_reset(orc* o, const double* x0) {
 }
 
 void orc_enable_trace(orc* o, long long cap) {
-    free(o->trace_near); free(o->trace_len);
+    free(o->trace_near); free(o->trace_len); free(o->trace_x);
     o->trace_near = (int*)malloc(sizeof(int) * cap);
     o->trace_len = (int*)malloc(sizeof(int) * cap);
+    o->trace_x = (double*)malloc(sizeof(double) * (size_t)cap * o->n);
     o->trace_cap = cap;
 }
 
@@ -644,7 +646,7 @@ int orc_extend(orc* o, long long max_iters, long long max_nodes, int pruning, in
         sample(o, xs);
         const int near = nearest(o, xs, Sd, pruning);
         const int len = steer(o, near, xs, ex, eu);
-        if (o->trace_near && o->iterations < o->trace_cap) { o->trace_near[o->iterations] = near; o->trace_len[o->iterations] = len; }
+        if (o->trace_near && o->iterations < o->trace_cap) { o->trace_near[o->iterations] = near; o->trace_len[o->iterations] = len; memcpy(o->trace_x + (size_t)o->iterations * n, xs, sizeof(double) * n); }
         o->iterations++;
         ++done;
         if (len > 0) {
@@ -700,7 +702,7 @@ int orc_extend_sync(orc* o, int wave, long long max_iters, long long max_nodes, 
             sample(o, xs);
             const int near = nearest_upto(o, xs, Sd, pruning, N0);
             const int len = steer(o, near, xs, ex, eu);
-            if (o->trace_near && o->iterations < o->trace_cap) { o->trace_near[o->iterations] = near; o->trace_len[o->iterations] = len; }
+            if (o->trace_near && o->iterations < o->trace_cap) { o->trace_near[o->iterations] = near; o->trace_len[o->iterations] = len; memcpy(o->trace_x + (size_t)o->iterations * n, xs, sizeof(double) * n); }
             o->iterations++;
             ++done;
             if (len > 0) {
@@ -806,6 +808,7 @@ void orc_get_trace(const orc* o, int* near, int* len, long long count) {
     memcpy(near, o->trace_near, sizeof(int) * count);
     memcpy(len, o->trace_len, sizeof(int) * count);
 }
+void orc_get_trace_samples(const orc* o, double* xs, long long count) { memcpy(xs, o->trace_x, sizeof(double) * (size_t)count * o->n); }
 /* single-call operators for tests */
 void orc_dynamics(const orc* o, const double* x, const double* u, double* xn) {
     double tr[4], uc[MAXM];

@@ -27,7 +27,7 @@ TAGS = ["600", "2500"]
 def _fx(golden_dir, tag):
     path = os.path.join(golden_dir, "traj_double_integrator_%s.npz" % tag)
     if not os.path.exists(path):
-        pytest.skip("fixture missing")
+        pytest.fail("fixture missing: tests/golden is committed, a lost fixture must not turn into a pass")
     return np.load(path)
 
 

@@ -35,7 +35,7 @@ DEMOS = ["boat_advanced", "boat_intermediate", "boat_novice", "car", "pendulum"]
 def _load(golden_dir, fname):
     path = os.path.join(golden_dir, fname)
     if not os.path.exists(path):
-        pytest.skip("fixture %s missing" % fname)
+        pytest.fail("fixture %s missing: tests/golden is committed, a lost fixture must not turn into a pass" % fname)
     return np.load(path)
 
 

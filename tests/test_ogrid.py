@@ -12,7 +12,7 @@ import pytest
 def _fixture(golden_dir):
     path = os.path.join(golden_dir, "ops_ogrid.npz")
     if not os.path.exists(path):
-        pytest.skip("fixture missing")
+        pytest.fail("fixture missing: tests/golden is committed, a lost fixture must not turn into a pass")
     return np.load(path)
 
 

@@ -22,7 +22,7 @@ DEMO_SYSTEMS = ["boat_advanced", "boat_intermediate", "boat_novice", "car", "pen
 def _load(golden_dir, fname):
     path = os.path.join(golden_dir, fname)
     if not os.path.exists(path):
-        pytest.skip("fixture %s not generated" % fname)
+        pytest.fail("fixture %s missing: tests/golden is committed, a lost fixture must not turn into a pass" % fname)
     return np.load(path)
 
 

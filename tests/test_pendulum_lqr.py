@@ -27,7 +27,7 @@ X_ATOL = 1e-7
 def _fx(golden_dir):
     path = os.path.join(golden_dir, "traj_pendulum_lqr_120.npz")
     if not os.path.exists(path):
-        pytest.skip("fixture missing")
+        pytest.fail("fixture missing: tests/golden is committed, a lost fixture must not turn into a pass")
     return np.load(path)
 
 

@@ -27,7 +27,7 @@ def _states_close(name, got, want):
 def _fixture(golden_dir, name):
     path = os.path.join(golden_dir, "ros_%s.npz" % name)
     if not os.path.exists(path):
-        pytest.skip("fixture missing")
+        pytest.fail("fixture missing: tests/golden is committed, a lost fixture must not turn into a pass")
     return np.load(path)
 
 
@@ -166,7 +166,7 @@ def test_coracle_teacher_forced(golden_dir, name):
     import teacher
     g = _fixture(golden_dir, name)
     if "xrand_all" not in g.files:
-        pytest.skip("fixture has no teacher data")
+        pytest.fail("fixture has no teacher data (regenerate with tools/gen_golden.py)")
     s = _native(name, g)
     sch = teacher.Schedule(g, s.goal, np.abs(s.goal_buffer))
     o = coracle.make(s, len(sch.state) + 8, seed=1)
@@ -195,7 +195,7 @@ def test_hip_teacher_forced(golden_dir, name):
     from test_teacher_gpu import replay_hip
     g = _fixture(golden_dir, name)
     if "xrand_all" not in g.files:
-        pytest.skip("fixture has no teacher data")
+        pytest.fail("fixture has no teacher data (regenerate with tools/gen_golden.py)")
     s = _native(name, g)
     sch = teacher.Schedule(g, s.goal, np.abs(s.goal_buffer))
     kw = s.plan_kwargs

@@ -27,10 +27,10 @@ from systems_np import SYSTEMS, make_oracle_planner
 def _load(golden_dir, name, tag):
     path = os.path.join(golden_dir, "traj_%s_%s.npz" % (name, tag))
     if not os.path.exists(path):
-        pytest.skip("fixture missing")
+        pytest.fail("fixture missing: tests/golden is committed, a lost fixture must not turn into a pass")
     g = np.load(path)
     if "xrand_all" not in g.files:
-        pytest.skip("fixture has no teacher data")
+        pytest.fail("fixture has no teacher data (regenerate with tools/gen_golden.py)")
     return g
 
 

@@ -25,10 +25,10 @@ pytestmark = pytest.mark.gpu
 def _load(golden_dir, fname):
     path = os.path.join(golden_dir, fname)
     if not os.path.exists(path):
-        pytest.skip("fixture %s missing" % fname)
+        pytest.fail("fixture %s missing: tests/golden is committed, a lost fixture must not turn into a pass" % fname)
     g = np.load(path)
     if "xrand_all" not in g.files:
-        pytest.skip("fixture %s has no teacher data" % fname)
+        pytest.fail("fixture %s has no teacher data (regenerate with tools/gen_golden.py)" % fname)
     return g
 
 

@@ -492,7 +492,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--long", action="store_true", help="also run boat_advanced to 10k nodes (~20 min)")
     ap.add_argument("--only", default=None, help="comma list: ops,traj")
-    ap.add_argument("--job", default=None, help="one teacher / tie-audit job: adv10k, adv3000, car500u, car2000u, pend150u, "
+    ap.add_argument("--job", default=None, help="one teacher / tie-audit job: adv10k, adv10ku, adv3000, car500u, car2000u, pend150u, "
                                                 "car500t, car2000t, pend150t (u = unpatched reference, t = teacher data of the patched run)")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
@@ -510,6 +510,8 @@ def main():
         "car500u": lambda: run_traj("car", 500, keep_xrand=64, tag="500_unpatched", teacher=True, stable_ties=False),
         "car2000u": lambda: run_traj("car", 2000, keep_xrand=64, tag="2000_unpatched", teacher=True, stable_ties=False),
         "pend150u": lambda: run_traj("pendulum", 150, keep_xrand=64, tag="150_unpatched", teacher=True, stable_ties=False),
+        # the headline run (BASELINE config 4, 10k nodes) with nothing patched either (~20 min)
+        "adv10ku": lambda: run_traj("boat_advanced", 10000, keep_xrand=64, tag="10k_unpatched", teacher=True, stable_ties=False),
         # BASELINE config 5 on the reference's Planner with the build's NumPy callbacks
         "di600": lambda: gen_config5(600, 3000),
         "di2500": lambda: gen_config5(2500, 3000),
