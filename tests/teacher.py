@@ -11,7 +11,30 @@ with no planner of ours in the loop.  A backend (C oracle, HIP engine) then has 
 from the reference's tree for every t: errors cannot accumulate, so chaotic dynamics (boat_advanced near
 standstill) show up as isolated, countable mismatches instead of a divergence point.
 """
+import os
+
 import numpy as np
+
+
+class Fixture(dict):
+    """dict of a fixture's arrays with np.load's `.files`."""
+
+    @property
+    def files(self):
+        return list(self.keys())
+
+
+def load_fixture(path):
+    """np.load of a traj_* fixture.  A compact `*_unpatched` fixture (tools/gen_golden.py compact_unpatched) lists the arrays
+    that are identical to its patched twin's in `same_as_patched`; they are taken from that file."""
+    g = np.load(path)
+    if "same_as_patched" not in g.files:
+        return g
+    twin = np.load(path.replace("_unpatched", ""))
+    out = Fixture({k: g[k] for k in g.files if k != "same_as_patched"})
+    for k in g["same_as_patched"]:
+        out[str(k)] = twin[str(k)]
+    return out
 
 
 class Schedule(object):

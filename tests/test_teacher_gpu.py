@@ -26,7 +26,7 @@ def _load(golden_dir, fname):
     path = os.path.join(golden_dir, fname)
     if not os.path.exists(path):
         pytest.fail("fixture %s missing: tests/golden is committed, a lost fixture must not turn into a pass" % fname)
-    g = np.load(path)
+    g = teacher.load_fixture(path)
     if "xrand_all" not in g.files:
         pytest.fail("fixture %s has no teacher data (regenerate with tools/gen_golden.py)" % fname)
     return g
@@ -105,6 +105,24 @@ def test_boat_advanced_teacher_forced(golden_dir, tag):
     assert r["nearest_miss"] == 0 and r["steer_len_mismatch"] == 0 and r["end_state_max_err"] < 1e-9
     assert r["end_state_compared"] == len(sch.state) - 1
     assert r["gain_max_err"] < 1e-8
+
+
+def test_boat_advanced_10k_unpatched_teacher_forced(golden_dir):
+    """The headline run of the reference with NOTHING patched (numpy's own argsort tie order): the engine's lowest-id rule
+    picks another node than numpy in 4 of 36,936 decisions, each time a node of bit-equal cost; steering from numpy's
+    choice reproduces the unpatched run's edge lengths and nodes."""
+    import lqrrt_amd
+    g = _load(golden_dir, "traj_boat_advanced_10k_unpatched.npz")
+    assert not bool(g["stable_ties"])
+    s = lqrrt_amd.systems.SYSTEMS["boat_advanced"](0)
+    sch = teacher.Schedule(g, s.goal, s.goal_buffer)
+    kw = s.plan_kwargs
+    r = replay_hip(s, sch, kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]))
+    _record("boat_advanced_10k_unpatched", r)
+    assert r["iterations"] == 36936
+    assert r["nearest_miss"] == 4 and r["nearest_miss_max_rel_gap"] == 0.0
+    assert r["steer_len_mismatch"] == 0 and r["end_state_max_err"] < 1e-9
+    assert r["end_state_compared"] == len(sch.state) - 1
 
 
 @pytest.mark.parametrize("name,tag,exact", [("boat_intermediate", "300", True), ("boat_novice", "300", True),

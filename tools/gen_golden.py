@@ -236,6 +236,28 @@ def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None, horizon=N
         bool(planner.plan_reached_goal), int(np.sum(ties)), wall))
 
 
+def compact_unpatched(name, tag):
+    """A 10k-node teacher fixture is 2.5 MB.  The unpatched twin of the headline run differs from the patched one in a handful
+    of parents / nearest choices only (bit-equal-cost ties), so it is committed as: every array that differs, plus the list of
+    arrays that are IDENTICAL to the patched fixture's (asserted here, on the full output of the unpatched run) -- the tests
+    take those from the patched file."""
+    full = os.path.join(OUT, "traj_%s_%s_unpatched.npz" % (name, tag))
+    a = np.load(os.path.join(OUT, "traj_%s_%s.npz" % (name, tag)))
+    b = np.load(full)
+    assert not bool(b["stable_ties"]) and bool(a["stable_ties"])
+    same, keep = [], {}
+    for k in b.files:
+        if k in a.files and a[k].shape == b[k].shape and np.array_equal(a[k], b[k]):
+            same.append(k)
+        else:
+            keep[k] = b[k]
+    for k in ("state", "K", "xrand_all", "edge_len", "steer_len", "last_u", "tie_mask"):
+        assert k in same, "%s differs between the patched and the unpatched run: keep the full fixture" % k
+    keep["same_as_patched"] = np.array(sorted(same))
+    np.savez_compressed(full, **keep)
+    print("compacted %s: kept %s, %d arrays identical to the patched fixture" % (full, sorted(keep), len(same)))
+
+
 # --------------------------------------------------------------------------- occupancy grid (8f-3)
 
 def gen_ogrid():
@@ -511,7 +533,8 @@ def main():
         "car2000u": lambda: run_traj("car", 2000, keep_xrand=64, tag="2000_unpatched", teacher=True, stable_ties=False),
         "pend150u": lambda: run_traj("pendulum", 150, keep_xrand=64, tag="150_unpatched", teacher=True, stable_ties=False),
         # the headline run (BASELINE config 4, 10k nodes) with nothing patched either (~20 min)
-        "adv10ku": lambda: run_traj("boat_advanced", 10000, keep_xrand=64, tag="10k_unpatched", teacher=True, stable_ties=False),
+        "adv10ku": lambda: (run_traj("boat_advanced", 10000, keep_xrand=64, tag="10k_unpatched", teacher=True, stable_ties=False),
+                            compact_unpatched("boat_advanced", "10k")),
         # BASELINE config 5 on the reference's Planner with the build's NumPy callbacks
         "di600": lambda: gen_config5(600, 3000),
         "di2500": lambda: gen_config5(2500, 3000),
