@@ -345,6 +345,43 @@ int lqrrt_engine_extend(lqrrt_engine* e, int wave, int64_t max_attempts, int64_t
                         int until_size, int pruning, int stop_on_goal,
                         lqrrt_extend_stats* out, void* stream);
 
+/* ---- sharded waves over the GPUs of one node, natively (one process per GPU) ----
+ * The reference is single-threaded (planner.py:233-290); this is the build's own multi-GPU form of that loop.  Every rank
+ * holds the whole tree and the same sample stream, every wave has ONE collective (RCCL all-gather on `stream`), and the
+ * commit is replicated, so the replicas stay bit-identical and equal to the single-GPU tree.
+ *
+ * Communicator: librccl.so is resolved at run time (the copy already loaded in the process -- PyTorch's -- if any;
+ * LQRRT_RCCL names another).  Rank 0 calls lqrrt_comm_unique_id and hands the 128 bytes to the other ranks by any means
+ * (lqrrt_amd/parallel.py broadcasts them with torch.distributed); every rank then calls lqrrt_comm_create.
+ * lqrrt_comm_create_loopback is a test double: one process plays `rank` of `world` and computes what the other ranks would
+ * contribute itself, through the same blocks and unpack path, on one GPU. */
+typedef struct lqrrt_comm lqrrt_comm;
+#define LQRRT_COMM_RCCL      0
+#define LQRRT_COMM_LOOPBACK  1
+int lqrrt_comm_unique_id(uint8_t* id128);
+int lqrrt_comm_create(const uint8_t* id128, int rank, int world, int device, lqrrt_comm** out);
+int lqrrt_comm_create_loopback(int rank, int world, lqrrt_comm** out);
+int lqrrt_comm_destroy(lqrrt_comm* c);
+
+/* LQRRT_SHARD_SAMPLES (north_star's scheme): rank g speculates samples [g*ceil(W/G), ...) of the wave; what the others need
+ * of its records -- {cost, parent, len, flags, xend, trig, K} per sample + the edges of the samples that added a node,
+ * compacted -- is written into the rank's all-gather block by the speculative launch itself; blocks are gathered in place;
+ * one kernel unpacks them into the local records and prepares the repair rounds.  A block's edge tail holds
+ * LQRRT_SHARD_TAIL (default 0.4) of the worst case; a sample whose edge did not fit is re-steered by the receivers.
+ * LQRRT_SHARD_TREE (SURVEY 8e's alternative for large trees): lqrrt_wave_scan_nodes over 1/G of the nodes, all-gather of
+ * 16*W bytes per rank, lqrrt_wave_steer_candidates. */
+#define LQRRT_SHARD_SAMPLES  0
+#define LQRRT_SHARD_TREE     1
+
+/* SURVEY 8(b) `lqrrt_allgather_nodes`: one sample-sharded wave of W samples up to, not including, its commit (speculate
+ * this rank's slice, exchange, unpack); lqrrt_wave_commit follows. */
+int lqrrt_allgather_nodes(lqrrt_engine* e, lqrrt_comm* c, int W, void* stream);
+
+/* lqrrt_engine_extend with sharded waves: same arguments and stopping rules, same tree on every rank. */
+int lqrrt_engine_extend_sharded(lqrrt_engine* e, lqrrt_comm* c, int scheme, int wave, int64_t max_attempts,
+                                int64_t node_limit, int until_size, int pruning, int stop_on_goal,
+                                lqrrt_extend_stats* out, void* stream);
+
 /* Goal bookkeeping (planner.py:260-283): number of goal hits so far and the node id of
  * the best (shortest, first on ties) plan end, its length in steps; -1 if none. */
 int lqrrt_plan_best(lqrrt_engine* e, int32_t* end_node, int64_t* steps, int64_t* hits);

@@ -102,6 +102,12 @@ SIGNATURES = {
     "lqrrt_wave_steer_candidates": (_I, [_P, _I, _I, _P, _P]),
     "lqrrt_wave_commit": (_I, [_P, _I, _I64, _I64, _I, C.POINTER(ExtendStats), _P]),
     "lqrrt_engine_extend": (_I, [_P, _I, _I64, _I64, _I, _I, _I, C.POINTER(ExtendStats), _P]),
+    "lqrrt_comm_unique_id": (_I, [_P]),
+    "lqrrt_comm_create": (_I, [_P, _I, _I, _I, C.POINTER(_P)]),
+    "lqrrt_comm_create_loopback": (_I, [_I, _I, C.POINTER(_P)]),
+    "lqrrt_comm_destroy": (_I, [_P]),
+    "lqrrt_allgather_nodes": (_I, [_P, _P, _I, _P]),
+    "lqrrt_engine_extend_sharded": (_I, [_P, _P, _I, _I, _I64, _I64, _I, _I, _I, C.POINTER(ExtendStats), _P]),
     "lqrrt_plan_best": (_I, [_P, C.POINTER(C.c_int32), C.POINTER(_I64), C.POINTER(_I64)]),
     "lqrrt_engine_counters": (_I, [_P, C.POINTER(ExtendStats)]),
     "lqrrt_profile_enable": (_I, [_P, _I]),

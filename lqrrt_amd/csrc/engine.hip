@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <dlfcn.h>
 #include <chrono>
 
 #include <algorithm>
@@ -159,6 +160,11 @@ struct lqrrt_engine {
     int* h_round = nullptr;       // pinned + mapped [8 + 3*maxW]: hz, round words (2 parities), summary
     int* h_round_dev = nullptr;
     bool spec_fusable = false;    // the last speculative launch prepared buffer 0 of the fused rounds
+    // sample-/tree-sharded waves (lqrrt_engine_extend_sharded): the ranks' all-gather blocks, the tail cursor of this rank's
+    bool wave_prepared = false;   // the records of the current wave came through lqrrt_allgather_nodes (k_shard_unpack_prep)
+    double* d_blk = nullptr;
+    size_t blk_cap = 0;           // doubles
+    int* d_blk_cursor = nullptr;
     int seq = 0;                  // sequence number of the last k_decide
     bool wave_complete = false;   // the last speculate covered the whole wave (single-GPU path)
     static constexpr int MAXCH = 1024;
@@ -528,7 +534,8 @@ static void free_all(lqrrt_engine* e) {
                     e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_M,
                     e->d_pidx, e->d_par_done, e->d_par_want, e->d_list,
                     e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_pool_trig, e->d_pool_S, e->d_QR, e->d_Sop, e->d_cand, e->d_flags,
-                    e->d_M2, e->d_lf[0], e->d_lf[1], e->d_par2, e->d_stale2, e->d_changed2, e->d_rctl, e->d_rank};
+                    e->d_M2, e->d_lf[0], e->d_lf[1], e->d_par2, e->d_stale2, e->d_changed2, e->d_rctl, e->d_rank,
+                    e->d_blk, e->d_blk_cursor};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_ign_pin) (void)hipHostFree(e->h_ign_pin);
@@ -1518,8 +1525,17 @@ extern "C" int lqrrt_wave_records(lqrrt_engine* e, void** p) {
     return 0;
 }
 
+// where the speculative launch of a sample-sharded wave also leaves this rank's records (SteerFuse::sh_*)
+struct ShardOut { double* hdr; double* tail; int* cursor; int hd, tb; };
+static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, const ShardOut* so);
+
 extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void* stream) {
+    return speculate_impl(e, W, lo, hi, stream, nullptr);
+}
+
+static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, const ShardOut* so) {
     if (!e) return fail(LQRRT_E_ARG, "null engine");
+    e->wave_prepared = false;
     if (W < 1 || W > e->maxW || lo < 0 || hi > W || lo > hi) return fail(LQRRT_E_ARG, "bad wave slice");
     if (!e->has_res) return fail(LQRRT_E_STATE, "set_resolution first");
     if (e->N < 1) return fail(LQRRT_E_STATE, "no tree: call lqrrt_tree_reset");
@@ -1559,6 +1575,7 @@ extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void
         if (e->riccati) { f.Sd = wave_sample_S(e); f.s_stride = (long long)e->n * e->n; }
         e->spec_fusable = f.M != nullptr;
         if (e->spec_fusable) { f.lf0 = e->d_lf[0]; f.round_ctl = e->d_rctl; }
+        if (so) { f.sh_hdr = so->hdr; f.sh_tail = so->tail; f.sh_cursor = so->cursor; f.sh_hd = so->hd; f.sh_tb = so->tb; }
         TRY(launch_steer(e, xs, nullptr, lo, cnt, e->d_par_done, st, nullptr, &f));
         if (hostprof_on()) { const double hp3 = now_us(); g_hp.flush += hp1 - hp0; g_hp.nn += hp2 - hp1; g_hp.steer += hp3 - hp2; g_hp.waves++; }
     } else {
@@ -1694,9 +1711,21 @@ extern "C" int lqrrt_wave_suggest(lqrrt_engine* e, int wave_cap) {
     return pick_wave(e, wave_cap);
 }
 
+static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_limit, int pruning, lqrrt_extend_stats* out,
+                       void* stream, bool prepared);
+
 extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_limit, int pruning,
                                  lqrrt_extend_stats* out, void* stream) {
+    return commit_impl(e, W, max_commit, node_limit, pruning, out, stream, false);
+}
+
+// prepared: a gathered wave whose bookkeeping (parents in use, flags, in-wave matrix rows, buffer 0 of the fused rounds) was
+// set up by k_shard_unpack_prep -- it runs the same rounds as a wave speculated here as a whole
+static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_limit, int pruning, lqrrt_extend_stats* out,
+                       void* stream, bool prepared) {
     if (!e) return fail(LQRRT_E_ARG, "null engine");
+    prepared = prepared || e->wave_prepared;
+    e->wave_prepared = false;
     if (W < 1 || W > e->maxW) return fail(LQRRT_E_ARG, "bad wave size");
     TRY(use_device(e));
     hipStream_t st = (hipStream_t)stream;
@@ -1705,7 +1734,7 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     memset(&ws, 0, sizeof ws);
     ws.waves = 1;
 
-    if (!e->wave_complete) {
+    if (!e->wave_complete && !prepared) {
         // sharded wave: parents of the records that came from other ranks (all-gather) are only in the records
         hipLaunchKernelGGL(k_par_from_records, dim3((W + 255) / 256), dim3(256), 0, st, e->d_rec, e->L, W, e->d_par_done);
         HIPCHK(hipMemsetAsync(e->d_changed, 0, W, st));
@@ -1725,10 +1754,10 @@ extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int
     // Fused repair rounds (RoundArgs in kernels.hpp): whole waves speculated here in matrix mode; the append is the
     // launch after the converged round, so there must be room for every sample (otherwise the legacy path reports
     // LQRRT_E_CAPACITY before anything is written).
-    const bool fused = mat && e->wave_complete && e->spec_fusable && !e->sync_mode && fused_rounds_enabled() &&
+    const bool fused = mat && ((e->wave_complete && e->spec_fusable) || prepared) && !e->sync_mode && fused_rounds_enabled() &&
                        (int64_t)e->N + W <= (int64_t)e->cap && W <= 256;      // (the round prologue keeps 4 x 64 samples' flags in registers)
     e->spec_fusable = false;
-    if (mat && !e->wave_complete) {
+    if (mat && !e->wave_complete && !prepared) {
         if (e->d_S) { DISPATCH(e, hipLaunchKernelGGL((k_wave_rows<S, true>), dim3(W), dim3(64), 0, st, e->d_rec, e->L, xs, e->d_S, e->d_M, W)); }
         else { DISPATCH(e, hipLaunchKernelGGL((k_wave_rows<S, false>), dim3(W), dim3(64), 0, st, e->d_rec, e->L, xs, nullptr, e->d_M, W)); }
     }
@@ -1931,6 +1960,260 @@ extern "C" int lqrrt_engine_extend(lqrrt_engine* e, int wave, int64_t max_attemp
         TRY(lqrrt_wave_speculate(e, W, 0, W, stream));
         lqrrt_extend_stats ws;
         TRY(lqrrt_wave_commit(e, W, cap_attempts, lim, pruning, &ws, stream));
+        acc.attempts += ws.attempts; acc.accepted += ws.accepted; acc.waves += 1;
+        acc.fix_rounds += ws.fix_rounds; acc.resteers += ws.resteers; acc.goal_hits += ws.goal_hits;
+        if (stop_on_goal && ws.goal_hits) { acc.stop_reason = LQRRT_STOP_GOAL; break; }
+    }
+    acc.tree_size = e->N;
+    acc.candidates = e->committed_row;
+    acc.speculated = e->tot.speculated - spec0;
+    if (out) *out = acc;
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// Sharded waves over the GPUs of one node, natively (the loop of lqrrt_engine_extend with ONE collective per
+// wave and no host language in it).  One process per GPU; every rank holds the whole tree and the same sample stream.
+//
+// RCCL is not linked: librccl.so is looked up at run time -- the copy the process has loaded already (PyTorch's) if there is
+// one -- and six entry points are resolved from it.  The communicator is made here from a unique id that rank 0 creates and
+// the caller hands to the other ranks by whatever means it has (the Python side broadcasts it with torch.distributed).
+
+typedef struct { char internal[128]; } lq_nccl_uid;           // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(lq_nccl_uid*) = nullptr;
+    int (*CommInitRank)(void**, int, lq_nccl_uid, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string error;
+};
+static RcclApi* rccl() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return &api;
+    tried = true;
+    const char* names[] = {getenv("LQRRT_RCCL"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* nm : names) {                            // first: a copy that is already in the process
+        if (!nm) continue;
+        api.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        if (api.lib) break;
+    }
+    for (const char* nm : names) {
+        if (api.lib) break;
+        if (nm) api.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!api.lib) { api.error = "librccl.so not found (set LQRRT_RCCL)"; return &api; }
+    api.GetUniqueId = (int (*)(lq_nccl_uid*))dlsym(api.lib, "ncclGetUniqueId");
+    api.CommInitRank = (int (*)(void**, int, lq_nccl_uid, int))dlsym(api.lib, "ncclCommInitRank");
+    api.CommDestroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
+    api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllGather");
+    api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) api.error = "librccl.so lacks the nccl* entry points";
+    return &api;
+}
+
+struct lqrrt_comm {
+    int kind;                 // LQRRT_COMM_RCCL or LQRRT_COMM_LOOPBACK
+    int rank, world, device;
+    void* nccl;               // ncclComm_t
+};
+
+#define NCCLCHK(call)                                                                                  \
+    do {                                                                                               \
+        int r__ = (call);                                                                              \
+        if (r__ != 0)                                                                                  \
+            return fail(LQRRT_E_HIP, "%s failed: %s", #call, rccl()->GetErrorString ? rccl()->GetErrorString(r__) : "?"); \
+    } while (0)
+
+extern "C" int lqrrt_comm_unique_id(uint8_t* id128) {
+    if (!id128) return fail(LQRRT_E_ARG, "null argument");
+    RcclApi* a = rccl();
+    if (!a->error.empty()) return fail(LQRRT_E_STATE, "%s", a->error.c_str());
+    lq_nccl_uid uid;
+    NCCLCHK(a->GetUniqueId(&uid));
+    memcpy(id128, uid.internal, 128);
+    return 0;
+}
+
+extern "C" int lqrrt_comm_create(const uint8_t* id128, int rank, int world, int device, lqrrt_comm** out) {
+    if (!id128 || !out || world < 1 || rank < 0 || rank >= world) return fail(LQRRT_E_ARG, "bad argument");
+    *out = nullptr;
+    RcclApi* a = rccl();
+    if (!a->error.empty()) return fail(LQRRT_E_STATE, "%s", a->error.c_str());
+    if (lqrrt_device_count() <= device || device < 0) return fail(LQRRT_E_NODEVICE, "HIP device %d not available", device);
+    HIPCHK(hipSetDevice(device));
+    lq_nccl_uid uid;
+    memcpy(uid.internal, id128, 128);
+    void* comm = nullptr;
+    NCCLCHK(a->CommInitRank(&comm, world, uid, rank));
+    *out = new lqrrt_comm{LQRRT_COMM_RCCL, rank, world, device, comm};
+    return 0;
+}
+
+extern "C" int lqrrt_comm_create_loopback(int rank, int world, lqrrt_comm** out) {
+    // test double: ONE process plays rank `rank` of `world`; what the other ranks would contribute to a wave's collective is
+    // computed on this engine and goes through the same blocks, so the whole exchange path runs on a single GPU
+    if (!out || world < 1 || rank < 0 || rank >= world) return fail(LQRRT_E_ARG, "bad argument");
+    *out = new lqrrt_comm{LQRRT_COMM_LOOPBACK, rank, world, -1, nullptr};
+    return 0;
+}
+
+extern "C" int lqrrt_comm_destroy(lqrrt_comm* c) {
+    if (!c) return 0;
+    if (c->kind == LQRRT_COMM_RCCL && c->nccl && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->nccl);
+    delete c;
+    return 0;
+}
+
+static int shard_buffers(lqrrt_engine* e, size_t doubles) {
+    if (doubles > e->blk_cap) {
+        if (e->d_blk) (void)hipFree(e->d_blk);
+        e->d_blk = nullptr; e->blk_cap = 0;
+        TRY(dalloc(&e->d_blk, doubles));
+        e->blk_cap = doubles;
+    }
+    if (!e->d_blk_cursor) TRY(dalloc(&e->d_blk_cursor, (size_t)64));
+    return 0;
+}
+
+static double shard_tail_fraction() {
+    // share of a rank's worst-case edge payload (per * H * (n + m) doubles) that its block reserves; the headline workload
+    // fills ~16 % (27 % of the samples add a node, their edges average 60 % of the horizon); a full tail only costs re-steers
+    static const double f = getenv("LQRRT_SHARD_TAIL") ? std::min(1.0, std::max(0.0, atof(getenv("LQRRT_SHARD_TAIL")))) : 0.4;
+    return f;
+}
+
+// SURVEY 8(b)'s lqrrt_allgather_nodes: the exchange step of a sample-sharded wave.  Every rank has speculated its slice
+// [rank * per, ...) of the W samples with its block as the second destination (ShardOut); this gathers the blocks -- in
+// place: the rank's own block is its chunk of the receive buffer -- and unpacks the other ranks' samples into the local
+// records, prepared for the repair rounds (k_shard_unpack_prep).  Payload per rank: per * (header + 1) + tail doubles.
+static int allgather_nodes(lqrrt_engine* e, lqrrt_comm* c, int W, int per, int hd, int tb, hipStream_t st) {
+    const size_t blk = (size_t)per * hd + tb;
+    if (c->kind == LQRRT_COMM_RCCL && c->world > 1) {
+        NCCLCHK(rccl()->AllGather(e->d_blk + (size_t)c->rank * blk, e->d_blk, blk * sizeof(double), /*ncclUint8*/ 1, c->nccl, st));
+    } else if (c->kind == LQRRT_COMM_RCCL) {
+        // world of one: still a real collective on the stream (what bench.py's forced-sharded mode times)
+        NCCLCHK(rccl()->AllGather(e->d_blk, e->d_blk, blk * sizeof(double), 1, c->nccl, st));
+    }
+    const double* xs = wave_samples(e);
+    const double* xtr = wave_sample_trig(e);
+    double* M = e->wave_matrix ? e->d_M : nullptr;
+    if (e->d_S) {
+        DISPATCH(e, hipLaunchKernelGGL((k_shard_unpack_prep<S, true>), dim3(W), dim3(64), 0, st, e->d_rec, e->L, e->d_blk, (long long)blk, hd, per,
+                                       c->rank, W, xs, xtr, e->d_S, M, e->d_par_done, e->d_changed, e->d_stale, e->d_lf[0], e->d_rctl));
+    } else {
+        DISPATCH(e, hipLaunchKernelGGL((k_shard_unpack_prep<S, false>), dim3(W), dim3(64), 0, st, e->d_rec, e->L, e->d_blk, (long long)blk, hd, per,
+                                       c->rank, W, xs, xtr, (const double*)nullptr, M, e->d_par_done, e->d_changed, e->d_stale, e->d_lf[0], e->d_rctl));
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int sample_sharded_wave(lqrrt_engine* e, lqrrt_comm* c, int W, hipStream_t st) {
+    const int G = c->world;
+    const int per = (W + G - 1) / G;
+    const int hd = e->L.off_xseq + 1;
+    const int edge = e->H * (e->n + e->m);
+    // (synchronous waves have no repair rounds that could re-steer a sample whose edge did not fit: they get the full tail)
+    const int tb = e->sync_mode ? per * edge : std::max(edge, (int)std::ceil(shard_tail_fraction() * (double)per * edge));
+    const size_t blk = (size_t)per * hd + tb;
+    TRY(shard_buffers(e, blk * G));
+    auto slice = [&](int g, int* lo, int* hi) { *lo = std::min(W, g * per); *hi = std::min(W, *lo + per); };
+    auto speculate_for = [&](int g) -> int {
+        int lo, hi;
+        slice(g, &lo, &hi);
+        HIPCHK(hipMemsetAsync(e->d_blk_cursor, 0, sizeof(int), st));
+        ShardOut so{e->d_blk + (size_t)g * blk, e->d_blk + (size_t)g * blk + (size_t)per * hd, e->d_blk_cursor, hd, tb};
+        return speculate_impl(e, W, lo, hi, st, &so);
+    };
+    TRY(speculate_for(c->rank));
+    if (c->kind == LQRRT_COMM_LOOPBACK) {
+        // play the other ranks: their slices are speculated here, into their blocks, and their records are then wiped so that
+        // what the commit sees of them is what came through the blocks
+        for (int g = 0; g < G; ++g) {
+            if (g == c->rank) continue;
+            TRY(speculate_for(g));
+            int lo, hi;
+            slice(g, &lo, &hi);
+            if (hi > lo) HIPCHK(hipMemsetAsync(e->d_rec + (size_t)lo * e->L.R, 0xff, sizeof(double) * (size_t)(hi - lo) * e->L.R, st));
+        }
+    }
+    e->wave_complete = false;
+    TRY(allgather_nodes(e, c, W, per, hd, tb, st));
+    e->wave_prepared = true;
+    return 0;
+}
+
+static int tree_sharded_wave(lqrrt_engine* e, lqrrt_comm* c, int W, hipStream_t st) {
+    const int G = c->world;
+    TRY(shard_buffers(e, (size_t)2 * W * G));
+    auto range = [&](int g, int* lo, int* hi) {
+        const int per = (((e->N + G - 1) / G) + 63) / 64 * 64;
+        *lo = std::min(e->N, g * per); *hi = std::min(e->N, *lo + per);
+    };
+    int lo, hi;
+    range(c->rank, &lo, &hi);
+    TRY(lqrrt_wave_scan_nodes(e, W, lo, hi, e->d_blk + (size_t)c->rank * 2 * W, st));
+    if (c->kind == LQRRT_COMM_LOOPBACK) {
+        for (int g = 0; g < G; ++g) {
+            if (g == c->rank) continue;
+            range(g, &lo, &hi);
+            TRY(lqrrt_wave_scan_nodes(e, W, lo, hi, e->d_blk + (size_t)g * 2 * W, st));
+        }
+    } else {
+        NCCLCHK(rccl()->AllGather(e->d_blk + (size_t)c->rank * 2 * W, e->d_blk, (size_t)2 * W * sizeof(double), 1, c->nccl, st));
+    }
+    return lqrrt_wave_steer_candidates(e, W, G, e->d_blk, st);
+}
+
+extern "C" int lqrrt_allgather_nodes(lqrrt_engine* e, lqrrt_comm* c, int W, void* stream) {
+    // one sample-sharded wave up to (not including) its commit: speculate this rank's slice, exchange, unpack
+    if (!e || !c) return fail(LQRRT_E_ARG, "null argument");
+    if (W < 1 || W > e->maxW) return fail(LQRRT_E_ARG, "bad wave size");
+    TRY(use_device(e));
+    return sample_sharded_wave(e, c, W, (hipStream_t)stream);
+}
+
+extern "C" int lqrrt_engine_extend_sharded(lqrrt_engine* e, lqrrt_comm* c, int scheme, int wave, int64_t max_attempts,
+                                           int64_t node_limit, int until_size, int pruning, int stop_on_goal,
+                                           lqrrt_extend_stats* out, void* stream) {
+    if (!e || !c) return fail(LQRRT_E_ARG, "null argument");
+    if (wave < 1) return fail(LQRRT_E_ARG, "wave must be >= 1");
+    if (scheme != LQRRT_SHARD_SAMPLES && scheme != LQRRT_SHARD_TREE) return fail(LQRRT_E_ARG, "unknown sharding scheme %d", scheme);
+    if (scheme == LQRRT_SHARD_SAMPLES && e->riccati) return fail(LQRRT_E_ARG, "sample-sharded waves are not instantiated for Riccati systems");
+    TRY(use_device(e));
+    hipStream_t st = (hipStream_t)stream;
+    lqrrt_extend_stats acc;
+    memset(&acc, 0, sizeof acc);
+    const int64_t spec0 = e->tot.speculated;
+    while (true) {
+        if (max_attempts >= 0 && acc.attempts >= max_attempts) { acc.stop_reason = LQRRT_STOP_ATTEMPTS; break; }
+        if (node_limit >= 0 && (int64_t)e->N > node_limit) { acc.stop_reason = LQRRT_STOP_NODES; break; }
+        if (until_size > 0 && e->N >= until_size) { acc.stop_reason = LQRRT_STOP_TARGET; break; }
+        // (every rank computes the same W: the controller only looks at replicated state)
+        int W = e->sync_mode ? std::min(wave, e->maxW) : pick_wave(e, wave);
+        int64_t cap_attempts = max_attempts >= 0 ? max_attempts - acc.attempts : (int64_t)W;
+        if ((int64_t)W > cap_attempts) W = (int)cap_attempts;
+        if (e->explicit_samples) {
+            const int64_t queued = e->pool_base + (int64_t)e->pool_rows_end.size() - e->cursor;
+            if (queued <= 0) { acc.stop_reason = LQRRT_STOP_ATTEMPTS; break; }
+            if ((int64_t)W > queued) W = (int)queued;
+        }
+        int64_t lim = node_limit;
+        if (until_size > 0) {
+            const int64_t l2 = (int64_t)until_size - 1;
+            lim = (lim < 0) ? l2 : std::min(lim, l2);
+        }
+        lqrrt_extend_stats ws;
+        if (scheme == LQRRT_SHARD_SAMPLES) {
+            TRY(sample_sharded_wave(e, c, W, st));
+            TRY(commit_impl(e, W, cap_attempts, lim, pruning, &ws, stream, true));
+        } else {
+            TRY(tree_sharded_wave(e, c, W, st));
+            TRY(commit_impl(e, W, cap_attempts, lim, pruning, &ws, stream, false));
+        }
         acc.attempts += ws.attempts; acc.accepted += ws.accepted; acc.waves += 1;
         acc.fix_rounds += ws.fix_rounds; acc.resteers += ws.resteers; acc.goal_hits += ws.goal_hits;
         if (stop_on_goal && ws.goal_hits) { acc.stop_reason = LQRRT_STOP_GOAL; break; }

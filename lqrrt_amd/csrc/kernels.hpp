@@ -573,6 +573,12 @@ struct SteerFuse {
     double* M; int W;                                        // M != null: row epilogue, leading dimension W
     const double* xtrig;                                     // cos/sin of the samples' angular coordinates [..][2*NW], or null
     int* lf0; int* round_ctl;                                // fused repair rounds: {len, flags} buffer 0, control block to clear (or null)
+    // Sample-sharded waves (lqrrt_engine_extend_sharded): the speculative launch also writes what the other ranks need of
+    // this rank's records straight into its all-gather block -- header [local sample][sh_hd] = the record up to the edges
+    // (cost, parent, len, flags, xend, trig, K) + one word: where the sample's edge lies in the block's tail (compacted:
+    // only accepted samples have one; the slot is taken with an atomic, so the order in the tail is arbitrary) or -1 (no
+    // edge) / -2 (tail full: the receivers re-steer that sample themselves).
+    double* sh_hdr; double* sh_tail; int* sh_cursor; int sh_hd, sh_tb;
 };
 
 // Fused repair rounds (small waves, exact mode).  One launch of k_steer with W workgroups is one round: every
@@ -1461,6 +1467,25 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             Mout[(size_t)t * Wm + u] = c;
         }
     }
+    if (f.sh_hdr) {
+        // this rank's share of a sample-sharded wave: header and (compacted) edge into the all-gather block
+        int off = -1;
+        const int need = cnt * (S::N + S::M);
+        if (cnt > 0) {
+            if (lane == 0) off = atomicAdd(f.sh_cursor, need);
+            off = __builtin_amdgcn_readfirstlane(off);
+            if (off + need > f.sh_tb) off = -2;                  // tail full (rare: the budget is ~2x the typical yield)
+        }
+        double* h = f.sh_hdr + (size_t)blockIdx.x * f.sh_hd;
+        __threadfence();                                         // the record fields read back below were written by other lanes
+        for (int q = lane; q < L.off_xseq; q += 64) h[q] = my[q];
+        if (lane == 0) h[L.off_xseq] = (double)off;
+        if (off >= 0) {
+            double* tl = f.sh_tail + off;
+            for (int q = lane; q < cnt * S::N; q += 64) tl[q] = hx[q];
+            for (int q = lane; q < cnt * S::M; q += 64) tl[cnt * S::N + q] = hu[q];
+        }
+    }
     STEER_TS(5);
 #ifdef STEER_TIMING
     if (threadIdx.x == 0 && steps >= 20) {
@@ -1559,6 +1584,77 @@ __global__ __launch_bounds__(64) void k_wave_rows(const double* __restrict__ rec
             c = quad_cost<S, DENSE>(e, Sd);
         }
         M[(size_t)t * W + u] = c;
+    }
+}
+
+// Sample-sharded wave, after the all-gather of the ranks' blocks (SteerFuse::sh_*): one wavefront per sample of the wave.
+//  * a sample another rank speculated: its header goes into the local record, and its edge if it has one in that rank's
+//    tail; "tail full" marks the sample stale, i.e. the first repair round re-steers it from its parent on every rank alike;
+//  * every sample: what the speculative launch prepares for the repair rounds of a whole wave -- parent in use, changed /
+//    stale flags, {len, flags} of buffer 0, its row of the in-wave cost matrix (M != null) -- so that the gathered wave
+//    runs the same fused rounds as a wave speculated on one GPU (RoundArgs); workgroup 0 clears the rounds' control block.
+template <class S, int DENSE>
+__global__ __launch_bounds__(64) void k_shard_unpack_prep(double* __restrict__ rec, RecLayout L, const double* __restrict__ blk,
+                                                          long long blk_stride, int hd, int per, int rank, int W,
+                                                          const double* __restrict__ xs, const double* __restrict__ xtrig,
+                                                          const double* __restrict__ Sd, double* __restrict__ M,
+                                                          int* __restrict__ par_done, unsigned char* __restrict__ changed,
+                                                          unsigned char* __restrict__ stale, int* __restrict__ lf0,
+                                                          int* __restrict__ round_ctl) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= W) return;
+    double* my = rec + (size_t)t * L.R;
+    const int g = t / per, j = t - g * per;
+    int mark_stale = 0;
+    if (g != rank) {
+        const double* b = blk + (size_t)g * blk_stride;
+        const double* h = b + (size_t)j * hd;
+        for (int q = lane; q < L.off_xseq; q += 64) my[q] = h[q];
+        const int len = (int)h[L.off_len];
+        const int off = (int)h[L.off_xseq];
+        if (len > 0 && off >= 0) {
+            const double* tl = b + (size_t)per * hd + off;
+            for (int q = lane; q < len * S::N; q += 64) my[L.off_xseq + q] = tl[q];
+            for (int q = lane; q < len * S::M; q += 64) my[L.off_useq + q] = tl[len * S::N + q];
+        } else if (len > 0) {
+            mark_stale = 1;
+        }
+    }
+    __threadfence();
+    const int len = (int)my[L.off_len];
+    if (lane == 0) {
+        par_done[t] = (int)my[L.off_parent];
+        changed[t] = 0;
+        stale[t] = (unsigned char)mark_stale;
+        if (lf0) { lf0[2 * t] = len; lf0[2 * t + 1] = (int)my[L.off_flags]; }
+        if (round_ctl && t == 0) {
+#pragma unroll
+            for (int q = 0; q < 10; ++q) round_ctl[q] = 0;
+        }
+    }
+    if (M) {
+        double x[S::N], trig[2 * S::NW + 1];
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) x[d] = my[L.off_xend + d];
+#pragma unroll
+        for (int jj = 0; jj < 2 * S::NW; ++jj) trig[jj] = my[L.off_trig + jj];
+        for (int u = t + 1 + lane; u < W; u += 64) {
+            double xu[S::N], tu[2 * S::NW + 1], e[S::N];
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) xu[d] = xs[(size_t)u * S::N + d];
+            if (xtrig) {
+#pragma unroll
+                for (int jj = 0; jj < 2 * S::NW; ++jj) tu[jj] = xtrig[(size_t)u * (2 * S::NW) + jj];
+            } else {
+                trig_of<S>(xu, tu);
+            }
+            double c = INFINITY;
+            if (len > 0) {
+                erf_cached<S>(xu, tu, x, trig, e);
+                c = quad_cost<S, DENSE>(e, Sd);
+            }
+            M[(size_t)t * W + u] = c;
+        }
     }
 }
 

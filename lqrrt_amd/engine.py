@@ -384,6 +384,17 @@ class Engine(object):
                                                 self._stream()))
         return st
 
+    def extend_sharded(self, comm, scheme, wave, max_attempts=-1, node_limit=-1, until_size=0, pruning=True, stop_on_goal=False):
+        """lqrrt_engine_extend_sharded: the native loop with one RCCL all-gather per wave (comm: parallel.NativeComm)."""
+        st = nat.ExtendStats()
+        nat.check(nat.lib().lqrrt_engine_extend_sharded(self.h, comm.h, {"sample": 0, "tree": 1}[scheme], int(wave), int(max_attempts),
+                                                       int(node_limit), int(until_size), 1 if pruning else 0,
+                                                       1 if stop_on_goal else 0, C.byref(st), self._stream()))
+        return st
+
+    def allgather_nodes(self, comm, W):
+        nat.check(nat.lib().lqrrt_allgather_nodes(self.h, comm.h, int(W), self._stream()))
+
     def plan_best(self):
         end, steps, hits = C.c_int32(), C.c_int64(), C.c_int64()
         nat.check(nat.lib().lqrrt_plan_best(self.h, C.byref(end), C.byref(steps), C.byref(hits)))

@@ -20,7 +20,60 @@ the winner by (cost, id) over ascending node ranges is exactly the node a single
 Both classes are engine-agnostic (anything with the wave_* methods and the buffers), which is how
 tests/test_parallel_cpu.py drives them with gloo on CPU.
 """
+import ctypes as C
+
 import numpy as np
+
+
+class NativeComm(object):
+    """Communicator of the native sharded loop (include/lqrrt_hip.h lqrrt_comm_*).  `dist` given: an RCCL communicator of its
+    own for this world -- rank 0 creates the unique id, the 128 bytes travel through torch.distributed (any backend), every
+    rank joins.  `dist` None: the loopback double (one process plays `rank` of `world`; tests)."""
+
+    def __init__(self, rank, world, device=0, dist=None):
+        from . import _native as nat
+        self._nat = nat
+        self.rank, self.world = int(rank), int(world)
+        h = C.c_void_p()
+        if dist is None:
+            nat.check(nat.lib().lqrrt_comm_create_loopback(self.rank, self.world, C.byref(h)))
+        else:
+            import torch
+            uid = np.zeros(128, dtype=np.uint8)
+            if self.rank == 0:
+                nat.check(nat.lib().lqrrt_comm_unique_id(uid.ctypes.data_as(C.c_void_p)))
+            on_gpu = hasattr(dist, "get_backend") and dist.get_backend() == "nccl"
+            t = torch.from_numpy(uid)
+            t = t.cuda(device) if on_gpu else t
+            dist.broadcast(t, 0)
+            uid = np.ascontiguousarray(t.cpu().numpy(), dtype=np.uint8)
+            nat.check(nat.lib().lqrrt_comm_create(uid.ctypes.data_as(C.c_void_p), self.rank, self.world, int(device), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self._nat.lib().lqrrt_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeSharded(object):
+    """Sharded waves without a host language in the loop: engine.extend_sharded runs speculate -> ncclAllGather -> commit on one
+    stream for as many waves as the call covers.  Same interface as ShardedWave / TreeShardedWave (`wave`)."""
+
+    def __init__(self, engine, comm, scheme="sample"):
+        self.e, self.comm, self.scheme = engine, comm, scheme
+
+    def wave(self, want, max_commit, node_limit=-1, pruning=True):
+        return self.e.extend_sharded(self.comm, self.scheme, want, max_attempts=max_commit, node_limit=node_limit, pruning=pruning)
+
+    def extend(self, wave, **kw):
+        return self.e.extend_sharded(self.comm, self.scheme, wave, **kw)
 
 
 class _DevBlob(object):
