@@ -55,6 +55,9 @@ extern "C" {
                                            * S, K from the discrete Riccati equation of the dynamics linearised about (x,u) by
                                            * central differences, recomputed per rollout step, per new node and per sample */
 
+#define LQRRT_MODEL_BOAT_NOVICE_LQR    9  /* demos/demo_boat_novice.py dynamics (6 states, 3 controls) with the same Riccati lqr,
+                                           * linearised about (x, 0): the north-star steer pipeline at the metric's dimension */
+
 #define LQRRT_MAX_STATES   12
 #define LQRRT_MAX_CONTROLS 6
 #define LQRRT_MAX_PARAMS   96
@@ -396,6 +399,10 @@ int lqrrt_engine_counters(lqrrt_engine* e, lqrrt_extend_stats* out);
 int lqrrt_profile_enable(lqrrt_engine* e, int on);
 int lqrrt_profile_read(lqrrt_engine* e, double* nn_ms, int64_t* nn_launches, double* nn_bytes,
                        double* steer_ms, int64_t* steer_launches);
+
+/* Measurement aid (bench.py): effective shader clock = s_memtime ticks / s_memrealtime (100 MHz) over a
+ * chain of dependent fp64 FMAs on one wavefront, and what a dependent / an independent fp64 FMA costs that wavefront. */
+int lqrrt_clock_probe(int device, double* shader_mhz, double* ns_dependent_fma, double* ns_independent_fma, void* stream);
 
 #ifdef __cplusplus
 }

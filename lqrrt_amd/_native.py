@@ -15,6 +15,7 @@ MAX_STATES, MAX_CONTROLS, MAX_PARAMS = 12, 6, 96
 
 MODEL_BOAT_ADVANCED, MODEL_BOAT_INTERMEDIATE, MODEL_BOAT_NOVICE = 1, 2, 3
 MODEL_CAR, MODEL_PENDULUM, MODEL_DOUBLE_INTEGRATOR, MODEL_ROS_BOAT, MODEL_PENDULUM_LQR = 4, 5, 6, 7, 8
+MODEL_BOAT_NOVICE_LQR = 9
 
 E_ARG, E_HIP, E_NODEVICE, E_CAPACITY, E_STATE = -1, -2, -3, -4, -5
 STOP_ATTEMPTS, STOP_NODES, STOP_TARGET, STOP_GOAL = 1, 2, 3, 4
@@ -108,6 +109,7 @@ SIGNATURES = {
     "lqrrt_comm_destroy": (_I, [_P]),
     "lqrrt_allgather_nodes": (_I, [_P, _P, _I, _P]),
     "lqrrt_engine_extend_sharded": (_I, [_P, _P, _I, _I, _I64, _I64, _I, _I, _I, C.POINTER(ExtendStats), _P]),
+    "lqrrt_clock_probe": (_I, [_I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), _P]),
     "lqrrt_plan_best": (_I, [_P, C.POINTER(C.c_int32), C.POINTER(_I64), C.POINTER(_I64)]),
     "lqrrt_engine_counters": (_I, [_P, C.POINTER(ExtendStats)]),
     "lqrrt_profile_enable": (_I, [_P, _I]),

@@ -227,6 +227,7 @@ struct lqrrt_engine {
         case LQRRT_MODEL_DOUBLE_INTEGRATOR: { using S = DoubleIntegratorT<6>; __VA_ARGS__; } break; \
         case LQRRT_MODEL_ROS_BOAT:          { using S = RosBoat;          __VA_ARGS__; } break;   \
         case LQRRT_MODEL_PENDULUM_LQR:      { using S = PendulumLqr;      __VA_ARGS__; } break;   \
+        case LQRRT_MODEL_BOAT_NOVICE_LQR:   { using S = BoatNoviceLqr;    __VA_ARGS__; } break;   \
         default: return fail(LQRRT_E_ARG, "unknown model %d", (e)->model);                        \
     }
 
@@ -250,6 +251,7 @@ static bool model_dims(int model, int* n, int* m, int* nw) {
         case LQRRT_MODEL_BOAT_ADVANCED:
         case LQRRT_MODEL_BOAT_INTERMEDIATE:
         case LQRRT_MODEL_ROS_BOAT:
+        case LQRRT_MODEL_BOAT_NOVICE_LQR:
         case LQRRT_MODEL_BOAT_NOVICE: *n = 6; *m = 3; *nw = 1; return true;
         case LQRRT_MODEL_CAR: *n = 5; *m = 2; *nw = 1; return true;
         case LQRRT_MODEL_PENDULUM_LQR:
@@ -262,8 +264,12 @@ static bool model_dims(int model, int* n, int* m, int* nw) {
 // index of the k-th angular (wrapped) state of a model: S::wd(k) on the host
 static int model_wd(int model, int k) { return (model == LQRRT_MODEL_PENDULUM || model == LQRRT_MODEL_PENDULUM_LQR) ? k : 2; }
 // systems whose lqr is a per-state Riccati solution: cooperative gain kernels, one cost-to-go matrix per sample
-static bool model_riccati(int model) { return model == LQRRT_MODEL_PENDULUM_LQR; }
-static constexpr int PLQR_Q = 18, PLQR_R = 34, PLQR_EPS = 35;      // systems.hpp PendulumLqr parameter layout
+static bool model_riccati(int model) { return model == LQRRT_MODEL_PENDULUM_LQR || model == LQRRT_MODEL_BOAT_NOVICE_LQR; }
+// where a Riccati system keeps Q, R and the difference step in its parameter block (systems.hpp S::P_Q / P_R / P_EPS)
+static int riccati_q(int model) { return model == LQRRT_MODEL_BOAT_NOVICE_LQR ? 19 : 18; }
+static int riccati_r(int model) { return model == LQRRT_MODEL_BOAT_NOVICE_LQR ? 55 : 34; }
+static int riccati_eps(int model) { return model == LQRRT_MODEL_BOAT_NOVICE_LQR ? 64 : 35; }
+static bool model_novice(int model) { return model == LQRRT_MODEL_BOAT_NOVICE || model == LQRRT_MODEL_BOAT_NOVICE_LQR; }
 
 static size_t geo_lds_bytes(const lqrrt_engine* e) {
     if (e->geo.og) return e->geo.og_lds ? sizeof(double) * (size_t)2 * e->geo.V : 0;
@@ -418,8 +424,13 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     hipExtLaunchKernelGGL((k_nn_scan<SYS, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
                           e->d_pcost, e->d_pidx, ps_c, ps_t)
     if (Spers) {
-        if (e->model != LQRRT_MODEL_PENDULUM_LQR) return fail(LQRRT_E_ARG, "per-sample S is only instantiated for Riccati systems");
-        if (tri) NN_ONE(PendulumLqr, S_PERSAMPLE, true); else NN_ONE(PendulumLqr, S_PERSAMPLE, false);
+        if (e->model == LQRRT_MODEL_PENDULUM_LQR) {
+            if (tri) NN_ONE(PendulumLqr, S_PERSAMPLE, true); else NN_ONE(PendulumLqr, S_PERSAMPLE, false);
+        } else if (e->model == LQRRT_MODEL_BOAT_NOVICE_LQR) {
+            if (tri) NN_ONE(BoatNoviceLqr, S_PERSAMPLE, true); else NN_ONE(BoatNoviceLqr, S_PERSAMPLE, false);
+        } else {
+            return fail(LQRRT_E_ARG, "per-sample S is only instantiated for Riccati systems");
+        }
     } else if (sm == S_BAND2 && e->model == LQRRT_MODEL_DOUBLE_INTEGRATOR) {
         if (tri) NN_ONE(DoubleIntegratorT<6>, S_BAND2, true); else NN_ONE(DoubleIntegratorT<6>, S_BAND2, false);
     } else if (sm == S_DIAG && e->model == LQRRT_MODEL_ROS_BOAT) {
@@ -628,10 +639,10 @@ static int upload_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys) {
         double hull_r = 0.0;
         for (int v = 0; v < sys->n_vertices; ++v)
             hull_r = std::max(hull_r, std::sqrt(sys->vps[v] * sys->vps[v] + sys->vps[sys->n_vertices + v] * sys->vps[sys->n_vertices + v]));
-        const double inflate = (sys->model == LQRRT_MODEL_BOAT_NOVICE) ? sys->params[18] : 0.0;
+        const double inflate = model_novice(sys->model) ? sys->params[18] : 0.0;
         std::vector<double> oc((size_t)4 * sys->n_obstacles + 4);
         for (int o = 0; o < sys->n_obstacles; ++o) {
-            const double r = (sys->model == LQRRT_MODEL_BOAT_NOVICE) ? inflate + sys->obs[3 * o + 2] : sys->obs[3 * o + 2];
+            const double r = model_novice(sys->model) ? inflate + sys->obs[3 * o + 2] : sys->obs[3 * o + 2];
             oc[4 * o] = sys->obs[3 * o]; oc[4 * o + 1] = sys->obs[3 * o + 1];
             oc[4 * o + 2] = exact_sq_threshold(r);
             oc[4 * o + 3] = (r >= 0.0) ? r * (1.0 + 1e-9) + 1e-9 : -1e300;      // padded radius for the cull (never near if invalid)
@@ -696,8 +707,8 @@ static int upload_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys) {
 static int upload_weights(lqrrt_engine* e) {
     if (!e->riccati) return 0;
     if (!e->d_QR) TRY(dalloc(&e->d_QR, (size_t)e->n * e->n + (size_t)e->m * e->m));
-    HIPCHK(hipMemcpy(e->d_QR, e->P.p + PLQR_Q, sizeof(double) * e->n * e->n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_QR + e->n * e->n, e->P.p + PLQR_R, sizeof(double) * e->m * e->m, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_QR, e->P.p + riccati_q(e->model), sizeof(double) * e->n * e->n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_QR + e->n * e->n, e->P.p + riccati_r(e->model), sizeof(double) * e->m * e->m, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -706,7 +717,7 @@ static int launch_sample_S(lqrrt_engine* e, const double* xs, int B, double* S_o
     if (B <= 0) return 0;
     if (!e->has_res) return fail(LQRRT_E_STATE, "set_resolution first (dt)");
     DISPATCH(e, hipLaunchKernelGGL((k_lqr_dare<S>), dim3(B), dim3(64), 0, st, e->P, xs, (const double*)nullptr, B, e->d_QR,
-                                   e->d_QR + e->n * e->n, e->res.dt, e->P.p[PLQR_EPS], 64, 1e-14, S_out, (double*)nullptr,
+                                   e->d_QR + e->n * e->n, e->res.dt, e->P.p[riccati_eps(e->model)], 64, 1e-14, S_out, (double*)nullptr,
                                    (double*)nullptr, (double*)nullptr, (int*)nullptr));
     HIPCHK(hipGetLastError());
     return 0;
@@ -2074,7 +2085,10 @@ static int shard_buffers(lqrrt_engine* e, size_t doubles) {
         TRY(dalloc(&e->d_blk, doubles));
         e->blk_cap = doubles;
     }
-    if (!e->d_blk_cursor) TRY(dalloc(&e->d_blk_cursor, (size_t)64));
+    if (!e->d_blk_cursor) {
+        TRY(dalloc(&e->d_blk_cursor, (size_t)64));
+        HIPCHK(hipMemset(e->d_blk_cursor, 0, sizeof(int) * 64));
+    }
     return 0;
 }
 
@@ -2102,10 +2116,10 @@ static int allgather_nodes(lqrrt_engine* e, lqrrt_comm* c, int W, int per, int h
     double* M = e->wave_matrix ? e->d_M : nullptr;
     if (e->d_S) {
         DISPATCH(e, hipLaunchKernelGGL((k_shard_unpack_prep<S, true>), dim3(W), dim3(64), 0, st, e->d_rec, e->L, e->d_blk, (long long)blk, hd, per,
-                                       c->rank, W, xs, xtr, e->d_S, M, e->d_par_done, e->d_changed, e->d_stale, e->d_lf[0], e->d_rctl));
+                                       c->rank, W, xs, xtr, e->d_S, M, e->d_par_done, e->d_changed, e->d_stale, e->d_lf[0], e->d_rctl, e->d_blk_cursor));
     } else {
         DISPATCH(e, hipLaunchKernelGGL((k_shard_unpack_prep<S, false>), dim3(W), dim3(64), 0, st, e->d_rec, e->L, e->d_blk, (long long)blk, hd, per,
-                                       c->rank, W, xs, xtr, (const double*)nullptr, M, e->d_par_done, e->d_changed, e->d_stale, e->d_lf[0], e->d_rctl));
+                                       c->rank, W, xs, xtr, (const double*)nullptr, M, e->d_par_done, e->d_changed, e->d_stale, e->d_lf[0], e->d_rctl, e->d_blk_cursor));
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -2124,7 +2138,8 @@ static int sample_sharded_wave(lqrrt_engine* e, lqrrt_comm* c, int W, hipStream_
     auto speculate_for = [&](int g) -> int {
         int lo, hi;
         slice(g, &lo, &hi);
-        HIPCHK(hipMemsetAsync(e->d_blk_cursor, 0, sizeof(int), st));
+        // (the tail cursor is reset by the previous wave's unpack kernel; the loopback double fills several blocks per wave)
+        if (c->kind == LQRRT_COMM_LOOPBACK) HIPCHK(hipMemsetAsync(e->d_blk_cursor, 0, sizeof(int), st));
         ShardOut so{e->d_blk + (size_t)g * blk, e->d_blk + (size_t)g * blk + (size_t)per * hd, e->d_blk_cursor, hd, tb};
         return speculate_impl(e, W, lo, hi, st, &so);
     };
@@ -2263,6 +2278,62 @@ extern "C" int lqrrt_profile_read(lqrrt_engine* e, double* nn_ms, int64_t* nn_la
     if (nn_bytes) *nn_bytes = e->nn_bytes;
     if (steer_ms) *steer_ms = e->steer_ms;
     if (steer_launches) *steer_launches = e->steer_launches;
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// Shader clock and issue rate, measured (bench.py reports them next to every latency-bound figure; tools/micro/clock.hip is
+// the long form, profiles/r03_clock.txt its output): s_memtime (shader ticks) against s_memrealtime (100 MHz) around a chain of
+// dependent fp64 FMAs and around eight independent chains, one wavefront.
+__global__ __launch_bounds__(64) void k_clock_probe(double* out, double a, double b, int n, unsigned long long* ticks) {
+    double x = a + threadIdx.x * 1e-9;
+    const unsigned long long r0 = wall_clock64(), s0 = clock64();
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x = fma(x, b, a);
+    }
+    const unsigned long long s1 = clock64(), r1 = wall_clock64();
+    double y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = a + j + threadIdx.x * 1e-9;
+    const unsigned long long r2 = wall_clock64(), s2 = clock64();
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = fma(y[j], b, a);
+        }
+    }
+    const unsigned long long s3 = clock64(), r3 = wall_clock64();
+    double sum = x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += y[j];
+    out[threadIdx.x] = sum;
+    if (threadIdx.x == 0) { ticks[0] = s1 - s0; ticks[1] = r1 - r0; ticks[2] = s3 - s2; ticks[3] = r3 - r2; }
+}
+
+extern "C" int lqrrt_clock_probe(int device, double* shader_mhz, double* ns_dependent_fma, double* ns_independent_fma, void* stream) {
+    if (lqrrt_device_count() <= device || device < 0) return fail(LQRRT_E_NODEVICE, "HIP device %d not available", device);
+    HIPCHK(hipSetDevice(device));
+    double* out = nullptr;
+    unsigned long long* ticks = nullptr;
+    TRY(dalloc(&out, (size_t)64));
+    TRY(dalloc(&ticks, (size_t)4));
+    const int n = 2000;                                          // 32k dependent FMAs ~ 80 us
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long t[4] = {0, 0, 0, 0};
+    for (int rep = 0; rep < 2; ++rep) {                          // (the second launch is the one that is read)
+        hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, st, out, 0.3, 0.5, n, ticks);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(t, ticks, sizeof t, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    (void)hipFree(out); (void)hipFree(ticks);
+    if (t[1] == 0 || t[3] == 0) return fail(LQRRT_E_HIP, "clock probe returned no ticks");
+    const double us_dep = t[1] / 100.0, us_ind = t[3] / 100.0;
+    if (shader_mhz) *shader_mhz = (double)t[0] / us_dep;
+    if (ns_dependent_fma) *ns_dependent_fma = 1e3 * us_dep / (16.0 * n);
+    if (ns_independent_fma) *ns_independent_fma = 1e3 * us_ind / (16.0 * n);
     return 0;
 }
 

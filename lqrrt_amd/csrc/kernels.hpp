@@ -87,6 +87,8 @@ __host__ __device__ inline RecLayout make_layout(int n, int m, int nw, int H) {
 // Systems whose lqr is the Riccati solution of the local linearisation (systems.hpp PendulumLqr) declare DARE_GAIN.
 template <class S, class = void> struct has_dare_gain : std::false_type {};
 template <class S> struct has_dare_gain<S, std::enable_if_t<S::DARE_GAIN>> : std::true_type {};
+template <class S, class = void> struct dare_zero_effort : std::false_type {};
+template <class S> struct dare_zero_effort<S, std::enable_if_t<S::DARE_ZERO_EFFORT>> : std::true_type {};
 template <class S> struct NoLds {};
 template <class S> using GainLds = std::conditional_t<has_dare_gain<S>::value, DareLds<S::N, S::M>, NoLds<S>>;
 
@@ -96,7 +98,14 @@ template <class S>
 __device__ __forceinline__ void system_gain(const double* P, const double* x, const double* trig, const double* u, double dt,
                                             GainLds<S>& L, int lane, double* K) {
     if constexpr (has_dare_gain<S>::value) {
-        dare_lqr<S>(P, x, u, P + S::P_Q, P + S::P_R, dt, P[S::P_EPS], 64, 1e-14, L, lane);
+        if constexpr (dare_zero_effort<S>::value) {
+            double u0[S::M];
+#pragma unroll
+            for (int j = 0; j < S::M; ++j) u0[j] = 0.0;
+            dare_lqr<S>(P, x, u0, P + S::P_Q, P + S::P_R, dt, P[S::P_EPS], 64, 1e-14, L, lane);
+        } else {
+            dare_lqr<S>(P, x, u, P + S::P_Q, P + S::P_R, dt, P[S::P_EPS], 64, 1e-14, L, lane);
+        }
 #pragma unroll
         for (int j = 0; j < S::M * S::N; ++j) K[j] = L.Y[j];
     } else {
@@ -1600,9 +1609,10 @@ __global__ __launch_bounds__(64) void k_shard_unpack_prep(double* __restrict__ r
                                                           const double* __restrict__ Sd, double* __restrict__ M,
                                                           int* __restrict__ par_done, unsigned char* __restrict__ changed,
                                                           unsigned char* __restrict__ stale, int* __restrict__ lf0,
-                                                          int* __restrict__ round_ctl) {
+                                                          int* __restrict__ round_ctl, int* __restrict__ tail_cursor) {
     const int t = blockIdx.x, lane = threadIdx.x;
     if (t >= W) return;
+    if (t == 0 && lane == 0) tail_cursor[0] = 0;                // for this rank's next speculative launch
     double* my = rec + (size_t)t * L.R;
     const int g = t / per, j = t - g * per;
     int mark_stale = 0;
@@ -1706,7 +1716,7 @@ __global__ __launch_bounds__(64) void k_steer_force(Params P, Geo g, Res r, Tree
         for (int d = 0; d < S::N; ++d) x[d] = xn[d];
 #pragma unroll
         for (int j = 0; j < 2 * S::NW; ++j) trig[j] = trn[j];
-        S::gain(P.p, x, trig, u, K);
+        system_gain<S>(P.p, x, trig, u, r.dt, gl_lds, lane, K);      // planner.py:436
     }
     if (lane == 0) out_len[0] = cnt;
 }

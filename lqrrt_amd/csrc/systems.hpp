@@ -578,16 +578,16 @@ struct BoatIntermediate : BoatCommon {
 struct BoatNovice : BoatCommon {
     static constexpr bool TWO_WAVEFRONTS = true;     // k_steer: a second wavefront runs the step tests
     // params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 u_max[3] | 12 kp[3] | 15 kd[3] | 18 boat_length/2
-    __device__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
+    __device__ __forceinline__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
         gain_pd(P + 12, P + 15, trig, K);
     }
-    __device__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+    __device__ __forceinline__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)          // demo_boat_novice.py:67-69
             if (fabs(u[i]) > P[9 + i]) u[i] = P[9 + i] * (u[i] > 0.0 ? 1.0 : -1.0);
         euler(P + 0, P + 3, P + 6, x, trig[0], trig[1], u, dt, xn);
     }
-    __device__ static bool feasible(const double*, const Geo&, const GeoL& gl, const double* x, const double*, const double*, int lane) {
+    __device__ __forceinline__ static bool feasible(const double*, const Geo&, const GeoL& gl, const double* x, const double*, const double*, int lane) {
         // centre point vs circles inflated by half the boat length (demo_boat_novice.py:160-164);
         // the inflated radius boat_length/2 + r is folded into the exact threshold on the host
         bool hit = false;
@@ -798,6 +798,19 @@ struct Pendulum {
 struct PendulumLqr : Pendulum {
     static constexpr bool DARE_GAIN = true;
     static constexpr int P_Q = 18, P_R = 34, P_EPS = 35;
+};
+
+// demo_boat_novice.py's 6-state boat with the same lqr contract, at the metric's state dimension (6 states, 3 controls):
+// A, B by central differences of the novice dynamics about (x, 0) -- like every lqr callback the reference ships, this one
+// does not look at its `u` argument (the thruster clamp demo_boat_novice.py:67-69 has zero slope beyond saturation, so a
+// linearisation about a saturated effort would have no stabilising Riccati solution) -- then the doubling DARE and
+// K = (R + B'SB)^-1 B'SA, per recorded rollout step, per new node, and S per sample in the cost-to-go.
+// params: BoatNovice's 0..18, then 19 Q[6][6] | 55 R[3][3] | 64 eps.
+struct BoatNoviceLqr : BoatNovice {
+    static constexpr bool TWO_WAVEFRONTS = false;    // the gain uses the whole wavefront (dare.hpp): one wavefront per rollout
+    static constexpr bool DARE_GAIN = true;
+    static constexpr bool DARE_ZERO_EFFORT = true;   // lqr(x, u) linearises about (x, 0)
+    static constexpr int P_Q = 19, P_R = 55, P_EPS = 64;
 };
 
 // ---------------------------------------------------------------------------------------------

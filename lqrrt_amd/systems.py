@@ -22,6 +22,7 @@ problem, a *system object* that
   BoatNovice        demos/demo_boat_novice.py:21-175
   Car               demos/demo_car.py:26-193
   DoublePendulum    demos/demo_pendulum.py:23-165
+  BoatNoviceLqr     demos/demo_boat_novice.py dynamics + the same Riccati lqr, linearised about (x, 0): 6 states, 3 controls
   PendulumLqr       demos/demo_pendulum.py dynamics + the lqr of the API contract (planner.py:39-42): Riccati gains
   DoubleIntegrator  BASELINE.json config 5 (not in the reference)
 """
@@ -538,6 +539,38 @@ class PendulumLqr(DoublePendulum):
         return (S[0], K[0])
 
 
+class BoatNoviceLqr(BoatNovice):
+    """
+    demo_boat_novice.py's boat (6 states, 3 controls: the metric's dimension) with the lqr of the API contract instead of the
+    demo's PD gain: A, B by central differences of the dynamics about (x, 0) -- like every lqr the reference ships, the
+    callback ignores its `u` (the thruster clamp has zero slope beyond saturation: no stabilising Riccati solution there) --
+    S from the doubling DARE, K = (R + B'SB)^-1 B'SA.  Per recorded rollout step, per new node, S per sample in the
+    nearest-neighbour cost.  params: BoatNovice's 0..18, then 19 Q[6][6] | 55 R[3][3] | 64 eps.
+    """
+    model = nat.MODEL_BOAT_NOVICE_LQR
+    riccati = True
+
+    def __init__(self, obstacle_seed=0, obstacles=None, Q=(1.0, 1.0, 10.0, 0.1, 0.1, 0.1), R=(1e-5, 1e-5, 1e-6), eps=1e-6):
+        BoatNovice.__init__(self, obstacle_seed, obstacles)
+        self.Q = np.diag(np.asarray(Q, dtype=np.float64))
+        self.R = np.diag(np.asarray(R, dtype=np.float64))
+        self.eps = float(eps)
+        # the demo's error_tol (goal_buffer / 2 = 3 m) makes every sample within 3 m of its nearest node converge on its first
+        # step, so the tree stops growing after ~800 nodes (SURVEY 8d): goal_buffer / 8 like the other boats
+        self.error_tol = list(np.array(self.goal_buffer, dtype=np.float64) / 8)
+
+    def params(self):
+        return np.concatenate((BoatNovice.params(self), self.Q.ravel(), self.R.ravel(), [self.eps]))
+
+    def Smatrix(self):
+        return None                                   # no constant S: it is a function of the state (lqr handle)
+
+    def _eval_lqr(self, x, u):
+        eng = self._engine(self.plan_kwargs["dt"] if self._ops_dt is None else None)
+        S, K, _, _, _ = eng.lqr_dare_batch(np.atleast_2d(x), np.zeros((1, self.ncontrols)), self.Q, self.R, self.eps)
+        return (S[0], K[0])
+
+
 # --------------------------------------------------------------------------- synthetic config 5
 
 class DoubleIntegrator(NativeSystem):
@@ -590,5 +623,6 @@ SYSTEMS = {
     "pendulum": DoublePendulum,
     "double_integrator": DoubleIntegrator,
     "pendulum_lqr": PendulumLqr,
+    "boat_novice_lqr": BoatNoviceLqr,
     "ros_boat": RosBoat,
 }

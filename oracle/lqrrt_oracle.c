@@ -28,7 +28,8 @@
 #define MAXN 12
 #define MAXM 6
 
-enum { BOAT_ADV = 1, BOAT_INT = 2, BOAT_NOV = 3, CAR = 4, PEND = 5, DINT = 6, ROS_BOAT = 7, PEND_LQR = 8 };
+enum { BOAT_ADV = 1, BOAT_INT = 2, BOAT_NOV = 3, CAR = 4, PEND = 5, DINT = 6, ROS_BOAT = 7, PEND_LQR = 8, BOAT_NOV_LQR = 9 };
+#define RICCATI(o) ((o)->model == PEND_LQR || (o)->model == BOAT_NOV_LQR)
 
 typedef struct {
     int model, n, m, nw, wd[2];
@@ -176,13 +177,16 @@ static void dsolve(double* W, double* RHS, int n, int q) {     /* W X = RHS by G
         for (int r = 0; r < n; ++r) if (r != p) W[r * n + p] = 0.0;
     }
 }
-#define PLQR_Q 18
-#define PLQR_R 34
-#define PLQR_EPS 35
+/* where a Riccati problem keeps Q, R and the difference step in its parameter block (pendulum: 18 | 34 | 35; the novice
+ * boat, whose lqr linearises about (x, 0) whatever u is: 19 | 55 | 64) */
 static void trig_of(const orc* o, const double* x, double* tr);
-static int dare_lqr(const orc* o, const double* x0, const double* u0, double* S_out, double* K_out) {
+static int dare_lqr(const orc* o, const double* x0, const double* u_in, double* S_out, double* K_out) {
     enum { NN = MAXN * MAXN };
     const int n = o->n, m = o->m;
+    const int boat = o->model == BOAT_NOV_LQR;
+    const int PLQR_Q = boat ? 19 : 18, PLQR_R = boat ? 55 : 34, PLQR_EPS = boat ? 64 : 35;
+    const double zero_u[MAXM] = {0};
+    const double* u0 = boat ? zero_u : u_in;
     const double *Qd = o->P + PLQR_Q, *Rd = o->P + PLQR_R, eps = o->P[PLQR_EPS], dt = o->dt, tol = 1e-14;
     double A[NN], Bm[NN], Ak[NN], G[NN], Hm[NN], W[NN], T1[NN], T2[NN], T3[NN], Rm[MAXM * MAXM], X[NN], Y[NN], Z[MAXM * MAXM];
     for (int lane = 0; lane < n + m; ++lane) {                 /* central differences, one perturbed coordinate each */
@@ -241,7 +245,7 @@ static int dare_lqr(const orc* o, const double* x0, const double* u0, double* S_
 }
 
 static void gain(const orc* o, const double* x, const double* tr, const double* u, double* K) {
-    if (o->model == PEND_LQR) { dare_lqr(o, x, u, 0, K); return; }
+    if (RICCATI(o)) { dare_lqr(o, x, u, 0, K); return; }
     const double* P = o->P;
     const double c = tr[0], s = tr[1];
     const double *kp = 0, *kd = 0;
@@ -320,6 +324,7 @@ static void step(const orc* o, const double* x, const double* tr, double* u, dou
             boat_euler(P, P + 3, P + 6, x, c, s, u, dt, xn);
             carlike(x, P[13], P[14], xn);
             break;
+        case BOAT_NOV_LQR:
         case BOAT_NOV:
             for (int i = 0; i < 3; ++i) if (fabs(u[i]) > P[9 + i]) u[i] = P[9 + i] * (u[i] > 0.0 ? 1.0 : -1.0);
             boat_euler(P, P + 3, P + 6, x, c, s, u, dt, xn);
@@ -411,6 +416,7 @@ static int feasible(const orc* o, const double* x, const double* u, const double
             if (o->og) return !grid_hits(o, x[0], x[1], tr[0], tr[1]);
             if (o->O == 0) return 1;
             return !hull_hits(o, x[0], x[1], tr[0], tr[1], 0);
+        case BOAT_NOV_LQR:
         case BOAT_NOV:
             for (int ob = 0; ob < o->O; ++ob) {
                 const double dx = x[0] - o->obs[ob * o->stride], dy = x[1] - o->obs[ob * o->stride + 1];
@@ -443,7 +449,7 @@ orc* orc_create(int model, const double* params, int n_params, const double* vps
     orc* o = (orc*)calloc(1, sizeof(orc));
     o->model = model;
     switch (model) {
-        case BOAT_ADV: case BOAT_INT: case BOAT_NOV: case ROS_BOAT: o->n = 6; o->m = 3; o->nw = 1; o->wd[0] = 2; break;
+        case BOAT_ADV: case BOAT_INT: case BOAT_NOV: case BOAT_NOV_LQR: case ROS_BOAT: o->n = 6; o->m = 3; o->nw = 1; o->wd[0] = 2; break;
         case CAR: o->n = 5; o->m = 2; o->nw = 1; o->wd[0] = 2; break;
         case PEND_LQR:
         case PEND: o->n = 4; o->m = 1; o->nw = 2; o->wd[0] = 0; o->wd[1] = 1; break;
@@ -556,7 +562,7 @@ static int nearest(const orc* o, const double* xs, const double* Sd, int pruning
 static int nearest_upto(const orc* o, const double* xs, const double* Sd, int pruning, int count) {
     const int n = o->n;
     double gt[4], e[MAXN], prod[MAXN], Sx[MAXN * MAXN], u0[MAXM] = {0};
-    if (o->model == PEND_LQR && !Sd) { dare_lqr(o, xs, u0, Sx, 0); Sd = Sx; }   /* S = lqr(xrand, 0)[0], planner.py:344-345 */
+    if (RICCATI(o) && !Sd) { dare_lqr(o, xs, u0, Sx, 0); Sd = Sx; }   /* S = lqr(xrand, 0)[0], planner.py:344-345 */
     trig_of(o, xs, gt);
     double best = INFINITY, best_all = INFINITY;
     int bi = -1, bai = -1;
@@ -763,7 +769,7 @@ int orc_nearest_prefix(orc* o, const double* x, const double* Sd, int pruning, i
 void orc_costs_prefix(orc* o, const double* xs, const double* Sd, int count, double* out) {
     const int n = o->n;
     double gt[4], e[MAXN], prod[MAXN], Sx[MAXN * MAXN], u0[MAXM] = {0};
-    if (o->model == PEND_LQR && !Sd) { dare_lqr(o, xs, u0, Sx, 0); Sd = Sx; }
+    if (RICCATI(o) && !Sd) { dare_lqr(o, xs, u0, Sx, 0); Sd = Sx; }
     trig_of(o, xs, gt);
     for (int i = 0; i < count; ++i) {
         erf_cached(o, xs, gt, o->state + (size_t)i * n, o->trig + (size_t)i * 4, e);
@@ -818,7 +824,7 @@ void orc_dynamics(const orc* o, const double* x, const double* u, double* xn) {
 }
 int orc_feasible(const orc* o, const double* x, const double* u) { double tr[4]; trig_of(o, x, tr); return feasible(o, x, u, tr); }
 void orc_gain(const orc* o, const double* x, const double* u, double* K) { double tr[4]; trig_of(o, x, tr); gain(o, x, tr, u, K); }
-/* (S, K, doubling iterations) of the Riccati lqr at (x, u) -- PEND_LQR only */
+/* (S, K, doubling iterations) of the Riccati lqr at (x, u) -- PEND_LQR and BOAT_NOV_LQR */
 int orc_lqr(const orc* o, const double* x, const double* u, double* S, double* K) { return dare_lqr(o, x, u, S, K); }
 void orc_erf(const orc* o, const double* xg, const double* x, double* e) {
     double gt[4], tr[4];

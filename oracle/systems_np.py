@@ -538,6 +538,46 @@ class PendulumLqr(DoublePendulum):
         return (S, K)
 
 
+class BoatNoviceLqr(BoatNovice):
+    """
+    demo_boat_novice.py's boat with a Riccati lqr callback written the way a user of the reference would (NumPy + SciPy):
+    A, B by central differences of `dynamics` about (x, 0) (the callback ignores u, like every lqr the reference ships),
+    S = solve_discrete_are(A, B, Q, R), K = (R + B'SB)^-1 B'SA.  The reference Planner driven by it generates
+    tests/golden/traj_boat_novice_lqr_*.npz.
+    """
+
+    def __init__(self, obstacle_seed=0, Q=(1.0, 1.0, 10.0, 0.1, 0.1, 0.1), R=(1e-5, 1e-5, 1e-6), eps=1e-6):
+        BoatNovice.__init__(self, obstacle_seed)
+        self.Q = np.diag(np.asarray(Q, dtype=np.float64))
+        self.R = np.diag(np.asarray(R, dtype=np.float64))
+        self.eps = float(eps)
+        # the demo's error_tol (goal_buffer / 2 = 3 m) makes every sample within 3 m of its nearest node converge on its first
+        # step, so the tree stops growing after ~800 nodes (SURVEY 8d): goal_buffer / 8 like the other boats
+        self.error_tol = list(np.array(self.goal_buffer, dtype=np.float64) / 8)
+
+    def linearize(self, x, u=None):
+        n, m, dt, eps = self.nstates, self.ncontrols, self.plan_kwargs["dt"], self.eps
+        x = np.array(x, dtype=np.float64)
+        u = np.zeros(m)
+        A, B = np.zeros((n, n)), np.zeros((n, m))
+        for j in range(n):
+            d = np.zeros(n)
+            d[j] = eps
+            A[:, j] = (self.dynamics(x + d, np.copy(u), dt) - self.dynamics(x - d, np.copy(u), dt)) / (2 * eps)
+        for j in range(m):
+            d = np.zeros(m)
+            d[j] = eps
+            B[:, j] = (self.dynamics(np.copy(x), u + d, dt) - self.dynamics(np.copy(x), u - d, dt)) / (2 * eps)
+        return A, B
+
+    def lqr(self, x, u):
+        import scipy.linalg
+        A, B = self.linearize(x)
+        S = scipy.linalg.solve_discrete_are(A, B, self.Q, self.R)
+        K = npl.solve(self.R + B.T.dot(S).dot(B), B.T.dot(S).dot(A))
+        return (S, K)
+
+
 # --------------------------------------------------------------------------- synthetic config 5
 
 class DoubleIntegrator(object):
@@ -601,6 +641,7 @@ SYSTEMS = {
     "pendulum": DoublePendulum,
     "double_integrator": DoubleIntegrator,
     "pendulum_lqr": PendulumLqr,
+    "boat_novice_lqr": BoatNoviceLqr,
     "ros_boat": RosBoat,
 }
 

@@ -39,6 +39,13 @@ def test_bench_line_fields():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["sample"]
     assert d["synchronous_mode"]["value"] > d["value"]             # the optional mode is an extra, never the metric
+    # measured by the run itself: shader clock and per-FMA issue cost of a lone wavefront; mean committed wave
+    assert 1500.0 < d["effective_mhz"] < 2600.0
+    ck = d["steer_kernel"]["clock"]
+    assert 3.5 < ck["cycles_per_dependent_fp64_fma"] < 9.0 and 1.0 < ck["ns_per_independent_fp64_fma"] < 5.0
+    assert 8 <= d["config"]["mean_wave"] <= d["config"]["wave_cap"] == 1024
+    # whatever is copied from a committed profile says so
+    assert d["roofline"]["traffic"] is None or d["roofline"]["traffic_static_from"].startswith("profiles/")
 
 
 def test_bench_sharded_code_path_world_of_one():
@@ -46,6 +53,16 @@ def test_bench_sharded_code_path_world_of_one():
     assert d["value"] > 1e4 and "cpu_baseline" not in d
     d = _run(["--no-cpu", "--no-extras", "--shard", "tree"], env={"LQRRT_FORCE_SHARDED": "1"})
     assert d["value"] > 1e4
+
+
+def test_bench_sharded_run_reports_three_curves():
+    """A sharded run (here: a world of one through the native loop and a real RCCL communicator) prints, next to the exact-mode
+    value, the synchronous mode sample-sharded and BASELINE config 5 tree-sharded."""
+    d = _run(["--no-cpu", "--units", "16"], env={"LQRRT_FORCE_SHARDED": "1"})
+    assert "native loop" in d["config"]["parallelism"]
+    assert d["synchronous_mode"]["value"] > d["value"] and "sample-sharded" in d["synchronous_mode"]["parallelism"]
+    c5 = d["config5_tree_sharded"]
+    assert c5["value"] > 1e4 and c5["workload"] == "double_integrator_100k_boxes_50k"
 
 
 def test_bench_config5_workload():

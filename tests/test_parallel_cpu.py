@@ -135,6 +135,60 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _comm_worker(rank, world, port, out):
+    """The communicator handshake of the native sharded loop: rank 0's RCCL unique id reaches every rank through
+    torch.distributed (gloo here); without a GPU lqrrt_comm_create must then refuse with LQRRT_E_NODEVICE, not crash."""
+    import hashlib
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lqrrt_amd import _native as nat
+    from lqrrt_amd import parallel
+    import ctypes as C
+    uid = np.zeros(128, dtype=np.uint8)
+    if rank == 0:
+        nat.check(nat.lib().lqrrt_comm_unique_id(uid.ctypes.data_as(C.c_void_p)))
+    t = torch.from_numpy(uid)
+    dist.broadcast(t, 0)
+    digest = hashlib.sha1(t.numpy().tobytes()).hexdigest()
+    refused = None
+    try:
+        parallel.NativeComm(rank, world, device=0, dist=dist)
+        refused = torch.cuda.is_available() and "created"
+    except nat.NativeError as ex:
+        refused = ex.args[0] if ex.args else True
+    loop = parallel.NativeComm(rank, world)         # the loopback double needs no device
+    loop.close()
+    out.put((rank, int(uid.any() or rank != 0), digest, str(refused)))
+    dist.destroy_process_group()
+
+
+def test_native_comm_handshake_gloo():
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    world = 2
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1] == 1, "rank 0 got no unique id from librccl"
+    assert res[0][2] == res[1][2], "the ranks hold different ids"
+    if not torch.cuda.is_available():
+        assert all("-3" in r[3] or "not available" in r[3] for r in res), res      # LQRRT_E_NODEVICE
+
+
 def test_shard_bounds_cover_wave():
     from lqrrt_amd.parallel import pick_wave, shard_bounds
     for W in (1, 7, 64, 100, 1024):

@@ -457,15 +457,19 @@ def gen_config5(max_nodes=600, n_boxes=3000, tag=None):
 
 
 def gen_pendulum_lqr(max_nodes=120, tag=None):
+    return gen_riccati("pendulum_lqr", max_nodes, tag)
+
+
+def gen_riccati(name, max_nodes, tag=None):
     """
-    The north-star steer pipeline on the reference itself: the REFERENCE's Planner with oracle/systems_np.PendulumLqr's
-    callbacks, whose lqr linearises the demo_pendulum dynamics by central differences and calls
+    The north-star steer pipeline on the reference itself: the REFERENCE's Planner with the callbacks of
+    oracle/systems_np.PendulumLqr / BoatNoviceLqr, whose lqr linearises the demo's dynamics by central differences and calls
     scipy.linalg.solve_discrete_are for every rollout step, new node and sample.
     """
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
-    from systems_np import PendulumLqr
+    from systems_np import SYSTEMS
     lq = rl.import_reference()
-    s = PendulumLqr(OBS_SEED)
+    s = SYSTEMS[name](OBS_SEED)
     cons = lq.Constraints(nstates=s.nstates, ncontrols=s.ncontrols, goal_buffer=s.goal_buffer, is_feasible=s.is_feasible)
     planner = lq.Planner(s.dynamics, s.lqr, cons, error_tol=s.error_tol, erf=s.erf, min_time=60, max_time=61, max_nodes=max_nodes,
                          goal0=s.goal, printing=False, sys_time=lambda: 0.0, **s.plan_kwargs)
@@ -504,7 +508,7 @@ def gen_pendulum_lqr(max_nodes=120, tag=None):
         out["edge_%s_id" % tagid] = np.int32(ID)
         out["edge_%s_x" % tagid] = np.array(tree.x_seq[ID], dtype=np.float64)
         out["edge_%s_u" % tagid] = np.array(tree.u_seq[ID], dtype=np.float64)
-    path = os.path.join(OUT, "traj_pendulum_lqr_%s.npz" % (tag or str(max_nodes)))
+    path = os.path.join(OUT, "traj_%s_%s.npz" % (name, tag or str(max_nodes)))
     np.savez_compressed(path, **out)
     print("wrote %s: iters=%d cand=%d nodes=%d hash=%s goal=%s wall=%.1fs" % (
         path, len(nearest), out["n_candidates"], tree.size, out["pid_hash"], bool(planner.plan_reached_goal), wall))
@@ -540,6 +544,9 @@ def main():
         "di2500": lambda: gen_config5(2500, 3000),
         # finite-difference linearise -> DARE -> K rollout on the reference's Planner (scipy.linalg.solve_discrete_are)
         "plqr120": lambda: gen_pendulum_lqr(120),
+        "plqr600": lambda: gen_pendulum_lqr(600),
+        # the same pipeline at the metric's dimension: demo_boat_novice dynamics, 6 states / 3 controls, Riccati lqr about (x, 0)
+        "bnlqr400": lambda: gen_riccati("boat_novice_lqr", 400),
     }
     if args.job:
         jobs[args.job]()

@@ -15,7 +15,7 @@ O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python $R/bench.py --steps 20 --warmup 5 > $O/bench_plain.json 2> $O/bench_plain.err < /dev/null
-CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu --no-extras"
+CMD="python $R/bench.py --steps 3 --warmup 1 --units 16 --no-cpu --no-extras"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $CMD > $O/bench_under_rocprof.json 2> $O/stats.log < /dev/null
 find $O/stats -name "bench_kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 rm -rf $O/stats

@@ -14,6 +14,9 @@ CONFIGS = [
     ("cfg3 boat_novice, 5k nodes (error_tol = goal_buffer/8)", "boat_novice", {}, 5000, "tight"),
     ("cfg4 boat_advanced, 10k nodes (headline)", "boat_advanced", {}, 10000, None),
     ("cfg5 12-DoF double integrator, 100k boxes, 50k nodes", "double_integrator", dict(n_boxes=100000, seed=0), 50000, None),
+    # the north-star steer pipeline (finite-difference linearise -> doubling DARE -> K per recorded step, S per sample)
+    ("Riccati pendulum (4 states, dt 1 ms), 500 nodes", "pendulum_lqr", {}, 500, None),
+    ("Riccati boat_novice (6 states, 3 controls), 3k nodes", "boat_novice_lqr", {}, 3000, None),
 ]
 for label, name, kw_sys, nodes, mod in CONFIGS:
     cls = lqrrt_amd.systems.SYSTEMS[name]
@@ -51,4 +54,18 @@ for label, name, kw_sys, nodes, mod in CONFIGS:
     print("%-58s %9.0f attempts/s  yield %4.1f %%  grow %6.2f s (%7d attempts)  NN %6.1f us x%-5d %6.2f TB/s alg.  steer %6.1f us" % (
         label, done / dt, 100.0 * acc / max(1, done), t_grow, g.attempts, 1e3 * pr["nn_ms"] / max(1, pr["nn_launches"]), pr["nn_launches"],
         pr["nn_bytes"] / 1e12 / max(1e-9, pr["nn_ms"] / 1e3), 1e3 * pr["steer_ms"] / max(1, pr["steer_launches"])))
+    if getattr(s, "riccati", False):
+        # what one Riccati gain costs: the batched operator, one wavefront per problem (what the rollout calls per recorded step)
+        import torch
+        xs = eng.states()[: min(eng.size, 2048)]
+        us = np.zeros((len(xs), s.ncontrols))
+        eng.lqr_dare_batch(xs[:64], us[:64], s.Q, s.R, s.eps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            _S, _K, _A, _B, iters = eng.lqr_dare_batch(xs, us, s.Q, s.R, s.eps)
+        torch.cuda.synchronize()
+        dt5 = (time.perf_counter() - t0) / 5
+        print("%-58s lqr_dare_batch of %d states: %.1f us per batch (incl. copies), %.1f doubling iterations on average" % (
+            "", len(xs), 1e6 * dt5, float(np.mean(iters))))
     eng.close()
