@@ -58,6 +58,9 @@ extern "C" {
 #define LQRRT_MODEL_BOAT_NOVICE_LQR    9  /* demos/demo_boat_novice.py dynamics (6 states, 3 controls) with the same Riccati lqr,
                                            * linearised about (x, 0): the north-star steer pipeline at the metric's dimension */
 
+#define LQRRT_MODEL_USER               100  /* an out-of-tree problem compiled in with -DLQRRT_USER_SYSTEM='"header.hpp"'
+                                             * (lqrrt_amd/csrc/models.def) */
+
 #define LQRRT_MAX_STATES   12
 #define LQRRT_MAX_CONTROLS 6
 #define LQRRT_MAX_PARAMS   96

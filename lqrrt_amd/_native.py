@@ -16,6 +16,7 @@ MAX_STATES, MAX_CONTROLS, MAX_PARAMS = 12, 6, 96
 MODEL_BOAT_ADVANCED, MODEL_BOAT_INTERMEDIATE, MODEL_BOAT_NOVICE = 1, 2, 3
 MODEL_CAR, MODEL_PENDULUM, MODEL_DOUBLE_INTEGRATOR, MODEL_ROS_BOAT, MODEL_PENDULUM_LQR = 4, 5, 6, 7, 8
 MODEL_BOAT_NOVICE_LQR = 9
+MODEL_USER = 100          # an out-of-tree problem compiled in (csrc/models.def)
 
 E_ARG, E_HIP, E_NODEVICE, E_CAPACITY, E_STATE = -1, -2, -3, -4, -5
 STOP_ATTEMPTS, STOP_NODES, STOP_TARGET, STOP_GOAL = 1, 2, 3, 4

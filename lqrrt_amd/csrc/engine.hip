@@ -217,19 +217,23 @@ struct lqrrt_engine {
 // --------------------------------------------------------------------------------------------
 // model dispatch
 
-#define DISPATCH(e, ...)                                                                          \
-    switch ((e)->model) {                                                                         \
-        case LQRRT_MODEL_BOAT_ADVANCED:     { using S = BoatAdvanced;     __VA_ARGS__; } break;   \
-        case LQRRT_MODEL_BOAT_INTERMEDIATE: { using S = BoatIntermediate; __VA_ARGS__; } break;   \
-        case LQRRT_MODEL_BOAT_NOVICE:       { using S = BoatNovice;       __VA_ARGS__; } break;   \
-        case LQRRT_MODEL_CAR:               { using S = Car;              __VA_ARGS__; } break;   \
-        case LQRRT_MODEL_PENDULUM:          { using S = Pendulum;         __VA_ARGS__; } break;   \
-        case LQRRT_MODEL_DOUBLE_INTEGRATOR: { using S = DoubleIntegratorT<6>; __VA_ARGS__; } break; \
-        case LQRRT_MODEL_ROS_BOAT:          { using S = RosBoat;          __VA_ARGS__; } break;   \
-        case LQRRT_MODEL_PENDULUM_LQR:      { using S = PendulumLqr;      __VA_ARGS__; } break;   \
-        case LQRRT_MODEL_BOAT_NOVICE_LQR:   { using S = BoatNoviceLqr;    __VA_ARGS__; } break;   \
-        default: return fail(LQRRT_E_ARG, "unknown model %d", (e)->model);                        \
+// One registration table (models.def) -> dispatch and per-model properties.  DISPATCH(e, stmt) runs `stmt` with S = the
+// plugin struct of the engine's model.
+template <class T> struct ModelTag { using type = T; };
+template <class F>
+static bool dispatch_model(int model, F&& f) {
+    switch (model) {
+#define LQ_MODEL(ID, TYPE) case ID: f(ModelTag<TYPE>{}); return true;
+#include "models.def"
+#undef LQ_MODEL
     }
+    return false;
+}
+#define DISPATCH(e, ...)                                                                                      \
+    do {                                                                                                      \
+        if (!dispatch_model((e)->model, [&](auto tag__) { using S = typename decltype(tag__)::type; __VA_ARGS__; })) \
+            return fail(LQRRT_E_ARG, "unknown model %d", (e)->model);                                          \
+    } while (0)
 
 // Largest T with fl(sqrt(T)) <= r: `d2 <= T` is then exactly `sqrt(d2) <= r` (sqrt is monotone and
 // correctly rounded), which removes the square root from the collision sweep without changing a bit.
@@ -246,29 +250,31 @@ static size_t geo_lds_bytes(const lqrrt_engine* e);
 
 static int build_box_grid(lqrrt_engine* e, const lqrrt_system_desc* sys);
 
-static bool model_dims(int model, int* n, int* m, int* nw) {
-    switch (model) {
-        case LQRRT_MODEL_BOAT_ADVANCED:
-        case LQRRT_MODEL_BOAT_INTERMEDIATE:
-        case LQRRT_MODEL_ROS_BOAT:
-        case LQRRT_MODEL_BOAT_NOVICE_LQR:
-        case LQRRT_MODEL_BOAT_NOVICE: *n = 6; *m = 3; *nw = 1; return true;
-        case LQRRT_MODEL_CAR: *n = 5; *m = 2; *nw = 1; return true;
-        case LQRRT_MODEL_PENDULUM_LQR:
-        case LQRRT_MODEL_PENDULUM: *n = 4; *m = 1; *nw = 2; return true;
-        case LQRRT_MODEL_DOUBLE_INTEGRATOR: *n = 12; *m = 6; *nw = 0; return true;
-    }
-    return false;
+// per-model properties, read off the plugin struct
+struct ModelInfo { int n, m, nw, wd[2]; bool riccati; int p_q, p_r, p_eps; };
+template <class S> static ModelInfo model_info_of() {
+    ModelInfo mi{S::N, S::M, S::NW, {0, 0}, has_dare_gain<S>::value, -1, -1, -1};
+    for (int k = 0; k < S::NW && k < 2; ++k) mi.wd[k] = S::wd(k);
+    if constexpr (has_dare_gain<S>::value) { mi.p_q = S::P_Q; mi.p_r = S::P_R; mi.p_eps = S::P_EPS; }
+    return mi;
 }
-
+static bool model_info(int model, ModelInfo* out) {
+    return dispatch_model(model, [&](auto tag__) { *out = model_info_of<typename decltype(tag__)::type>(); });
+}
+static bool model_dims(int model, int* n, int* m, int* nw) {
+    ModelInfo mi;
+    if (!model_info(model, &mi)) return false;
+    *n = mi.n; *m = mi.m; *nw = mi.nw;
+    return true;
+}
 // index of the k-th angular (wrapped) state of a model: S::wd(k) on the host
-static int model_wd(int model, int k) { return (model == LQRRT_MODEL_PENDULUM || model == LQRRT_MODEL_PENDULUM_LQR) ? k : 2; }
+static int model_wd(int model, int k) { ModelInfo mi; return model_info(model, &mi) && k < 2 ? mi.wd[k] : 0; }
 // systems whose lqr is a per-state Riccati solution: cooperative gain kernels, one cost-to-go matrix per sample
-static bool model_riccati(int model) { return model == LQRRT_MODEL_PENDULUM_LQR || model == LQRRT_MODEL_BOAT_NOVICE_LQR; }
+static bool model_riccati(int model) { ModelInfo mi; return model_info(model, &mi) && mi.riccati; }
 // where a Riccati system keeps Q, R and the difference step in its parameter block (systems.hpp S::P_Q / P_R / P_EPS)
-static int riccati_q(int model) { return model == LQRRT_MODEL_BOAT_NOVICE_LQR ? 19 : 18; }
-static int riccati_r(int model) { return model == LQRRT_MODEL_BOAT_NOVICE_LQR ? 55 : 34; }
-static int riccati_eps(int model) { return model == LQRRT_MODEL_BOAT_NOVICE_LQR ? 64 : 35; }
+static int riccati_q(int model) { ModelInfo mi; model_info(model, &mi); return mi.p_q; }
+static int riccati_r(int model) { ModelInfo mi; model_info(model, &mi); return mi.p_r; }
+static int riccati_eps(int model) { ModelInfo mi; model_info(model, &mi); return mi.p_eps; }
 static bool model_novice(int model) { return model == LQRRT_MODEL_BOAT_NOVICE || model == LQRRT_MODEL_BOAT_NOVICE_LQR; }
 
 static size_t geo_lds_bytes(const lqrrt_engine* e) {
@@ -424,13 +430,8 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     hipExtLaunchKernelGGL((k_nn_scan<SYS, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
                           e->d_pcost, e->d_pidx, ps_c, ps_t)
     if (Spers) {
-        if (e->model == LQRRT_MODEL_PENDULUM_LQR) {
-            if (tri) NN_ONE(PendulumLqr, S_PERSAMPLE, true); else NN_ONE(PendulumLqr, S_PERSAMPLE, false);
-        } else if (e->model == LQRRT_MODEL_BOAT_NOVICE_LQR) {
-            if (tri) NN_ONE(BoatNoviceLqr, S_PERSAMPLE, true); else NN_ONE(BoatNoviceLqr, S_PERSAMPLE, false);
-        } else {
-            return fail(LQRRT_E_ARG, "per-sample S is only instantiated for Riccati systems");
-        }
+        if (!e->riccati) return fail(LQRRT_E_ARG, "per-sample S is only instantiated for Riccati systems");
+        DISPATCH(e, if constexpr (has_dare_gain<S>::value) { if (tri) NN_ONE(S, S_PERSAMPLE, true); else NN_ONE(S, S_PERSAMPLE, false); });
     } else if (sm == S_BAND2 && e->model == LQRRT_MODEL_DOUBLE_INTEGRATOR) {
         if (tri) NN_ONE(DoubleIntegratorT<6>, S_BAND2, true); else NN_ONE(DoubleIntegratorT<6>, S_BAND2, false);
     } else if (sm == S_DIAG && e->model == LQRRT_MODEL_ROS_BOAT) {

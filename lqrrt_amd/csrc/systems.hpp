@@ -257,7 +257,7 @@ __device__ __forceinline__ bool hull_hits(const GeoL& g, double px, double py, d
 
 struct BoatCommon {
     static constexpr int N = 6, M = 3, NW = 1;
-    __device__ static constexpr int wd(int) { return 2; }
+    __host__ __device__ static constexpr int wd(int) { return 2; }
 
     // K = [kp R(h)' | kd] with diagonal kp, kd (demo_boat_advanced.py:139-151)
     __device__ static void gain_pd(const double* kp, const double* kd, const double* trig, double* K) {
@@ -723,7 +723,7 @@ struct RosBoat : BoatCommon {
 struct Car {
     static constexpr bool TWO_WAVEFRONTS = true;     // k_steer: a second wavefront runs the step tests
     static constexpr int N = 5, M = 2, NW = 1;
-    __device__ static constexpr int wd(int) { return 2; }
+    __host__ __device__ static constexpr int wd(int) { return 2; }
     // params: 0 invM[2] | 2 D[2] | 4 u_lo[2] | 6 u_hi[2] | 8 velmax0 | 9 kp[2] | 11 kd[2]
     __device__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
         // K = [kp * rows(0,2) of R' | kd]  (demo_car.py:98-113)
@@ -754,7 +754,7 @@ struct Car {
 
 struct Pendulum {
     static constexpr int N = 4, M = 1, NW = 2;
-    __device__ static constexpr int wd(int k) { return k; }
+    __host__ __device__ static constexpr int wd(int k) { return k; }
     // params: 0 a=(m0+m1)L0^2+m1L1^2 | 1 b2=2 m1 L0 L1 | 2 m1 L1^2 | 3 h=m1 L0 L1 | 4 g0=g(m0+m1)L0
     //         5 g1=m1 g L1 | 6 d[2] | 8 b[2] | 10 c[2] | 12 umax | 13 umax_plan | 14 K[4]
     __device__ static void gain(const double* P, const double*, const double*, const double*, double* K) {
@@ -820,7 +820,7 @@ template <int D>
 struct DoubleIntegratorT {
     static constexpr bool TWO_WAVEFRONTS = true;     // k_steer: a second wavefront runs the step tests
     static constexpr int N = 2 * D, M = D, NW = 0;
-    __device__ static constexpr int wd(int) { return 0; }
+    __host__ __device__ static constexpr int wd(int) { return 0; }
     // params: 0 dt of the model | 1 K[D][2D] constant DARE gain (row-major)
     __device__ static void gain(const double* P, const double*, const double*, const double*, double* K) {
 #pragma unroll
@@ -861,6 +861,16 @@ struct DoubleIntegratorT {
         return __any(hit) == 0;
     }
 };
+
+}  // namespace lq
+
+// An out-of-tree problem: the header named on the hipcc command line defines lq::UserSystem with the
+// same static interface as the structs above (N, M, NW, wd, gain, step, feasible; optionally TWO_WAVEFRONTS / DARE_GAIN).
+#ifdef LQRRT_USER_SYSTEM
+#include LQRRT_USER_SYSTEM
+#endif
+
+namespace lq {
 
 // cos/sin of every angular state of x: trig[2k], trig[2k+1] = cos, sin of x[wd(k)]
 template <class S>

@@ -615,6 +615,34 @@ class DoubleIntegrator(NativeSystem):
         return np.concatenate(([self.dt_model], self.K.ravel()))
 
 
+class UserSystem(NativeSystem):
+    """
+    Host-side description of an out-of-tree problem (INTEGRATION.md section 5): the device code is lq::UserSystem of the header
+    the library was built with (tools/build_user_system.py, loaded through LQRRT_LIB); this object carries the numbers --
+    parameter block, dimensions, hull / obstacle tables, and the planning set-up the demos keep in module globals.
+    """
+    model = nat.MODEL_USER
+
+    def __init__(self, nstates, ncontrols, params, wrap_dims=(), x0=None, goal=None, goal_buffer=None, error_tol=None,
+                 sample_space=None, goal_bias=None, plan_kwargs=None, vps=None, obs=None, S=None):
+        NativeSystem.__init__(self)
+        self.nstates, self.ncontrols = int(nstates), int(ncontrols)
+        self._params = np.ascontiguousarray(params, dtype=np.float64)
+        self.wrap_dims = tuple(wrap_dims)
+        self.x0 = np.zeros(self.nstates) if x0 is None else np.array(x0, dtype=np.float64)
+        self.goal, self.goal_buffer, self.error_tol = goal, goal_buffer, error_tol
+        self.sample_space, self.goal_bias = sample_space, goal_bias
+        self.plan_kwargs = dict(plan_kwargs or dict(horizon=2, dt=0.1, FPR=0))
+        if vps is not None:
+            self.vps = np.ascontiguousarray(vps, dtype=np.float64).reshape(2, -1)
+        if obs is not None:
+            self.obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, 3)
+        self.S = None if S is None else np.array(S, dtype=np.float64)
+
+    def params(self):
+        return self._params
+
+
 SYSTEMS = {
     "boat_advanced": BoatAdvanced,
     "boat_intermediate": BoatIntermediate,

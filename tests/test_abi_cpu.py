@@ -166,8 +166,11 @@ def test_steer_kernels_use_no_scratch():
     import kernel_resources as kr
     if not shutil.which(kr.HIPCC) and not os.path.exists(kr.HIPCC):
         pytest.skip("hipcc not available")
-    rows = kr.parse(kr.remarks())
+    # (compiled with the out-of-tree example problem in: a user's kernels obey the same rule)
+    user = os.path.join(ROOT, "examples", "user_system", "unicycle.hpp")
+    rows = kr.parse(kr.remarks(["-DLQRRT_USER_SYSTEM=\"%s\"" % user]))
     steer = [r for r in rows if "k_steer<" in r["name"]]
+    assert any("UserSystem" in r["name"] for r in steer)
     scan = [r for r in rows if "k_nn_scan<" in r["name"]]
     assert len(steer) >= 14 and len(scan) >= 20
     assert all(r["scratch"] == 0 for r in steer), [(r["name"][:60], r["scratch"]) for r in steer if r["scratch"]]
