@@ -1,0 +1,299 @@
+// ABI: library info, engine creation / destruction, resolution, sampler, geometry swap, wave mode, MT19937 state.
+// Fragment of engine.hip.
+// --------------------------------------------------------------------------------------------
+// lifecycle
+
+extern "C" const char* lqrrt_last_error(void) { return g_err.c_str(); }
+extern "C" int lqrrt_abi_version(void) { return LQRRT_ABI_VERSION; }
+
+extern "C" int lqrrt_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return c;
+}
+
+static void free_all(lqrrt_engine* e) {
+    void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_og, e->d_ogc, e->d_cell_start, e->d_cell_items, e->d_S, e->tv.state, e->tv.trig, e->tv.werr, e->tv.K, e->tv.pID, e->tv.elen,
+                    e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_M,
+                    e->d_pidx, e->d_par_done, e->d_par_want, e->d_list,
+                    e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_pool_trig, e->d_pool_S, e->d_QR, e->d_Sop, e->d_cand, e->d_flags,
+                    e->d_M2, e->d_lf[0], e->d_lf[1], e->d_par2, e->d_stale2, e->d_changed2, e->d_rctl, e->d_rank,
+                    e->d_blk, e->d_blk_cursor};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e->h_ign_pin) (void)hipHostFree(e->h_ign_pin);
+    if (e->h_summary) (void)hipHostFree(e->h_summary);
+    if (e->h_rank) (void)hipHostFree(e->h_rank);
+    if (e->h_round) (void)hipHostFree(e->h_round);
+}
+
+static int alloc_wave(lqrrt_engine* e) {
+    // (re)allocates everything that depends on H (record size, edge pools)
+    void* old[] = {e->tv.xedge, e->tv.uedge, e->d_rec};
+    for (void* p : old)
+        if (p) (void)hipFree(p);
+    e->tv.xedge = e->tv.uedge = nullptr; e->d_rec = nullptr;
+    e->L = make_layout(e->n, e->m, e->nw, e->H);
+    e->tv.H = e->H;
+    TRY(dalloc(&e->tv.xedge, (size_t)e->cap * e->H * e->n));
+    TRY(dalloc(&e->tv.uedge, (size_t)e->cap * e->H * e->m));
+    TRY(dalloc(&e->d_rec, (size_t)e->maxW * e->L.R));
+    HIPCHK(hipMemset(e->d_rec, 0, (size_t)e->maxW * e->L.R * sizeof(double)));
+    return 0;
+}
+
+extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int capacity, int max_wave,
+                                   lqrrt_engine** out) {
+    if (!sys || !out) return fail(LQRRT_E_ARG, "null argument");
+    *out = nullptr;
+    int n, m, nw;
+    if (!model_dims(sys->model, &n, &m, &nw)) return fail(LQRRT_E_ARG, "unknown model %d", sys->model);
+    if (sys->nstates != n || sys->ncontrols != m)
+        return fail(LQRRT_E_ARG, "model %d expects nstates=%d ncontrols=%d, got %d/%d", sys->model, n, m,
+                    sys->nstates, sys->ncontrols);
+    if (capacity < 2 || max_wave < 1 || max_wave > 4096)
+        return fail(LQRRT_E_ARG, "capacity must be >= 2 and 1 <= max_wave <= 4096");
+    if (sys->n_params < 0 || sys->n_params > LQRRT_MAX_PARAMS) return fail(LQRRT_E_ARG, "bad n_params");
+    if (lqrrt_device_count() <= device || device < 0)
+        return fail(LQRRT_E_NODEVICE, "HIP device %d not available (found %d)", device, lqrrt_device_count());
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (prop.warpSize != 64) return fail(LQRRT_E_NODEVICE, "wavefront size %d != 64 (gfx950 expected)", prop.warpSize);
+
+    lqrrt_engine* e = new lqrrt_engine();
+    e->device = device; e->model = sys->model; e->n = n; e->m = m; e->nw = nw;
+    e->cap = ((capacity + 63) / 64) * 64; e->maxW = max_wave; e->H = 1;
+    memset(&e->P, 0, sizeof e->P);
+    memcpy(e->P.p, sys->params, sizeof(double) * sys->n_params);
+    int rc = 0;
+    if ((sys->n_vertices > 0 && !sys->vps) || (sys->n_obstacles > 0 && !sys->obs)) {
+        delete e;
+        return fail(LQRRT_E_ARG, "vps/obs pointer missing");
+    }
+    e->riccati = model_riccati(sys->model);
+    rc = upload_geometry(e, sys);
+    if (!rc) rc = upload_weights(e);
+    if (!rc && e->riccati) rc = dalloc(&e->d_Sop, (size_t)e->maxW * n * n);
+    e->tv.cap = e->cap;
+    if (!rc) rc = dalloc(&e->tv.state, (size_t)n * e->cap);
+    if (!rc) rc = dalloc(&e->tv.trig, (size_t)(2 * nw + 1) * e->cap);
+    if (!rc) rc = dalloc(&e->tv.werr, (size_t)(nw + 1) * e->cap);
+    if (!rc) rc = dalloc(&e->tv.K, (size_t)e->cap * m * n);
+    if (!rc) rc = dalloc(&e->tv.pID, (size_t)e->cap);
+    if (!rc) rc = dalloc(&e->tv.elen, (size_t)e->cap);
+    if (!rc) rc = dalloc(&e->tv.ignore, (size_t)e->cap / 64 + 1);
+    if (!rc && hipMemset(e->tv.ignore, 0, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1)) != hipSuccess) rc = fail(LQRRT_E_HIP, "hipMemset failed");
+    const size_t pw = (size_t)lqrrt_engine::MAXCH * e->maxW;
+    if (!rc) rc = dalloc(&e->d_pcost, pw);
+    if (!rc) rc = dalloc(&e->d_pidx, pw);
+    if (!rc) rc = dalloc(&e->d_M, (size_t)lqrrt_engine::MATRIX_MAX_W * lqrrt_engine::MATRIX_MAX_W);
+    if (!rc) rc = dalloc(&e->d_par_done, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_par_want, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_list, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_changed, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_stale, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_need, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_summary, (size_t)4);
+    if (!rc) rc = dalloc(&e->d_M2, (size_t)lqrrt_engine::MATRIX_MAX_W * lqrrt_engine::MATRIX_MAX_W);
+    if (!rc) rc = dalloc(&e->d_lf[0], (size_t)2 * e->maxW);
+    if (!rc) rc = dalloc(&e->d_lf[1], (size_t)2 * e->maxW);
+    if (!rc) rc = dalloc(&e->d_par2, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_stale2, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_changed2, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_rctl, (size_t)16);
+    if (!rc) rc = dalloc(&e->d_rank, (size_t)e->maxW);
+    if (!rc && hipMemset(e->d_rctl, 0, sizeof(int) * 16) != hipSuccess) rc = fail(LQRRT_E_HIP, "hipMemset failed");
+    const unsigned hflags = hipHostMallocMapped | hipHostMallocCoherent;
+    if (!rc && hipHostMalloc((void**)&e->h_summary, sizeof(int) * (4 + 3 * (size_t)e->maxW), hflags) != hipSuccess)
+        rc = fail(LQRRT_E_HIP, "hipHostMalloc failed");
+    if (!rc && hipHostMalloc((void**)&e->h_rank, sizeof(int) * (size_t)e->maxW, hflags) != hipSuccess)
+        rc = fail(LQRRT_E_HIP, "hipHostMalloc failed");
+    if (!rc && (hipHostGetDevicePointer((void**)&e->h_summary_dev, e->h_summary, 0) != hipSuccess ||
+                hipHostGetDevicePointer((void**)&e->h_rank_dev, e->h_rank, 0) != hipSuccess))
+        rc = fail(LQRRT_E_HIP, "hipHostGetDevicePointer failed");
+    if (!rc) memset(e->h_summary, 0, sizeof(int) * 4);
+    if (!rc && hipHostMalloc((void**)&e->h_round, sizeof(int) * (8 + 3 * (size_t)e->maxW), hflags) != hipSuccess)
+        rc = fail(LQRRT_E_HIP, "hipHostMalloc failed");
+    if (!rc && hipHostGetDevicePointer((void**)&e->h_round_dev, e->h_round, 0) != hipSuccess) rc = fail(LQRRT_E_HIP, "hipHostGetDevicePointer failed");
+    if (!rc) memset(e->h_round, 0, sizeof(int) * 8);
+    if (!rc && hipHostMalloc((void**)&e->h_ign_pin, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1), hipHostMallocDefault) != hipSuccess)
+        rc = fail(LQRRT_E_HIP, "hipHostMalloc failed");
+    if (!rc) rc = alloc_wave(e);
+    if (rc) { free_all(e); delete e; return rc; }
+    e->h_pid.reserve(e->cap); e->h_elen.reserve(e->cap);
+    e->h_ign.assign((size_t)e->cap / 64 + 1, 0ull);
+    for (int i = 0; i < 624; ++i) e->mt_gen.key[i] = 0;
+    e->mt_gen.pos = 624;
+    e->mt_base = e->mt_gen;
+    *out = e;
+    return 0;
+}
+
+extern "C" int lqrrt_engine_destroy(lqrrt_engine* e) {
+    if (hostprof_on()) {
+        long tot = 0;
+        for (long v : g_steer_hist) tot += v;
+        if (tot > 0) {
+            fprintf(stderr, "[hostprof] event-timed steer launches by duration (4 us buckets, incl. the 4.1 us event floor):");
+            for (int i = 0; i < 16; ++i) fprintf(stderr, " %d-%d:%ld", 4 * i, 4 * i + 4, g_steer_hist[i]);
+            fprintf(stderr, "\n");
+        }
+    }
+    if (hostprof_on() && g_hp.waves > 0)
+        fprintf(stderr, "[hostprof] per wave over %ld waves (us): sampler+ignore upload %.1f | scan launch %.1f | steer launch %.1f | waiting for rounds %.1f | commit bookkeeping %.1f\n",
+                g_hp.waves, g_hp.flush / g_hp.waves, g_hp.nn / g_hp.waves, g_hp.steer / g_hp.waves, g_hp.wait / g_hp.waves, g_hp.book / g_hp.waves);
+    if (!e) return 0;
+    (void)hipSetDevice(e->device);
+    prof_flush(e);
+    for (hipEvent_t ev : e->ev_free) (void)hipEventDestroy(ev);
+    e->ev_free.clear();
+    free_all(e);
+    delete e;
+    return 0;
+}
+
+extern "C" int lqrrt_engine_set_dense_S(lqrrt_engine* e, const double* S_host) {
+    // constant dense cost-to-go matrix of the system (lqr(x,u)[0]); NULL restores identity
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    TRY(use_device(e));
+    if (e->d_S) { (void)hipFree(e->d_S); e->d_S = nullptr; }
+    if (S_host) {
+        TRY(dalloc(&e->d_S, (size_t)e->n * e->n));
+        HIPCHK(hipMemcpy(e->d_S, S_host, sizeof(double) * e->n * e->n, hipMemcpyHostToDevice));
+        // classify S so that the scans can leave its zero terms out (quad_cost)
+        const int n = e->n, h = n / 2;
+        bool diag = true, band2 = (n % 2 == 0);
+        for (int j = 0; j < n; ++j)
+            for (int k = 0; k < n; ++k) {
+                const bool nz = S_host[j * n + k] != 0.0;
+                if (nz && j != k) diag = false;
+                if (nz && band2 && (j % h) != (k % h)) band2 = false;
+            }
+        e->smode = diag ? S_DIAG : (band2 ? S_BAND2 : S_DENSE);
+        if (getenv("LQRRT_S_DENSE")) e->smode = S_DENSE;
+    }
+    return 0;
+}
+
+extern "C" int lqrrt_engine_set_resolution(lqrrt_engine* e, const lqrrt_resolution* r) {
+    if (!e || !r) return fail(LQRRT_E_ARG, "null argument");
+    if (r->horizon_iters < 1 || r->horizon_iters > 4096) return fail(LQRRT_E_ARG, "horizon_iters out of range");
+    if (!(r->dt > 0)) return fail(LQRRT_E_ARG, "dt must be positive");
+    TRY(use_device(e));
+    e->res.dt = r->dt; e->res.FPR = r->FPR; e->res.H = r->horizon_iters; e->res.adaptive = r->adaptive ? 1 : 0;
+    e->hspan_min = std::max(1, (int)r->hspan_min);
+    e->h_iters = r->adaptive ? std::max(1, (int)r->horizon_iters_state) : r->horizon_iters;
+    for (int d = 0; d < MAXN; ++d) {
+        e->res.tol[d] = r->error_tol[d];
+        e->res.goal_lo[d] = r->goal_lo[d];
+        e->res.goal_hi[d] = r->goal_hi[d];
+        e->goal[d] = r->goal[d];
+    }
+    const bool goal_changed = true;
+    e->d_pool_count = 0;                                      // per-sample trig / S tables are rebuilt with the next upload
+    e->has_goal = r->has_goal != 0;
+    e->has_res = true;
+    if (r->horizon_iters != e->H) {
+        e->N = 0;   // edge pools are re-laid out: the tree must be reset afterwards
+        e->H = r->horizon_iters;
+        TRY(alloc_wave(e));
+    }
+    if (goal_changed) {
+        // goal-biased samples depend on the goal: drop prepared-but-unused samples and rewind the generator
+        e->pool.clear(); e->pool_rows_end.clear();
+        e->pool_base = e->cursor;
+        MT g = e->mt_base;
+        for (int64_t i = 0; i < (e->committed_row - e->base_row) * (int64_t)(e->n + 1); ++i) (void)g.next_double();
+        e->mt_base = g; e->base_row = e->committed_row;
+        e->mt_gen = g; e->gen_row = e->committed_row; e->pregen_rows = 0;
+        e->tries_carry = 0; e->d_pool_count = 0;
+    }
+    return 0;
+}
+
+extern "C" int lqrrt_engine_horizon_iters(lqrrt_engine* e) { return e ? e->h_iters : LQRRT_E_ARG; }
+
+// Queued (not yet committed) samples depend on the goal, the sampler settings and the feasibility of the world:
+// drop them and rewind the generator to the first uncommitted candidate row.
+static void invalidate_samples(lqrrt_engine* e) {
+    e->pool.clear(); e->pool_rows_end.clear();
+    e->pool_base = e->cursor;
+    MT g = e->mt_base;
+    for (int64_t i = 0; i < (e->committed_row - e->base_row) * (int64_t)(e->n + 1); ++i) (void)g.next_double();
+    e->mt_base = g; e->base_row = e->committed_row;
+    e->mt_gen = g; e->gen_row = e->committed_row; e->pregen_rows = 0;
+    e->tries_carry = 0; e->d_pool_count = 0;
+}
+
+extern "C" int lqrrt_engine_set_sampler(lqrrt_engine* e, const lqrrt_sampler_desc* s) {
+    if (!e || !s) return fail(LQRRT_E_ARG, "null argument");
+    if (s->tries_limit < 1) return fail(LQRRT_E_ARG, "tries_limit must be >= 1");
+    e->smp = *s;
+    e->has_sampler = true;
+    e->explicit_samples = false;
+    invalidate_samples(e);
+    // fixed angular coordinates: zero-width span and never goal-biased on every wrapped state (planner.py:201-206:
+    // the sample's angle is then `center` in every draw)
+    FixedAngles fx;
+    memset(&fx, 0, sizeof fx);
+    fx.on = e->nw > 0;
+    for (int k = 0; k < e->nw; ++k) {
+        const int d = model_wd(e->model, k);
+        if (s->spans[d] != 0.0 || s->goal_bias[d] > 0.0) fx.on = 0;
+        const double ang = s->centers[d] + s->spans[d] * (0.5 - 0.5);
+        lq_sincos(ang, &fx.t[2 * k + 1], &fx.t[2 * k]);
+    }
+    if (memcmp(&fx, &e->fix, sizeof fx) != 0) { e->fix = fx; e->werr_valid = false; }
+    return 0;
+}
+
+extern "C" int lqrrt_engine_set_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys, void* stream) {
+    if (!e || !sys) return fail(LQRRT_E_ARG, "null argument");
+    if (sys->model != e->model || sys->nstates != e->n || sys->ncontrols != e->m)
+        return fail(LQRRT_E_ARG, "set_geometry cannot change the model (engine: model %d, %d states)", e->model, e->n);
+    if (sys->n_params < 0 || sys->n_params > LQRRT_MAX_PARAMS) return fail(LQRRT_E_ARG, "bad n_params");
+    if ((sys->n_vertices > 0 && !sys->vps) || (sys->n_obstacles > 0 && !sys->obs)) return fail(LQRRT_E_ARG, "vps/obs pointer missing");
+    TRY(use_device(e));
+    (void)stream;
+    HIPCHK(hipDeviceSynchronize());                          // nothing in flight, on any stream, may still read the old tables
+    free_geometry(e);
+    memset(&e->P, 0, sizeof e->P);
+    memcpy(e->P.p, sys->params, sizeof(double) * sys->n_params);
+    TRY(upload_geometry(e, sys));
+    TRY(upload_weights(e));
+    e->d_pool_count = 0;                                      // (per-sample S of the device pool depends on the parameters)
+    if (!e->explicit_samples) invalidate_samples(e);          // queued samples were filtered against the old world
+    return 0;
+}
+
+extern "C" int lqrrt_engine_set_wave_mode(lqrrt_engine* e, int mode) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    if (mode != LQRRT_WAVE_EXACT && mode != LQRRT_WAVE_SYNCHRONOUS) return fail(LQRRT_E_ARG, "unknown wave mode %d", mode);
+    e->sync_mode = mode == LQRRT_WAVE_SYNCHRONOUS;
+    return 0;
+}
+
+extern "C" int lqrrt_engine_set_mt19937(lqrrt_engine* e, const uint32_t* key624, int pos) {
+    if (!e || !key624) return fail(LQRRT_E_ARG, "null argument");
+    if (pos < 0 || pos > 624) return fail(LQRRT_E_ARG, "bad MT19937 position");
+    memcpy(e->mt_gen.key, key624, sizeof(uint32_t) * 624);
+    e->mt_gen.pos = pos;
+    e->mt_base = e->mt_gen;
+    e->pregen_rows = 0;
+    e->base_row = e->gen_row = e->committed_row = 0;
+    e->pool.clear(); e->pool_rows_end.clear();
+    e->pool_base = e->cursor;
+    e->tries_carry = 0; e->d_pool_count = 0;
+    return 0;
+}
+
+extern "C" int lqrrt_engine_get_mt19937(lqrrt_engine* e, uint32_t* key624, int* pos) {
+    if (!e || !key624 || !pos) return fail(LQRRT_E_ARG, "null argument");
+    MT g = e->mt_base;
+    for (int64_t i = 0; i < (e->committed_row - e->base_row) * (int64_t)(e->n + 1); ++i) (void)g.next_double();
+    e->mt_base = g; e->base_row = e->committed_row;
+    memcpy(key624, g.key, sizeof(uint32_t) * 624);
+    *pos = g.pos;
+    return 0;
+}

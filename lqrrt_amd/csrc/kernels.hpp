@@ -8,23 +8,34 @@
 //   k_tree_root / k_append   <- Tree.__init__ / Tree.add_node             tree.py:50-96
 //   k_decide                 (build-only: exact-mode wave validation, see engine.hip)
 //
-// Execution model choices (MI355X):
-//   * NN scan: one lane = one sample; each workgroup stages its chunk of nodes into LDS with
-//     coalesced loads (the tree is SoA, node index fastest) and then every lane walks the same
-//     node sequence through LDS broadcasts; no cross-lane traffic at all, each lane keeps its
-//     own running (min, argmin).  The grid is (sample groups) x (node chunks)
-//     so that >> 1024 wavefronts cover the 256 CUs x 4 SIMDs even though one wave of samples
-//     is only 16 wavefronts wide.  The node table is tiny (480 KB at 10k x 6) and lives in L2;
-//     the kernel is bound by fp64 VALU (the per-pair atan2), see DESIGN.md.
-//   * steer: one problem per wavefront (64-thread blocks); the scalar rollout is computed
-//     redundantly by all lanes (wave-uniform, no divergence) and the lanes split the
-//     hull x obstacle collision sweep; the edge under construction lives in LDS.
+// Execution model choices (MI355X; DESIGN.md section 4 has the measurements):
+//   * NN scan: one lane = one sample, one wavefront per workgroup, grid = (64-sample groups) x (node chunks) with an
+//     XCD-aware tile mapping.  The loop over a chunk's nodes is wave-uniform, so node data is fetched by the SCALAR unit
+//     (s_load_dwordx8: four consecutive nodes per state component of the SoA table, straight from L2 / scalar cache) and
+//     used as the scalar operand of the per-lane fp64 arithmetic: no LDS and no vector-memory instruction in the inner loop
+//     (round 1 staged tiles in LDS and was bound by the LDS pipe).  Angle errors come from a per-node table when the
+//     sampler's angular coordinates are fixed.  Bound by fp64 issue, not by HBM: the node table is cache-resident.
+//   * steer: one problem per WORKGROUP of 1-4 wavefronts.  Every value of a rollout is wave-uniform; the lanes only split the
+//     hull x obstacle sweep.  The boats with the heading torque spread a step over up to four SIMDs (main / torque /
+//     checker / next heading, two barriers per step); other analytic-gain systems run the step tests on a second wavefront;
+//     Riccati systems keep one wavefront (dare.hpp uses all of it).  Edge history, geometry and constants in LDS; no
+//     scratch in any instantiation (tests/test_abi_cpu.py).
+//   * exact-mode repair rounds of waves <= 256 are fused into k_steer launches (RoundArgs): every workgroup decides for its
+//     own sample, re-steers if it must; the last one to finish closes the round and, on convergence, prepares the commit.
+//   * gfx9-specific assumptions (the build is refused for any other target below; this file is gfx950 code, not portable HIP):
+//     a wavefront that has returned drops out of the workgroup barrier count, so the main wavefront may execute
+//     __syncthreads() after its helpers left; `s_waitcnt vmcnt(0)` covers stores as well as loads (gfx10+ counts stores
+//     separately in vscnt), which the publication of a round's summary to pinned host memory relies on.
 #pragma once
 #include <type_traits>
 #include "systems.hpp"
 #include "dare.hpp"
 
 namespace lq {
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "kernels.hpp is gfx950 code (64-wide wavefronts, gfx9 barrier and s_waitcnt semantics): build with --offload-arch=gfx950"
+#endif
 
 // Resolution / goal block (Planner.set_resolution / set_goal), passed by value.
 struct Res {

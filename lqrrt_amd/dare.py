@@ -4,7 +4,8 @@ Discrete algebraic Riccati equation for the LQR contract of the reference
 
 No shipped demo of the reference actually solves a Riccati equation (their `lqr` returns a
 constant S and an analytic PD gain), so this operator is an addition of the build; its golden
-is scipy.linalg.solve_discrete_are (tests/test_dare.py).
+is scipy.linalg.solve_discrete_are (tests/test_dare_gpu.py::test_dare_batch_vs_scipy on the device,
+tests/test_pendulum_lqr.py for the systems whose lqr is a Riccati solution).
 
 `dare_doubling` is the structure-preserving doubling algorithm (Chu, Fan, Lin, Wang 2004):
 quadratically convergent (~9 iterations to 1e-14 for the double integrator, versus >100 plain

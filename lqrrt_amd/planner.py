@@ -210,6 +210,8 @@ class Planner:
                 break
             if time_elapsed >= max_time or self.tree.size > self.max_nodes:
                 # no goal hit (or not enough time spent): plan to the node nearest the guide state (planner.py:311-323)
+                if getattr(self.system, "riccati", False):
+                    self.system._engine(self.dt)       # the lqr handle of a Riccati system linearises with THIS planner's dt
                 Sguide = np.array(self.lqr(self.xguide, np.zeros(self.ncontrols))[0], dtype=np.float64)
                 Sguide[:, np.isinf(np.asarray(self.constraints.goal_buffer, dtype=np.float64))] = 0
                 ids, _ = eng.nn_argmin(self.xguide.reshape(1, -1), S=Sguide, use_ignore=False)
