@@ -68,3 +68,8 @@ tail -c 400 $O/bench_plain.json
 # 9. what an instruction costs when a wavefront has a SIMD to itself; cost of a workgroup barrier hand-off
 $R/tools/micro/issue.bin > $O/issue.txt 2>&1
 $R/tools/micro/barrier.bin > $O/barrier.txt 2>&1
+# 10. the N > 1 code path on this one GPU: native sharded loop, real RCCL communicator, world of one (+ its two extra curves)
+LQRRT_FORCE_SHARDED=1 timeout 600 python $R/bench.py --steps 20 --warmup 5 --no-cpu > $O/bench_forced_sharded.json 2> $O/bench_forced_sharded.err < /dev/null
+# 11. every BASELINE configuration + the two Riccati systems; busy / gap breakdown of the loop's kernel timeline
+timeout 600 python $R/tools/run_configs.py 2>&1 | grep -v amdgpu.ids > $O/configs.txt
+bash $R/tools/timeline.sh > /dev/null 2>&1; python $R/tools/timeline_report.py $R/gpurun_out/kt_tail.csv > $O/timeline.txt 2>&1

@@ -69,14 +69,15 @@ def pmc(a, b, part, note):
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
     src = os.path.join(ROOT, "gpurun_out", "prof")
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(out, "%s_kernel_stats.csv" % rnd))
     for a, b in (("bench_plain.json", "bench.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"),
                  ("launch_floor.txt", "launch_floor.txt"), ("launch_chain.txt", "launch_chain.txt"), ("nn_bench.txt", "nn_bench.txt"),
-                 ("issue.txt", "issue.txt"), ("barrier.txt", "barrier.txt")):
+                 ("issue.txt", "issue.txt"), ("barrier.txt", "barrier.txt"), ("bench_forced_sharded.json", "bench_forced_sharded.json"),
+                 ("configs.txt", "configs.txt"), ("timeline.txt", "timeline.txt")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(out, "%s_%s" % (rnd, b)))
     for f in glob.glob(os.path.join(ROOT, "gpurun_out", "teacher_*.json")):
@@ -86,7 +87,7 @@ def main():
     kern = "k_nn_scan<lq::BoatAdvanced, 0, false>"
     kf, kw = kernel(fetch, kern), kernel(write, kern)
     traffic = {
-        "kernel": kern, "command": "python bench.py --steps 3 --warmup 1 --no-cpu --no-extras (3 x 16,384 attempts in the 10k-node window)",
+        "kernel": kern, "command": "python bench.py --steps 3 --warmup 1 --units 16 --no-cpu --no-extras (3 x 16,384 attempts in the 10k-node window)",
         "launches": kf["launches_steady"], "launches_note": "second half of the process's launches = the windowed loop at 9.5k-10.5k nodes",
         "FETCH_SIZE_KiB_per_launch": kf["per_launch"]["FETCH_SIZE"], "WRITE_SIZE_KiB_per_launch": kw["per_launch"]["WRITE_SIZE"],
         "fetch_correction": 2.0,
