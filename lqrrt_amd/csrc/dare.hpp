@@ -30,45 +30,58 @@ __device__ __forceinline__ void mm(double* C, const double* A, const double* B, 
     __syncthreads();
 }
 
-// Solves W X = RHS in place (Gauss-Jordan, partial pivoting); W is n x n, RHS is n x q; both destroyed/overwritten.
-__device__ __forceinline__ void solve_inplace(double* W, double* RHS, int n, int q, int lane) {
+// Solves W X = RHS in place (Gauss-Jordan, partial pivoting: largest |entry| of the column, lowest row on ties); W is n x n,
+// RHS is n x q, row-major; W is destroyed, RHS becomes X.  One wavefront; the sums of an entry run in one lane in a fixed order,
+// so every right-hand-side column gets the same bits whether it is solved alone or next to others.
+//   per pivot: every lane scans the column itself (n broadcast LDS reads instead of a 6-stage butterfly), lanes j < n + q
+//   divide the pivot row once, and one pass over the n (n + q) entries scales and eliminates (reads, barrier, writes).
+template <int n, int q>
+__device__ __forceinline__ void solve_inplace(double* W, double* RHS, int lane) {
+    constexpr int C = n + q, E = n * C, IT = (E + 63) / 64;
+    static_assert(C <= 64, "one lane per column of [W | RHS]");
+#pragma unroll 1
     for (int p = 0; p < n; ++p) {
-        // pivot search over rows >= p (lanes over rows, then a butterfly)
         double best = -1.0;
         int brow = p;
-        for (int r = p + lane; r < n; r += 64) {
+#pragma unroll
+        for (int r = 0; r < n; ++r) {
+            if (r < p) continue;
             const double v = fabs(W[r * n + p]);
             if (v > best) { best = v; brow = r; }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ob = __shfl_xor(best, off);
-            const int orow = __shfl_xor(brow, off);
-            if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
-        }
+        brow = __builtin_amdgcn_readfirstlane(brow);
         if (brow != p) {
-            for (int j = lane; j < n + q; j += 64) {
-                double* a = j < n ? &W[p * n + j] : &RHS[p * q + (j - n)];
-                double* b = j < n ? &W[brow * n + j] : &RHS[brow * q + (j - n)];
+            if (lane < C) {
+                double* a = lane < n ? &W[p * n + lane] : &RHS[p * q + (lane - n)];
+                double* b = lane < n ? &W[brow * n + lane] : &RHS[brow * q + (lane - n)];
                 const double t = *a; *a = *b; *b = t;
             }
+            __syncthreads();
         }
-        __syncthreads();
         const double piv = W[p * n + p];
-        __syncthreads();
-        for (int j = lane; j < n + q; j += 64) {
-            if (j < n) W[p * n + j] = W[p * n + j] / piv; else RHS[p * q + (j - n)] = RHS[p * q + (j - n)] / piv;
+        double yl = 0.0;
+        if (lane < C) yl = (lane < n ? W[p * n + lane] : RHS[p * q + (lane - n)]) / piv;       // the scaled pivot row
+        double nv[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int idx = lane + 64 * k;
+            const int r = idx / C, j = idx % C;
+            const double y = __shfl(yl, j);
+            nv[k] = y;
+            if (idx < E && r != p) {
+                const double f = W[r * n + p];
+                double x = j < n ? W[r * n + j] : RHS[r * q + (j - n)];
+                x -= f * y;
+                nv[k] = x;
+            }
         }
-        __syncthreads();
-        for (int idx = lane; idx < n * (n + q); idx += 64) {
-            const int r = idx / (n + q), j = idx % (n + q);
-            if (r == p) continue;
-            const double f = W[r * n + p];
-            if (j == p) continue;                       // column p is zeroed after the sweep
-            if (j < n) W[r * n + j] -= f * W[p * n + j]; else RHS[r * q + (j - n)] -= f * RHS[p * q + (j - n)];
+        __syncthreads();                                          // every read of this sweep is done
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int idx = lane + 64 * k;
+            const int r = idx / C, j = idx % C;
+            if (idx < E) { if (j < n) W[r * n + j] = nv[k]; else RHS[r * q + (j - n)] = nv[k]; }
         }
-        __syncthreads();
-        for (int r = lane; r < n; r += 64) if (r != p) W[r * n + p] = 0.0;
         __syncthreads();
     }
 }
@@ -78,6 +91,7 @@ template <int n, int m>
 struct DareLds {
     double A[n * n], Bm[n * m], Ak[n * n], G[n * n], Hm[n * n], W[n * n], T1[n * n], T2[n * n], T3[n * n];
     double Rm[m * m], X[m * n], Y[m * n], Z[m * m];
+    double AG[n * 2 * n];                                         // [A_k | G]: both right-hand sides of one elimination
     double red[2];
 };
 
@@ -86,31 +100,37 @@ struct DareLds {
 // P: model parameters; Qd (n x n), Rd (m x m): weights (any address space).  Results are left in the work space:
 // L.T1 = S (symmetrised), L.Y = K (m x n), L.A / L.Bm = the linearisation.  Returns the doubling iterations used.
 // Every sum runs in a fixed order inside ONE lane (mm, solve_inplace), so the result does not depend on the lane
-// count and oracle/lqrrt_oracle.c restates it sequentially bit for bit.
+// count and oracle/lqrrt_oracle.c restates it sequentially (two eliminations there, one here: same bits per column).
 template <class S>
 __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const double* u0, const double* Qd, const double* Rd,
                                         double dt, double eps, int max_iter, double tol, DareLds<S::N, S::M>& L, int lane) {
     constexpr int n = S::N, m = S::M;
     double *A = L.A, *Bm = L.Bm, *Ak = L.Ak, *G = L.G, *Hm = L.Hm, *W = L.W, *T1 = L.T1, *T2 = L.T2, *T3 = L.T3;
-    double *Rm = L.Rm, *X = L.X, *Y = L.Y, *Z = L.Z, *red = L.red;
+    double *Rm = L.Rm, *X = L.X, *Y = L.Y, *Z = L.Z, *red = L.red, *AG = L.AG;
     __syncthreads();                                             // the previous user of the work space is done
-    // ---- central differences: lane j < n perturbs state j, lanes n..n+m-1 perturb effort j-n
-    if (lane < n + m) {
-        double xp[n], xm[n], tr[2 * S::NW + 1], uc[m];
-        double xa[n], ua[m];
-        for (int sgn = 0; sgn < 2; ++sgn) {
+    // ---- central differences: lane j < n perturbs state j, lanes n..n+m-1 perturb effort j-n; lanes 32.. take the minus side
+    static_assert(n + m <= 32, "plus and minus sides of the difference quotients share the wavefront");
+    {
+        const int col = lane & 31;
+        const bool minus = lane >= 32;
+        double xo[n];
+        if (col < n + m) {
+            double tr[2 * S::NW + 1], uc[m], xa[n], ua[m];
             for (int d = 0; d < n; ++d) xa[d] = x0[d];
             for (int j = 0; j < m; ++j) ua[j] = u0[j];
-            const double h = sgn == 0 ? eps : -eps;
-            if (lane < n) { for (int d = 0; d < n; ++d) if (d == lane) xa[d] += h; }
-            else { for (int j = 0; j < m; ++j) if (j == lane - n) ua[j] += h; }
+            const double h = minus ? -eps : eps;
+            if (col < n) { for (int d = 0; d < n; ++d) if (d == col) xa[d] += h; }
+            else { for (int j = 0; j < m; ++j) if (j == col - n) ua[j] += h; }
             trig_of<S>(xa, tr);
             for (int j = 0; j < m; ++j) uc[j] = ua[j];
-            S::step(P, xa, tr, uc, dt, sgn == 0 ? xp : xm);
+            S::step(P, xa, tr, uc, dt, xo);
+        } else {
+            for (int d = 0; d < n; ++d) xo[d] = 0.0;
         }
         for (int d = 0; d < n; ++d) {
-            const double v = (xp[d] - xm[d]) / (2.0 * eps);
-            if (lane < n) A[d * n + lane] = v; else Bm[d * m + (lane - n)] = v;
+            const double xm = __shfl_xor(xo[d], 32);
+            const double v = (xo[d] - xm) / (2.0 * eps);
+            if (!minus && col < n + m) { if (col < n) A[d * n + col] = v; else Bm[d * m + (col - n)] = v; }
         }
     }
     for (int i = lane; i < m * m; i += 64) Rm[i] = Rd[i];
@@ -121,20 +141,18 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
     for (int i = lane; i < m * n; i += 64) X[i] = Bm[(i % n) * m + (i / n)];     // X = B' (m x n)
     for (int i = lane; i < m * m; i += 64) Z[i] = Rm[i];
     __syncthreads();
-    solve_inplace(Z, X, m, n, lane);                                           // X = R^-1 B'
+    solve_inplace<m, n>(Z, X, lane);                                           // X = R^-1 B'
     mm(G, Bm, X, n, m, n, false, false, lane);
     // ---- doubling
     int it = 0;
     for (; it < max_iter; ++it) {
         mm(W, G, Hm, n, n, n, false, false, lane);                             // W = G H
         for (int i = lane; i < n; i += 64) W[i * n + i] += 1.0;                 // W = I + G H
-        for (int i = lane; i < n * n; i += 64) { T1[i] = Ak[i]; T2[i] = G[i]; }
+        for (int i = lane; i < n * n; i += 64) { const int r = i / n, c = i % n; AG[r * 2 * n + c] = Ak[i]; AG[r * 2 * n + n + c] = G[i]; }
         __syncthreads();
-        // one elimination for both right-hand sides: [T1 | T2] <- W^-1 [A | G]
-        for (int i = lane; i < n * n; i += 64) T3[i] = W[i];
+        solve_inplace<n, 2 * n>(W, AG, lane);                                   // one elimination: [T1 | T2] = W^-1 [A | G]
+        for (int i = lane; i < n * n; i += 64) { const int r = i / n, c = i % n; T1[i] = AG[r * 2 * n + c]; T2[i] = AG[r * 2 * n + n + c]; }
         __syncthreads();
-        solve_inplace(W, T1, n, n, lane);                                       // T1 = W^-1 A
-        solve_inplace(T3, T2, n, n, lane);                                      // T2 = W^-1 G
         mm(W, Hm, T1, n, n, n, false, false, lane);                            // W = H W^-1 A
         mm(T3, Ak, W, n, n, n, true, false, lane);                             // T3 = A' H W^-1 A
         double dmax = 0.0, hmax = 0.0;
@@ -161,7 +179,7 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
     mm(Z, X, Bm, m, n, m, false, false, lane);                                 // Z = B' S B   (m x m)
     for (int i = lane; i < m * m; i += 64) Z[i] += Rm[i];
     mm(Y, X, A, m, n, n, false, false, lane);                                  // Y = B' S A   (m x n)
-    solve_inplace(Z, Y, m, n, lane);                                           // Y = K
+    solve_inplace<m, n>(Z, Y, lane);                                           // Y = K
     __syncthreads();
     return it;
 }

@@ -18,7 +18,10 @@ CONFIGS = [
     ("Riccati pendulum (4 states, dt 1 ms), 500 nodes", "pendulum_lqr", {}, 500, None),
     ("Riccati boat_novice (6 states, 3 controls), 3k nodes", "boat_novice_lqr", {}, 3000, None),
 ]
+ONLY = os.environ.get("RC_ONLY")                     # substring filter on the label (tools/riccati_ab.sh)
 for label, name, kw_sys, nodes, mod in CONFIGS:
+    if ONLY and ONLY not in label:
+        continue
     cls = lqrrt_amd.systems.SYSTEMS[name]
     s = cls(**kw_sys) if kw_sys else cls(0)
     if mod == "tight":
