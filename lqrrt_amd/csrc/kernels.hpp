@@ -617,13 +617,19 @@ struct RoundArgs {
     int* par[2];                         // parent in use per sample
     unsigned char* stale[2];
     unsigned char* changed[2];
-    int* ctl;                            // device: n_list[2], n_defer[2], ticket[2], converged[2], C, acc
+    int* ctl;                            // device: packed {ticket, n_list, n_defer} x 2 (64-bit each), -, -, converged[2], C, acc
     int* rank;                           // device [W]: accepted samples before t (written at convergence)
     int* host_ctrl;                      // pinned: as k_decide's ctrl
     int* host_summary;                   // pinned: len, flags, parent per sample (converged round only)
     FixedAngles fx;
 };
-enum { RC_LIST = 0, RC_DEFER = 2, RC_TICKET = 4, RC_CONV = 6, RC_C = 8, RC_ACC = 9 };
+// One 64-bit word per round parity counts the workgroups that are through (bits 0-15), those that re-steered (16-31) and those
+// that deferred (32-47): every workgroup adds its share with ONE atomic when it is done, and the value the last one gets back
+// is the round's result -- no second round trip for the counts, and no fences: a workgroup reads nothing that another
+// workgroup of the same launch writes (the decision works on the previous launch's buffers, the closer on the atomic's return
+// value and, in a converged round, on buffers that nobody changed), the kernel boundary publishes the rest.
+enum { RC_PACK = 0, RC_CONV = 6, RC_C = 8, RC_ACC = 9 };
+constexpr unsigned long long RC_ONE_LIST = 1ull << 16, RC_ONE_DEFER = 1ull << 32;
 
 // wave-cooperative: first goal hit among the current records (or W - 1)
 __device__ __forceinline__ int round_horizon(const int* __restrict__ lf, int W, int lane) {
@@ -770,6 +776,17 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     // list mode with a device-side count: the launch is enqueued before the host knows how many samples
     // k_decide listed, so surplus workgroups simply leave (and a converged round costs one empty launch)
     if (list_count && (int)blockIdx.x + lo >= list_count[0]) return;
+#ifndef LQRRT_NO_KERNARG_TOUCH
+    {
+        // The argument block is ~2 KB (31 cache lines) that no cache holds when a launch starts, and most of it is read
+        // lazily, at the point of use, by scalar loads on the critical path (~1 us each on a miss).  One vector load per line
+        // up front brings the whole block into this XCD's L2 while the first real loads are in flight anyway.
+        const volatile int* ka = (const volatile int*)__builtin_amdgcn_kernarg_segment_ptr();
+        constexpr int KA_LINES = (int)((sizeof(Params) + sizeof(Geo) + sizeof(Res) + sizeof(TreeView) + sizeof(RecLayout) +
+                                        sizeof(SteerFuse) + sizeof(RoundArgs) + 40) / 64);       // (rounded down: never past the block)
+        if ((int)(threadIdx.x & 63) < KA_LINES) (void)ka[(threadIdx.x & 63) * 16];
+    }
+#endif
     STEER_TS(0);
     BLK_T(blk_t0);
     constexpr bool DUO = NWF >= 2;
@@ -1010,6 +1027,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         }
     };
     int pref;
+    unsigned long long round_share = 1ull;                        // fused round: this workgroup's contribution to the round's word
     if (f.n_chunks > 0) {
         // nearest node of this sample from the scan's partial minima (see k_nn_reduce for the rules)
         double b = INFINITY;
@@ -1167,9 +1185,9 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             ra.par[nxt][t] = redo ? want : ra.par[cur][t];
             ra.stale[nxt][t] = redo ? 0 : ((need && defer) || mark_stale ? 1 : ra.stale[cur][t]);
             ra.changed[nxt][t] = redo ? 1 : 0;
-            if (redo) atomicAdd(&ra.ctl[RC_LIST + cur], 1);
-            else if (need) atomicAdd(&ra.ctl[RC_DEFER + cur], 1);
         }
+        if (redo) round_share += RC_ONE_LIST;
+        else if (need) round_share += RC_ONE_DEFER;
         if (!redo) {
             // nothing to recompute: this sample's row and len/flags move on unchanged
             for (int u = t + 1 + lane; u < ra.W; u += 64) ra.M[nxt][(size_t)t * ra.W + u] = ra.M[cur][(size_t)t * ra.W + u];
@@ -1518,19 +1536,19 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     // ---- end of a fused round: the last wavefront to get here closes it
     {
         const int cur = ra.round & 1, nxt = cur ^ 1;
-        __threadfence();                                        // this workgroup's writes, before its ticket
-        int ticket = 0;
-        if (lane == 0) ticket = atomicAdd(&ra.ctl[RC_TICKET + cur], 1);
-        ticket = __shfl(ticket, 0);
-        if (ticket != ra.W - 1) return;
-        __threadfence();                                        // everybody else's writes, after the last ticket
-        const int n_list = __hip_atomic_load(&ra.ctl[RC_LIST + cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int n_defer = __hip_atomic_load(&ra.ctl[RC_DEFER + cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long* word_r = (unsigned long long*)(ra.ctl + RC_PACK) + cur;
+        unsigned long long before_me = 0;
+        if (lane == 0) before_me = __hip_atomic_fetch_add(word_r, round_share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        before_me = ((unsigned long long)(unsigned)__shfl((int)(before_me >> 32), 0) << 32) | (unsigned)__shfl((int)before_me, 0);
+        if ((int)(before_me & 0xffffu) != ra.W - 1) return;
+        const unsigned long long all = before_me + round_share;
+        const int n_list = (int)((all >> 16) & 0xffffu), n_defer = (int)((all >> 32) & 0xffffu);
         const bool converged = n_list == 0 && n_defer == 0;
         if (converged) {
             // commit rules of lqrrt_wave_commit (planner.py:311 node limit, :270 the wave ends at a goal hit), on the
-            // final records: accepted-before counts, committed prefix C
-            const int* lfn = ra.lf[nxt];
+            // final records: accepted-before counts, committed prefix C.  (Nobody re-steered: this round's buffers are
+            // copies of the previous round's, which the kernel boundary has already published.)
+            const int* lfn = ra.lf[cur];
             int before = 0, first_hit = ra.W, t_room = ra.W, total = 0;
             for (int c0 = 0; c0 < ra.W; c0 += 64) {
                 const int tt = c0 + lane;
@@ -1541,7 +1559,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
                 const int mine = before + __popcll(A & ((1ull << lane) - 1ull));      // accepted before sample tt
                 if (in) {
                     ra.rank[tt] = mine;
-                    ra.host_summary[tt] = len; ra.host_summary[ra.W + tt] = flg; ra.host_summary[2 * ra.W + tt] = ra.par[nxt][tt];
+                    ra.host_summary[tt] = len; ra.host_summary[ra.W + tt] = flg; ra.host_summary[2 * ra.W + tt] = ra.par[cur][tt];
                     if (a && (flg & 1)) first_hit = min(first_hit, tt);
                     if (ra.room >= 0 && (long long)mine >= ra.room) t_room = min(t_room, tt);
                 }
@@ -1567,7 +1585,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             }
         }
         if (lane == 0) {
-            ra.ctl[RC_LIST + cur] = 0; ra.ctl[RC_DEFER + cur] = 0; ra.ctl[RC_TICKET + cur] = 0;     // for round + 2
+            *word_r = 0ull;                                                                          // for round + 2
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
