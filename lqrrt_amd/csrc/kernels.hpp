@@ -1028,6 +1028,66 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     };
     int pref;
     unsigned long long round_share = 1ull;                        // fused round: this workgroup's contribution to the round's word
+    unsigned long long round_before = 0;                          // (lane 0) the round's word as this workgroup's atomic found it
+    bool round_redo = false;
+    // The last workgroup to add its share closes the round: counts to the host and, in a converged round, ranks and the
+    // committed prefix for the append.  Main wavefront only (the helpers wait at barrier S or are gone): no workgroup barrier.
+    auto close_round = [&]() {
+        const int cur = ra.round & 1, nxt = cur ^ 1;
+        unsigned long long* word_r = (unsigned long long*)(ra.ctl + RC_PACK) + cur;
+        const unsigned long long before_me = ((unsigned long long)(unsigned)__shfl((int)(round_before >> 32), 0) << 32) |
+                                             (unsigned)__shfl((int)round_before, 0);
+        if ((int)(before_me & 0xffffu) == ra.W - 1) {
+            const unsigned long long all = before_me + round_share;
+            const int n_list = (int)((all >> 16) & 0xffffu), n_defer = (int)((all >> 32) & 0xffffu);
+            const bool converged = n_list == 0 && n_defer == 0;
+            if (converged) {
+                // commit rules of lqrrt_wave_commit (planner.py:311 node limit, :270 the wave ends at a goal hit), on the
+                // final records: accepted-before counts, committed prefix C.  (Nobody re-steers: this round's buffers
+                // will be copies of the previous round's, which the kernel boundary has already published.)
+                const int* lfn = ra.lf[cur];
+                int before = 0, first_hit = ra.W, t_room = ra.W;
+                for (int c0 = 0; c0 < ra.W; c0 += 64) {
+                    const int tt = c0 + lane;
+                    const bool in = tt < ra.W;
+                    const int len = in ? lfn[2 * tt] : 0, flg = in ? lfn[2 * tt + 1] : 0;
+                    const bool a = len > 0;
+                    const unsigned long long A = __ballot(a);
+                    const int mine = before + __popcll(A & ((1ull << lane) - 1ull));      // accepted before sample tt
+                    if (in) {
+                        ra.rank[tt] = mine;
+                        ra.host_summary[tt] = len; ra.host_summary[ra.W + tt] = flg; ra.host_summary[2 * ra.W + tt] = ra.par[cur][tt];
+                        if (a && (flg & 1)) first_hit = min(first_hit, tt);
+                        if (ra.room >= 0 && (long long)mine >= ra.room) t_room = min(t_room, tt);
+                    }
+                    before += __popcll(A);
+                }
+    #pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    first_hit = min(first_hit, __shfl_xor(first_hit, off));
+                    t_room = min(t_room, __shfl_xor(t_room, off));
+                }
+                long long Cl = ra.W;
+                if (ra.max_commit < Cl) Cl = ra.max_commit;
+                if (t_room < Cl) Cl = t_room;
+                if (first_hit + 1 < Cl) Cl = first_hit + 1;
+                const int C = (int)(Cl < 0 ? 0 : Cl);
+                // ranks of samples at or beyond C are never used by the append (parents point backwards)
+                if (lane == 0) {
+                    ra.ctl[RC_C] = C;
+                    ra.ctl[RC_CONV + nxt] = 1;
+                    ra.host_ctrl[0] = first_hit < ra.W ? first_hit : ra.W - 1;
+                }
+            }
+            if (lane == 0) *word_r = 0ull;                                                          // for round + 2
+            // the summary (all lanes' stores, pinned host memory) before the word that announces it
+            if (converged) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __threadfence_system(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (lane == 0) {
+                const unsigned long long word = ((unsigned long long)(unsigned)ra.seq << 32) | (unsigned)((n_list << 16) | (n_defer & 0xffff));
+                __hip_atomic_store((unsigned long long*)(ra.host_ctrl + 2 + 2 * cur), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
     if (f.n_chunks > 0) {
         // nearest node of this sample from the scan's partial minima (see k_nn_reduce for the rules)
         double b = INFINITY;
@@ -1188,6 +1248,17 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         }
         if (redo) round_share += RC_ONE_LIST;
         else if (need) round_share += RC_ONE_DEFER;
+        {
+            // ---- the round's counts: every workgroup adds its share as soon as it has decided (one atomic, nobody waits for
+            // it here).  A workgroup that does not re-steer looks at what came back right away and closes the round if it was
+            // the last one -- in a converged round that is ~5 us into the launch, so the host hears about the wave while the
+            // launch is still running; one that re-steers looks after its rollout, when the answer has long arrived: no
+            // workgroup ends with an atomic round trip across the chip.
+            unsigned long long* word_r = (unsigned long long*)(ra.ctl + RC_PACK) + cur;
+            if (lane == 0) round_before = __hip_atomic_fetch_add(word_r, round_share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            round_redo = redo;
+            if (!redo) close_round();
+        }
         if (!redo) {
             // nothing to recompute: this sample's row and len/flags move on unchanged
             for (int u = t + 1 + lane; u < ra.W; u += 64) ra.M[nxt][(size_t)t * ra.W + u] = ra.M[cur][(size_t)t * ra.W + u];
@@ -1532,69 +1603,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     }
 #endif
     }   // !round_skip
-    if (!ron) return;
-    // ---- end of a fused round: the last wavefront to get here closes it
-    {
-        const int cur = ra.round & 1, nxt = cur ^ 1;
-        unsigned long long* word_r = (unsigned long long*)(ra.ctl + RC_PACK) + cur;
-        unsigned long long before_me = 0;
-        if (lane == 0) before_me = __hip_atomic_fetch_add(word_r, round_share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        before_me = ((unsigned long long)(unsigned)__shfl((int)(before_me >> 32), 0) << 32) | (unsigned)__shfl((int)before_me, 0);
-        if ((int)(before_me & 0xffffu) != ra.W - 1) return;
-        const unsigned long long all = before_me + round_share;
-        const int n_list = (int)((all >> 16) & 0xffffu), n_defer = (int)((all >> 32) & 0xffffu);
-        const bool converged = n_list == 0 && n_defer == 0;
-        if (converged) {
-            // commit rules of lqrrt_wave_commit (planner.py:311 node limit, :270 the wave ends at a goal hit), on the
-            // final records: accepted-before counts, committed prefix C.  (Nobody re-steered: this round's buffers are
-            // copies of the previous round's, which the kernel boundary has already published.)
-            const int* lfn = ra.lf[cur];
-            int before = 0, first_hit = ra.W, t_room = ra.W, total = 0;
-            for (int c0 = 0; c0 < ra.W; c0 += 64) {
-                const int tt = c0 + lane;
-                const bool in = tt < ra.W;
-                const int len = in ? lfn[2 * tt] : 0, flg = in ? lfn[2 * tt + 1] : 0;
-                const bool a = len > 0;
-                const unsigned long long A = __ballot(a);
-                const int mine = before + __popcll(A & ((1ull << lane) - 1ull));      // accepted before sample tt
-                if (in) {
-                    ra.rank[tt] = mine;
-                    ra.host_summary[tt] = len; ra.host_summary[ra.W + tt] = flg; ra.host_summary[2 * ra.W + tt] = ra.par[cur][tt];
-                    if (a && (flg & 1)) first_hit = min(first_hit, tt);
-                    if (ra.room >= 0 && (long long)mine >= ra.room) t_room = min(t_room, tt);
-                }
-                before += __popcll(A);
-            }
-            total = before;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                first_hit = min(first_hit, __shfl_xor(first_hit, off));
-                t_room = min(t_room, __shfl_xor(t_room, off));
-            }
-            long long Cl = ra.W;
-            if (ra.max_commit < Cl) Cl = ra.max_commit;
-            if (t_room < Cl) Cl = t_room;
-            if (first_hit + 1 < Cl) Cl = first_hit + 1;
-            const int C = (int)(Cl < 0 ? 0 : Cl);
-            // ranks of samples at or beyond C are never used by the append (parents point backwards)
-            (void)total;
-            if (lane == 0) {
-                ra.ctl[RC_C] = C;
-                ra.ctl[RC_CONV + nxt] = 1;
-                ra.host_ctrl[0] = first_hit < ra.W ? first_hit : ra.W - 1;
-            }
-        }
-        if (lane == 0) {
-            *word_r = 0ull;                                                                          // for round + 2
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (lane == 0) {
-            if (converged) { __threadfence_system(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            const unsigned long long word = ((unsigned long long)(unsigned)ra.seq << 32) | (unsigned)((n_list << 16) | (n_defer & 0xffff));
-            __hip_atomic_store((unsigned long long*)(ra.host_ctrl + 2 + 2 * cur), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    if (ron && round_redo) close_round();
 }
 
 // Rows of the in-wave cost matrix straight from the records (sharded waves: records of other ranks arrive by
