@@ -192,7 +192,8 @@ static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
 static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int W, const double* Sd,
                      bool tri, int* out_id, double* out_cost, double* rec, hipStream_t st,
                      bool profile, int* n_chunks_out = nullptr, int wave_lo = -1, bool defer_reduce = false,
-                     const double* xtrig = nullptr, const double* Spers = nullptr, bool range_candidates = false) {
+                     const double* xtrig = nullptr, const double* Spers = nullptr, bool range_candidates = false,
+                     const IgnPatch* patch = nullptr) {
     // Spers: one dense S per sample, [W][n*n] (Riccati systems: S = lqr(sample, 0)[0], planner.py:344-345); else Sd (one
     // matrix for all samples) or the system's constant S
     if (W <= 0) return 0;
@@ -206,15 +207,17 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     const int ps_c = tri ? W : 1, ps_t = tri ? 1 : n_chunks;     // chunk-major for k_decide, sample-major for k_nn_reduce
     EvPair ev;
     ev.a = ev.b = nullptr;
+    IgnPatch pt;
+    if (patch) pt = *patch; else memset(&pt, 0, sizeof pt);
     if (profile) prof_begin(e, st, &ev, 0);
 #define NN_LAUNCH(DENSE, TRI)                                                                            \
     DISPATCH(e, hipExtLaunchKernelGGL((k_nn_scan<S, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
-                                      e->d_pcost, e->d_pidx, ps_c, ps_t))
+                                      e->d_pcost, e->d_pidx, ps_c, ps_t, pt))
     // structured forms of the engine's own S are instantiated only for the systems that have them
     const int sm = !S_use ? S_IDENT : (Sd ? S_DENSE : e->smode);
 #define NN_ONE(SYS, DENSE, TRI)                                                                            \
     hipExtLaunchKernelGGL((k_nn_scan<SYS, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
-                          e->d_pcost, e->d_pidx, ps_c, ps_t)
+                          e->d_pcost, e->d_pidx, ps_c, ps_t, pt)
     if (Spers) {
         if (!e->riccati) return fail(LQRRT_E_ARG, "per-sample S is only instantiated for Riccati systems");
         DISPATCH(e, if constexpr (has_dare_gain<S>::value) { if (tri) NN_ONE(S, S_PERSAMPLE, true); else NN_ONE(S, S_PERSAMPLE, false); });

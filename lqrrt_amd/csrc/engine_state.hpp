@@ -73,6 +73,8 @@ struct lqrrt_engine {
     unsigned long long* h_ign_pin = nullptr;   // pinned staging copy (async upload)
     int ign_hi = 0;                            // highest tree size since the last upload
     bool ign_dirty = false;
+    bool ign_patch_valid = false;              // ign_patch lists every word in which the device copy differs from h_ign
+    std::vector<int> ign_patch;
     int64_t goal_hits = 0;
     int best_end = -1;
     int64_t best_steps = -1;

@@ -167,7 +167,7 @@ extern "C" int lqrrt_tree_load(lqrrt_engine* e, int count, const double* states,
     // the whole device bitmap, not only the words of the loaded nodes: nodes appended later must start un-ignored
     HIPCHK(hipMemsetAsync(e->tv.ignore, 0, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1), st));
     e->ign_hi = std::max(e->ign_hi, std::max(e->N, count));
-    e->ign_dirty = true;
+    e->ign_dirty = true; e->ign_patch_valid = false;
     e->N = count;
     e->werr_valid = false;
     TRY(flush_ignore(e, st, false));
@@ -185,7 +185,7 @@ extern "C" int lqrrt_tree_truncate(lqrrt_engine* e, int size) {
     if (size == e->N) return 0;
     e->ign_hi = std::max(e->ign_hi, e->N);
     for (int i = size; i < e->N; ++i) e->h_ign[i >> 6] &= ~(1ull << (i & 63));
-    e->ign_dirty = true;
+    e->ign_dirty = true; e->ign_patch_valid = false;
     e->N = size;
     e->h_pid.resize(size); e->h_elen.resize(size);
     // Goal bookkeeping of the dropped nodes goes with them: the best plan is forgotten if its end node is gone, and a mark
@@ -207,7 +207,7 @@ extern "C" int lqrrt_tree_set_ignored(lqrrt_engine* e, int first, int count, con
         else e->h_ign[id >> 6] &= ~(1ull << (id & 63));
     }
     e->ign_hi = std::max(e->ign_hi, e->N);
-    e->ign_dirty = true;
+    e->ign_dirty = true; e->ign_patch_valid = false;
     return 0;
 }
 
@@ -225,7 +225,7 @@ extern "C" int lqrrt_tree_rewind(lqrrt_engine* e) {
     e->ign_hi = std::max(e->ign_hi, e->N);
     e->N = e->mark_N;
     e->h_pid.resize(e->N); e->h_elen.resize(e->N);
-    e->h_ign = e->mark_ign; e->ign_dirty = true;
+    e->h_ign = e->mark_ign; e->ign_dirty = true; e->ign_patch_valid = false;
     e->goal_hits = e->mark_hits; e->best_end = e->mark_best_end; e->best_steps = e->mark_best_steps;
     e->tot.tree_size = e->N;
     return 0;
@@ -241,6 +241,7 @@ static int flush_ignore(lqrrt_engine* e, hipStream_t st, bool sync_first) {
     memcpy(e->h_ign_pin, e->h_ign.data(), sizeof(unsigned long long) * words);
     HIPCHK(hipMemcpyAsync(e->tv.ignore, e->h_ign_pin, sizeof(unsigned long long) * words, hipMemcpyHostToDevice, st));
     e->ign_dirty = false;
+    e->ign_patch_valid = false;
     e->ign_hi = e->N;
     return 0;
 }

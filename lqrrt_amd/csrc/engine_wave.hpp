@@ -36,11 +36,21 @@ static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, 
     hipStream_t st = (hipStream_t)stream;
     const double hp0 = hostprof_on() ? now_us() : 0.0;
     TRY(ensure_samples(e, e->cursor + W, st));
-    TRY(flush_ignore(e, st, false));
+    const int cnt = hi - lo;
+    // the few words a goal hit changed travel with the scan's arguments (IgnPatch); anything else is uploaded
+    IgnPatch patch;
+    memset(&patch, 0, sizeof patch);
+    static const bool patch_on = [] { const char* v = getenv("LQRRT_IGNORE_PATCH"); return !(v && atoi(v) == 0); }();
+    if (patch_on && e->ign_dirty && e->ign_patch_valid && cnt > 0 && !e->ign_patch.empty()) {
+        patch.n = (int)e->ign_patch.size();
+        for (int k = 0; k < patch.n; ++k) { patch.idx[k] = e->ign_patch[k]; patch.val[k] = e->h_ign[e->ign_patch[k]]; }
+        e->ign_dirty = false; e->ign_patch_valid = false; e->ign_hi = e->N;
+    } else {
+        TRY(flush_ignore(e, st, false));
+    }
     TRY(ensure_werr(e, st));
     const double hp1 = hostprof_on() ? now_us() : 0.0;
     const double* xs = wave_samples(e);
-    const int cnt = hi - lo;
     const bool whole = (lo == 0 && hi == W);
     static const int matrix_max = getenv("LQRRT_MATRIX_MAX_W") ? std::min(atoi(getenv("LQRRT_MATRIX_MAX_W")), (int)lqrrt_engine::MATRIX_MAX_W)
                                                                 : (int)lqrrt_engine::MATRIX_MAX_W;
@@ -56,7 +66,7 @@ static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, 
         const double* xtr = wave_sample_trig(e);
         TRY(launch_nn(e, nv, xs + (size_t)lo * e->n, cnt, nullptr, false, nullptr, nullptr,
                       e->d_rec + (size_t)lo * e->L.R, st, true, &n_chunks, lo, true, xtr ? xtr + (size_t)lo * 2 * e->nw : nullptr,
-                      e->riccati ? wave_sample_S(e) + (size_t)lo * e->n * e->n : nullptr));
+                      e->riccati ? wave_sample_S(e) + (size_t)lo * e->n * e->n : nullptr, false, &patch));
         const double hp2 = hostprof_on() ? now_us() : 0.0;
         SteerFuse f;
         memset(&f, 0, sizeof f);
@@ -397,16 +407,26 @@ static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_
         for (int off : sync_hits) {                          // in commit order
             const int id = base + off;
             int64_t steps = 0;
+            if (pruning && !e->ign_dirty) { e->ign_patch.clear(); e->ign_patch_valid = true; }   // device copy == host copy so far
             for (int v = id; v != -1; v = e->h_pid[v]) {
                 steps += e->h_elen[v];
                 // ignores = union of succeeded paths, planner.py:270 (only consulted when pruning, :239)
-                if (pruning) e->h_ign[v >> 6] |= (1ull << (v & 63));
+                if (pruning) {
+                    const unsigned long long bit = 1ull << (v & 63);
+                    if (!(e->h_ign[v >> 6] & bit)) {
+                        e->h_ign[v >> 6] |= bit;
+                        e->ign_dirty = true;
+                        if (e->ign_patch_valid && std::find(e->ign_patch.begin(), e->ign_patch.end(), v >> 6) == e->ign_patch.end()) {
+                            if (e->ign_patch.size() < 16) e->ign_patch.push_back(v >> 6);
+                            else e->ign_patch_valid = false;                   // too many words: the next scan waits for an upload
+                        }
+                    }
+                }
             }
             e->goal_hits++;
             ws.goal_hits++;
             if (e->best_end < 0 || steps < e->best_steps) { e->best_end = id; e->best_steps = steps; }  // planner.py:276 (T < self.T)
         }
-        if (pruning) e->ign_dirty = true;
     }
     if (trace_on()) fprintf(stderr, "[wave N=%d W=%d] commit C=%d acc=%d hit=%d rounds=%d\n", base, W, C, acc, (int)hit, rounds);
     // advance the stream

@@ -61,6 +61,12 @@ struct NodeView {
     int count, first;       // nodes first .. first + count - 1 are scanned (first = 0 except for tree-sharded scans)
 };
 
+// Words of the tree's ignore bitmap that the host has changed since the device copy was written (a goal hit puts the nodes
+// of one path on it: a handful of words).  They ride along as arguments of the next tree scan instead of going through a
+// host-to-device copy (an API call of ~6 us and a blit dispatch in front of every second wave's scan): every workgroup
+// applies them to the words it reads, workgroup (0, 0) stores them for the launches that follow.
+struct IgnPatch { int n, pad; int idx[16]; unsigned long long val[16]; };
+
 struct TreeView {
     double* state;          // [n][cap]
     double* trig;           // [2*NW][cap]
@@ -205,8 +211,12 @@ template <class S, int DENSE, bool TRI>
 __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __restrict__ xs, const double* __restrict__ xtrig,
                                                 int W, const double* __restrict__ Sd, int chunk,
                                                 double* __restrict__ pcost, int* __restrict__ pidx,
-                                                int ps_c, int ps_t) {
+                                                int ps_c, int ps_t, IgnPatch pt) {
     const int lane = threadIdx.x;
+    if constexpr (!TRI) {
+        if (pt.n > 0 && blockIdx.x == 0 && blockIdx.y == 0 && lane < pt.n && nv.ignore)
+            const_cast<unsigned long long*>(nv.ignore)[pt.idx[lane]] = pt.val[lane];
+    }
     // XCD-aware tile mapping: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each
     // with its own L2.  Re-index so that XCD k owns a contiguous band of node chunks (for every sample
     // group): each L2 then holds 1/8 of the node table instead of all of it.  Speed only; any mapping is
@@ -279,7 +289,15 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
         if (lane < cnt) {
             const long long i = base + lane;
             if constexpr (TRI) el = nv.len[i * nv.sn] > 0.0;
-            else el = nv.ignore ? ((nv.ignore[i >> 6] >> (i & 63)) & 1ull) == 0 : true;
+            else if (nv.ignore) {
+                const int wi = (int)(i >> 6);
+                unsigned long long w = nv.ignore[wi];
+                if (pt.n > 0) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) w = (k < pt.n && pt.idx[k] == wi) ? pt.val[k] : w;
+                }
+                el = ((w >> (i & 63)) & 1ull) == 0;
+            } else el = true;
         }
         const unsigned long long m = __ballot(el);
         if (m == 0) continue;
