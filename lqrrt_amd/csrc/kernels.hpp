@@ -725,10 +725,23 @@ template <class S, class = void> struct has_trio_split : std::false_type {};
 template <class S> struct has_trio_split<S, std::enable_if_t<S::TRIO_SPLIT>> : std::true_type {};
 
 // The sequential loop's tests on the step that produced xn (planner.py:393-433); true when the edge ends here
+// rec_later != null: the step's verdict only; when it says "record", *rec_later is set and the caller writes the history entry
+// itself (rollout_record) -- behind the barrier that hands the verdict over, off the step's critical path.
+template <class S>
+__device__ __forceinline__ void rollout_record(const double* xn, const double* trn, const double* u, int cnt,
+                                               double* hx, double* hu, double* htr) {
+#pragma unroll
+    for (int d = 0; d < S::N; ++d) hx[cnt * S::N + d] = xn[d];
+#pragma unroll
+    for (int j = 0; j < S::M; ++j) hu[cnt * S::M + j] = u[j];
+#pragma unroll
+    for (int j = 0; j < 2 * S::NW; ++j) htr[2 * S::NW * cnt + j] = trn[j];
+}
 template <class S>
 __device__ __forceinline__ bool rollout_check(const double* Pl, const Geo& g, const GeoL& gl, const Res& r, const double* xn,
                                               const double* trn, const double* e, const double* u, int lane, int& cnt, int& steps,
-                                              double* last, const double* tolr, double* hx, double* hu, double* htr, DuoLds& duo) {
+                                              double* last, const double* tolr, double* hx, double* hu, double* htr, DuoLds& duo,
+                                              bool* rec_later = nullptr) {
     bool stop = false;
     const bool feas_ok = uniform_true(S::feasible(Pl, g, gl, xn, u, trn, lane));
     if (!feas_ok) {                                             // planner.py:393-396
@@ -752,13 +765,8 @@ __device__ __forceinline__ bool rollout_check(const double* Pl, const Geo& g, co
             if (steps > r.H || uniform_true(conv)) {            // planner.py:428
                 stop = true;
             } else {                                            // record (planner.py:432-433)
-#pragma unroll
-                for (int d = 0; d < S::N; ++d) hx[cnt * S::N + d] = xn[d];
-#pragma unroll
-                for (int j = 0; j < S::M; ++j) hu[cnt * S::M + j] = u[j];
-#pragma unroll
-                for (int j = 0; j < 2 * S::NW; ++j) htr[2 * S::NW * cnt + j] = trn[j];
-                ++cnt;
+                if (rec_later) *rec_later = true;
+                else { rollout_record<S>(xn, trn, u, cnt, hx, hu, htr); ++cnt; }
             }
         }
     }
@@ -875,12 +883,13 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
 #pragma unroll
                 for (int j = 0; j < S::M; ++j) u[j] = duo.eu[(k + 1) & 1][S::N + j];
                 const bool fin = duo.finp[k & 1] != 0;
-                bool stop = false;
-                if (k >= 1) stop = rollout_check<S>(Pl, g, gl, r, xn, trn, e, u, lane, cnt, steps, last, tolr, hx, hu, htr, duo);
+                bool stop = false, rec_now = false;
+                if (k >= 1) stop = rollout_check<S>(Pl, g, gl, r, xn, trn, e, u, lane, cnt, steps, last, tolr, hx, hu, htr, duo, &rec_now);
                 STEP_TS(cs1);
                 STEP_ACC(5, cs0, cs1);
                 __syncthreads();                                            // Y_k
                 if (duo.stop) return;
+                if (rec_now) { rollout_record<S>(xn, trn, u, cnt, hx, hu, htr); ++cnt; }   // (nobody reads the history before the loop ends)
                 if (NWF == 3 && !fin && !stop) {
                     // what the main wavefront needs for step k + 1 and only depends on x_k: cos/sin of the next heading
                     // (euler(): xn[2] = x[2] + x[5] dt) and the gain there (planner.py:436)
