@@ -719,6 +719,7 @@ struct DuoLds {
     double pk2[2][2 * MAXN + 4 + MAXM];  // plain two-wavefront rollout: xn | trn | e | u of step k in pk2[k & 1]
     double e2b[2];                       // NWF = 4: erf angle of step k in e2b[k & 1]
     double tt[2];                        // NWF = 4: cos/sin of the target's heading
+    double pre[12];                      // chain-owner rollout: ta[4] | Dv[3] | xn012[3] | u[2] of step k, main -> torque wavefront
 };
 struct NoSplit { struct TrioPre {}; };
 template <class S, class = void> struct has_trio_split : std::false_type {};
@@ -741,9 +742,9 @@ template <class S>
 __device__ __forceinline__ bool rollout_check(const double* Pl, const Geo& g, const GeoL& gl, const Res& r, const double* xn,
                                               const double* trn, const double* e, const double* u, int lane, int& cnt, int& steps,
                                               double* last, const double* tolr, double* hx, double* hu, double* htr, DuoLds& duo,
-                                              bool* rec_later = nullptr) {
+                                              bool* rec_later = nullptr, const bool* feas_known = nullptr) {
     bool stop = false;
-    const bool feas_ok = uniform_true(S::feasible(Pl, g, gl, xn, u, trn, lane));
+    const bool feas_ok = feas_known ? *feas_known : uniform_true(S::feasible(Pl, g, gl, xn, u, trn, lane));
     if (!feas_ok) {                                             // planner.py:393-396
         cnt = (int)(r.FPR * (double)cnt);
         duo.truncated = 1;
@@ -829,7 +830,107 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     __shared__ DuoLds duo;
     double* htr = hist + (size_t)r.H * (S::N + S::M) + geo_lds_doubles(g);   // DUO: cos/sin of every recorded state
     constexpr int PKN = S::N + 2 * S::NW;                                    // plain two-wavefront packet: offset of e
-    if constexpr (NWF == 4) {
+    // Chain-owner rollout (four wavefronts, systems with the split step): the only true dependency chain of a step is
+    //   x_k -> heading torque (atan2, sincos, atan2) -> x_k+1 ,
+    // so the wavefront that computes the torque also finishes the step and keeps the state in registers: nothing on the
+    // chain crosses a wavefront boundary except u_k and the torque-free half of the step, which the main wavefront has
+    // long put into LDS (duo.pre).  Two barriers per step: Y_k (effort, next heading, feasibility answer are there) and
+    // X_k+1 (x_k+1 and the verdict on x_k are there; everybody leaves here when the edge has ended).  The checking
+    // wavefront is off the chain: feasibility before Y, book-keeping and the history entry after it.
+    constexpr bool QX = NWF == 4 && has_trio_split<S>::value;
+    if constexpr (QX) {
+        if (threadIdx.x >= 192) {
+            // ---------------- next-heading wavefront: what step k + 1 needs and only depends on x_k
+            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;
+            __syncthreads();                                                // S
+            if (!duo.go) return;
+            const double tt0 = duo.tt[0], tt1 = duo.tt[1];
+            for (int k = 0;; ++k) {
+                const bool alive = !duo.finp[k & 1];
+                double tn[2];
+                if (alive) {
+                    double Kn[S::M * S::N], xk[S::N];
+#pragma unroll
+                    for (int d = 0; d < S::N; ++d) xk[d] = duo.pk[d];
+                    lq_sincos(xk[2] + xk[5] * r.dt, &tn[1], &tn[0]);
+                    S::gain(Pl, xk, tn, xk, Kn);
+                    duo.tr[(k + 1) & 1][0] = tn[0]; duo.tr[(k + 1) & 1][1] = tn[1];
+#pragma unroll
+                    for (int j = 0; j < S::M * S::N; ++j) duo.Kb[(k + 1) & 1][j] = Kn[j];
+                }
+                __syncthreads();                                            // Y_k
+                if (alive) duo.e2b[(k + 1) & 1] = lq_atan2(tt1 * tn[0] - tt0 * tn[1], tt0 * tn[0] + tt1 * tn[1]);
+                __syncthreads();                                            // X_k+1
+                if (duo.stop) return;
+            }
+        }
+        if (threadIdx.x >= 128) {
+            // ---------------- checking wavefront
+            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
+            for (int i = lane; i < MAXP; i += 64) Pl[i] = P.p[i];
+            if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
+            const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
+            __syncthreads();                                                // S
+            if (!duo.go) return;
+            double tolr[S::N], last[S::N];
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) { tolr[d] = tol_l[d]; last[d] = INFINITY; }           // planner.py:377
+            int cnt = 0, steps = 0;
+            for (int k = 0;; ++k) {
+                double xn[S::N], trn[2], e[S::N], u[S::M];
+                STEP_TS(cs0);
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) { xn[d] = duo.pk[d]; e[d] = duo.eu[(k + 1) & 1][d]; }
+                trn[0] = duo.tr[k & 1][0]; trn[1] = duo.tr[k & 1][1];
+#pragma unroll
+                for (int j = 0; j < S::M; ++j) u[j] = duo.eu[(k + 1) & 1][S::N + j];
+                bool feas_ok = true;
+                if (k >= 1) feas_ok = uniform_true(S::feasible(Pl, g, gl, xn, u, trn, lane));
+                STEP_TS(cs1);
+                STEP_ACC(5, cs0, cs1);
+                __syncthreads();                                            // Y_k
+                if (k >= 1) rollout_check<S>(Pl, g, gl, r, xn, trn, e, u, lane, cnt, steps, last, tolr, hx, hu, htr, duo, nullptr, &feas_ok);
+                __syncthreads();                                            // X_k+1
+                if (duo.stop) return;
+            }
+        }
+        if (threadIdx.x >= 64) {
+            // ---------------- torque wavefront: owns the state
+            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;
+            __syncthreads();                                                // S
+            if (!duo.go) return;
+            typename S::TrioPre q;
+            S::trio_consts(Pl, q);
+            double xk[S::N], tk[2];
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) xk[d] = duo.pk[d];
+            tk[0] = duo.tr[0][0]; tk[1] = duo.tr[0][1];
+            for (int k = 0;; ++k) {
+                STEP_TS(ps0);
+                const bool alive = !duo.finp[k & 1];
+                double rud = 0.0;
+                if (alive) rud = S::duo_chain(Pl, xk, tk);
+                STEP_TS(ps1);
+                STEP_ACC(6, ps0, ps1);
+                __syncthreads();                                            // Y_k
+                if (alive) {
+                    double u[S::M], xn[S::N];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) q.ta[j] = duo.pre[j];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { q.Dv[i] = duo.pre[4 + i]; q.xn012[i] = duo.pre[7 + i]; }
+                    u[0] = 0.0; u[1] = 0.0; u[2] = duo.pre[10];
+                    tk[0] = duo.tr[(k + 1) & 1][0]; tk[1] = duo.tr[(k + 1) & 1][1];
+                    S::trio_post(q, xk, u, rud, r.dt, xn);                  // planner.py:390
+#pragma unroll
+                    for (int d = 0; d < S::N; ++d) { duo.pk[d] = xn[d]; xk[d] = xn[d]; }
+                }
+                __syncthreads();                                            // X_k+1
+                if (duo.stop) return;
+            }
+        }
+    }
+    if constexpr (NWF == 4 && !QX) {
         if (threadIdx.x >= 192) {
             // ---------------- next-heading wavefront: what step k + 1 needs and only depends on x_k
             if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;
@@ -861,7 +962,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             }
         }
     }
-    if constexpr (NWF >= 3) {
+    if constexpr (NWF >= 3 && !QX) {
         if (threadIdx.x >= 128) {
             // ---------------- checking wavefront
             if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
@@ -1309,7 +1410,77 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     BLK_T(blk_tq);
     int cnt = 0, steps = 0;
     bool grew = false, truncated = false;
-    if constexpr (NWF >= 3) {
+    if constexpr (QX) {
+        // main wavefront of the chain-owner rollout: erf, u = K e and the torque-free half of the step, one step after the other
+        duo.go = 1; duo.stop = 0; duo.cnt = 0; duo.steps = 0; duo.grew = 0; duo.truncated = 0; duo.finp[0] = 0; duo.finp[1] = 0;
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) duo.pk[d] = x[d];
+        duo.tr[0][0] = trig[0]; duo.tr[0][1] = trig[1];
+        duo.tt[0] = ttrig[0]; duo.tt[1] = ttrig[1];
+        __syncthreads();                                             // S
+        BLK_T(blk_t1);
+#ifdef STEER_TIMING
+        if (threadIdx.x == 0) {
+            const int mode = f.n_chunks > 0 ? 0 : (ron ? 1 : 2);
+            atomicAdd(&g_pro_acc[mode * 5 + 0], blk_tp - blk_t0); atomicAdd(&g_pro_acc[mode * 5 + 1], blk_tq - blk_tp);
+            atomicAdd(&g_pro_acc[mode * 5 + 2], blk_t1 - blk_tq); atomicAdd(&g_pro_acc[mode * 5 + 3], 1ull);
+        }
+#endif
+        double tolr[S::N];
+#pragma unroll
+        for (int d = 0; d < S::N; ++d) tolr[d] = tol_l[d];
+        bool live = true;
+        for (int k = 0;; ++k) {
+            STEP_TS(ms0);
+            if (live) {
+                double e[S::N], u[S::M];
+                typename S::TrioPre pre;
+                if (k >= 1) {                                        // x_k from the torque wavefront; cos/sin, K = lqr(x_k), erf angle
+#pragma unroll                                                       // from the next-heading wavefront
+                    for (int d = 0; d < S::N; ++d) x[d] = duo.pk[d];
+                    trig[0] = duo.tr[k & 1][0]; trig[1] = duo.tr[k & 1][1];
+#pragma unroll
+                    for (int j = 0; j < S::M * S::N; ++j) K[j] = duo.Kb[k & 1][j];
+                    S::quad_effort(xt, x, K, duo.e2b[k & 1], e, u);
+                } else {
+                    S::trio_effort(xt, ttrig, x, trig, K, e, u);                  // planner.py:386-387
+                }
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) duo.eu[k & 1][d] = e[d];
+#pragma unroll
+                for (int j = 0; j < S::M; ++j) duo.eu[k & 1][S::N + j] = u[j];
+                // planner.py:428 as the checker will apply it to this step if every step so far is feasible: steps = k + 1
+                bool conv = true;
+#pragma unroll
+                for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= tolr[d]);
+                if (k + 1 > r.H || uniform_true(conv)) { duo.finp[(k + 1) & 1] = 1; live = false; }
+                S::trio_pre(Pl, x, trig, u, r.dt, pre);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) duo.pre[j] = pre.ta[j];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { duo.pre[4 + i] = pre.Dv[i]; duo.pre[7 + i] = pre.xn012[i]; }
+                duo.pre[10] = u[2];
+            }
+            STEP_TS(ms1);
+            __syncthreads();                                         // Y_k
+            STEP_TS(ms2);
+            __syncthreads();                                         // X_k+1: x_k+1 and the verdict on x_k are there
+            STEP_TS(ms4);
+            STEP_ACC(0, ms0, ms1); STEP_ACC(1, ms1, ms2); STEP_ACC(4, ms2, ms4); STEP_ACC(3, ms0, ms0 + 1);
+            if (duo.stop) break;
+        }
+        cnt = duo.cnt; steps = duo.steps; grew = duo.grew != 0;
+        truncated = true;                                            // the node comes from the history
+#ifdef STEER_TIMING
+        if (threadIdx.x == 0 && steps >= 20) {
+            const unsigned long long t2 = wall_clock64();
+            atomicAdd(&g_blk_acc[1], t2 - blk_t1); atomicMax(&g_blk_acc[4], t2 - blk_t1);
+            atomicAdd(&g_blk_acc[5], blk_t1 - blk_t0); atomicMax(&g_blk_acc[6], blk_t1 - blk_t0);
+            atomicAdd(&g_blk_acc[2], 1ull);
+            atomicAdd(&g_loop_hist[min(31, (int)((t2 - blk_t1) / 200))], 1ull);      // 2 us buckets
+        }
+#endif
+    } else if constexpr (NWF >= 3) {
         duo.go = 1; duo.stop = 0; duo.cnt = 0; duo.steps = 0; duo.grew = 0; duo.truncated = 0; duo.finp[0] = 0; duo.finp[1] = 0;
 #pragma unroll
         for (int d = 0; d < S::N; ++d) duo.pk[d] = x[d];

@@ -476,6 +476,17 @@ struct BoatAdvanced : BoatCommon {
         }
         q.vp = P[38]; q.vn = P[39];
     }
+    // the members of TrioPre that do not depend on the step (chain-owner rollout: the torque wavefront keeps them in registers
+    // and gets ta / Dv / xn012 of each step from the main wavefront)
+    __device__ __forceinline__ static void trio_consts(const double* P, TrioPre& q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { q.b2[j] = P[21 + 3 * j + 2]; q.tmax[j] = P[33 + j]; }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) q.Bm[i] = P[9 + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) q.invM[i] = P[i];
+        q.vp = P[38]; q.vn = P[39];
+    }
     __device__ __forceinline__ static void trio_post(const TrioPre& q, const double* x, const double* u, double rud, double dt, double* xn) {
         const double u2 = u[2] + rud;
         double t[4];
