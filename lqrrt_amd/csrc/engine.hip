@@ -160,6 +160,10 @@ extern "C" int lqrrt_debug_blk_acc(unsigned long long* out8) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lq::g_blk_acc), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
     return 0;
 }
+extern "C" int lqrrt_debug_place_acc(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(lq::g_place_acc), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    return 0;
+}
 extern "C" int lqrrt_debug_step_acc(unsigned long long* out8) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lq::g_step_acc), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
     return 0;

@@ -781,6 +781,9 @@ __device__ unsigned long long g_steer_ts[8];
 __device__ unsigned long long g_step_acc[8];        // per-phase ticks of the rollout loop of block 0, + step count
 __device__ unsigned long long g_loop_hist[32];
 __device__ unsigned long long g_blk_acc[8];
+__device__ unsigned long long g_place_acc[16];      // full-horizon rollouts by placement class: [class*2 + {sum loop ticks, count}], class = (two of the
+                                                    // workgroup's wavefronts on one SIMD ? 1 : 0) + (another rollout on the same CU ? 2 : 0) + (steps with a near obstacle ? 4 : 0)
+__device__ int g_cu_live[4096];
 __device__ unsigned long long g_pro_acc[16];        // prologue of rolling workgroups: [mode*5 + {to pref, parent loads, to S barrier, count}]         // full-horizon rollouts: sum kernel time, sum loop time, count, max kernel, max loop
 #define BLK_T(v) const unsigned long long v = wall_clock64()
 #define STEP_TS(v) const unsigned long long v = wall_clock64()
@@ -838,6 +841,11 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     // X_k+1 (x_k+1 and the verdict on x_k are there; everybody leaves here when the edge has ended).  The checking
     // wavefront is off the chain: feasibility before Y, book-keeping and the history entry after it.
     constexpr bool QX = NWF == 4 && has_trio_split<S>::value;
+#ifdef STEER_TIMING
+    __shared__ int hw_l[4];
+    __shared__ int cu_prev_l;
+    if ((threadIdx.x & 63) == 0) hw_l[threadIdx.x >> 6] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+#endif
     if constexpr (QX) {
         if (threadIdx.x >= 192) {
             // ---------------- next-heading wavefront: what step k + 1 needs and only depends on x_k
@@ -1420,6 +1428,12 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         __syncthreads();                                             // S
         BLK_T(blk_t1);
 #ifdef STEER_TIMING
+        int cu_key = 0, cu_prev = 0;
+        {
+            const int xcc = (int)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;                               // HW_REG_XCC_ID
+            cu_key = (xcc << 8) | ((hw_l[0] >> 8) & 0xff);
+            if (threadIdx.x == 0) cu_prev = atomicAdd(&g_cu_live[cu_key], 1);
+        }
         if (threadIdx.x == 0) {
             const int mode = f.n_chunks > 0 ? 0 : (ron ? 1 : 2);
             atomicAdd(&g_pro_acc[mode * 5 + 0], blk_tp - blk_t0); atomicAdd(&g_pro_acc[mode * 5 + 1], blk_tq - blk_tp);
@@ -1472,6 +1486,16 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         cnt = duo.cnt; steps = duo.steps; grew = duo.grew != 0;
         truncated = true;                                            // the node comes from the history
 #ifdef STEER_TIMING
+        if (threadIdx.x == 0) {
+            const int still = atomicSub(&g_cu_live[cu_key], 1);
+            if (steps >= 20) {
+                const int s0 = (hw_l[0] >> 4) & 3, s1 = (hw_l[1] >> 4) & 3, s2 = (hw_l[2] >> 4) & 3, s3 = (hw_l[3] >> 4) & 3;
+                const bool distinct = s0 != s1 && s0 != s2 && s0 != s3 && s1 != s2 && s1 != s3 && s2 != s3;
+                const int cls = (distinct ? 0 : 1) + ((cu_prev > 0 || still > 1) ? 2 : 0);
+                const unsigned long long t2c = wall_clock64();
+                atomicAdd(&g_place_acc[cls * 2], t2c - blk_t1); atomicAdd(&g_place_acc[cls * 2 + 1], 1ull);
+            }
+        }
         if (threadIdx.x == 0 && steps >= 20) {
             const unsigned long long t2 = wall_clock64();
             atomicAdd(&g_blk_acc[1], t2 - blk_t1); atomicMax(&g_blk_acc[4], t2 - blk_t1);

@@ -48,3 +48,8 @@ for mode, name in enumerate(("speculative launch", "fused repair round (re-steer
 h = (C.c_ulonglong * 32)()
 nat.lib().lqrrt_debug_loop_hist(h)
 print("loop time of full-horizon rollouts, 2 us buckets:", " ".join("%d-%d:%d" % (2 * i, 2 * i + 2, h[i]) for i in range(32) if h[i]))
+pl = (C.c_ulonglong * 16)()
+if hasattr(nat.lib(), "lqrrt_debug_place_acc") and nat.lib().lqrrt_debug_place_acc(pl) == 0:
+    names = ("own CU, four SIMDs", "own CU, two wavefronts on one SIMD", "shared CU, four SIMDs", "shared CU, two wavefronts on one SIMD")
+    print("full-horizon rollouts by placement (chain-owner rollout):", " | ".join(
+        "%s: %d, loop avg %.2f us" % (names[c], pl[2 * c + 1], pl[2 * c] * 0.01 / max(1, pl[2 * c + 1])) for c in range(4)))
