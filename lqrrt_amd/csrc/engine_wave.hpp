@@ -43,7 +43,11 @@ static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, 
     static const bool patch_on = [] { const char* v = getenv("LQRRT_IGNORE_PATCH"); return !(v && atoi(v) == 0); }();
     if (patch_on && e->ign_dirty && e->ign_patch_valid && cnt > 0 && !e->ign_patch.empty()) {
         patch.n = (int)e->ign_patch.size();
-        for (int k = 0; k < patch.n; ++k) { patch.idx[k] = e->ign_patch[k]; patch.val[k] = e->h_ign[e->ign_patch[k]]; }
+        patch.wmin = patch.wmax = e->ign_patch[0];
+        for (int k = 0; k < patch.n; ++k) {
+            patch.idx[k] = e->ign_patch[k]; patch.val[k] = e->h_ign[e->ign_patch[k]];
+            patch.wmin = std::min(patch.wmin, patch.idx[k]); patch.wmax = std::max(patch.wmax, patch.idx[k]);
+        }
         e->ign_dirty = false; e->ign_patch_valid = false; e->ign_hi = e->N;
     } else {
         TRY(flush_ignore(e, st, false));

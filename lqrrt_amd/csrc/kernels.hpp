@@ -65,7 +65,7 @@ struct NodeView {
 // of one path on it: a handful of words).  They ride along as arguments of the next tree scan instead of going through a
 // host-to-device copy (an API call of ~6 us and a blit dispatch in front of every second wave's scan): every workgroup
 // applies them to the words it reads, workgroup (0, 0) stores them for the launches that follow.
-struct IgnPatch { int n, pad; int idx[16]; unsigned long long val[16]; };
+struct IgnPatch { int n, wmin, wmax, pad; int idx[16]; unsigned long long val[16]; };   // wmin..wmax: range of idx[0..n-1]
 
 struct TreeView {
     double* state;          // [n][cap]
@@ -240,6 +240,16 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
         const int tmax = bx * 64 + 63;
         if (i1 > tmax) i1 = tmax;
     }
+    // does a patched ignore word cover nodes of this workgroup's chunk at all?  (a hit's path: a few words, mostly the newest
+    // nodes -- nearly every workgroup skips the patch lookup below)
+    bool patched = false;
+    if constexpr (!TRI) {
+        const int w0 = i0 >> 6, w1 = (i1 - 1) >> 6;
+        if (pt.n > 0 && w1 >= pt.wmin && w0 <= pt.wmax) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) patched = patched || (k < pt.n && pt.idx[k] >= w0 && pt.idx[k] <= w1);
+        }
+    }
     double xg[S::N], gtrig[2 * S::NW + 1];
 #pragma unroll
     for (int d = 0; d < S::N; ++d) xg[d] = xs[(size_t)ts * S::N + d];
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
             else if (nv.ignore) {
                 const int wi = (int)(i >> 6);
                 unsigned long long w = nv.ignore[wi];
-                if (pt.n > 0) {
+                if (patched) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k) w = (k < pt.n && pt.idx[k] == wi) ? pt.val[k] : w;
                 }
@@ -795,6 +805,66 @@ __device__ unsigned long long g_pro_acc[16];        // prologue of rolling workg
 #define STEP_ACC(i, a, b) do {} while (0)
 #endif
 
+// The last workgroup to add its share to the round's word closes the round: counts to the host and, in a converged round,
+// ranks and the committed prefix for the append.  One wavefront (the helpers wait at barrier S or are gone): no workgroup
+// barrier in here.  (A function, not a lambda: a closure that is not scalarised costs the kernel a stack frame.)
+__device__ __forceinline__ void close_round(const RoundArgs& ra, int lane, unsigned long long round_before, unsigned long long round_share) {
+    const int cur = ra.round & 1, nxt = cur ^ 1;
+    unsigned long long* word_r = (unsigned long long*)(ra.ctl + RC_PACK) + cur;
+    const unsigned long long before_me = ((unsigned long long)(unsigned)__shfl((int)(round_before >> 32), 0) << 32) |
+                                         (unsigned)__shfl((int)round_before, 0);
+    if ((int)(before_me & 0xffffu) == ra.W - 1) {
+        const unsigned long long all = before_me + round_share;
+        const int n_list = (int)((all >> 16) & 0xffffu), n_defer = (int)((all >> 32) & 0xffffu);
+        const bool converged = n_list == 0 && n_defer == 0;
+        if (converged) {
+            // commit rules of lqrrt_wave_commit (planner.py:311 node limit, :270 the wave ends at a goal hit), on the
+            // final records: accepted-before counts, committed prefix C.  (Nobody re-steers: this round's buffers
+            // will be copies of the previous round's, which the kernel boundary has already published.)
+            const int* lfn = ra.lf[cur];
+            int before = 0, first_hit = ra.W, t_room = ra.W;
+            for (int c0 = 0; c0 < ra.W; c0 += 64) {
+                const int tt = c0 + lane;
+                const bool in = tt < ra.W;
+                const int len = in ? lfn[2 * tt] : 0, flg = in ? lfn[2 * tt + 1] : 0;
+                const bool a = len > 0;
+                const unsigned long long A = __ballot(a);
+                const int mine = before + __popcll(A & ((1ull << lane) - 1ull));      // accepted before sample tt
+                if (in) {
+                    ra.rank[tt] = mine;
+                    ra.host_summary[tt] = len; ra.host_summary[ra.W + tt] = flg; ra.host_summary[2 * ra.W + tt] = ra.par[cur][tt];
+                    if (a && (flg & 1)) first_hit = min(first_hit, tt);
+                    if (ra.room >= 0 && (long long)mine >= ra.room) t_room = min(t_room, tt);
+                }
+                before += __popcll(A);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                first_hit = min(first_hit, __shfl_xor(first_hit, off));
+                t_room = min(t_room, __shfl_xor(t_room, off));
+            }
+            long long Cl = ra.W;
+            if (ra.max_commit < Cl) Cl = ra.max_commit;
+            if (t_room < Cl) Cl = t_room;
+            if (first_hit + 1 < Cl) Cl = first_hit + 1;
+            const int C = (int)(Cl < 0 ? 0 : Cl);
+            // ranks of samples at or beyond C are never used by the append (parents point backwards)
+            if (lane == 0) {
+                ra.ctl[RC_C] = C;
+                ra.ctl[RC_CONV + nxt] = 1;
+                ra.host_ctrl[0] = first_hit < ra.W ? first_hit : ra.W - 1;
+            }
+        }
+        if (lane == 0) *word_r = 0ull;                                                          // for round + 2
+        // the summary (all lanes' stores, pinned host memory) before the word that announces it
+        if (converged) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __threadfence_system(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if (lane == 0) {
+            const unsigned long long word = ((unsigned long long)(unsigned)ra.seq << 32) | (unsigned)((n_list << 16) | (n_defer & 0xffff));
+            __hip_atomic_store((unsigned long long*)(ra.host_ctrl + 2 + 2 * cur), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 template <class S, int DENSE, int NWF>
 __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, TreeView tv, double* __restrict__ rec,
                                               RecLayout L, const double* __restrict__ xs,
@@ -1165,65 +1235,6 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     int pref;
     unsigned long long round_share = 1ull;                        // fused round: this workgroup's contribution to the round's word
     unsigned long long round_before = 0;                          // (lane 0) the round's word as this workgroup's atomic found it
-    bool round_redo = false;
-    // The last workgroup to add its share closes the round: counts to the host and, in a converged round, ranks and the
-    // committed prefix for the append.  Main wavefront only (the helpers wait at barrier S or are gone): no workgroup barrier.
-    auto close_round = [&]() {
-        const int cur = ra.round & 1, nxt = cur ^ 1;
-        unsigned long long* word_r = (unsigned long long*)(ra.ctl + RC_PACK) + cur;
-        const unsigned long long before_me = ((unsigned long long)(unsigned)__shfl((int)(round_before >> 32), 0) << 32) |
-                                             (unsigned)__shfl((int)round_before, 0);
-        if ((int)(before_me & 0xffffu) == ra.W - 1) {
-            const unsigned long long all = before_me + round_share;
-            const int n_list = (int)((all >> 16) & 0xffffu), n_defer = (int)((all >> 32) & 0xffffu);
-            const bool converged = n_list == 0 && n_defer == 0;
-            if (converged) {
-                // commit rules of lqrrt_wave_commit (planner.py:311 node limit, :270 the wave ends at a goal hit), on the
-                // final records: accepted-before counts, committed prefix C.  (Nobody re-steers: this round's buffers
-                // will be copies of the previous round's, which the kernel boundary has already published.)
-                const int* lfn = ra.lf[cur];
-                int before = 0, first_hit = ra.W, t_room = ra.W;
-                for (int c0 = 0; c0 < ra.W; c0 += 64) {
-                    const int tt = c0 + lane;
-                    const bool in = tt < ra.W;
-                    const int len = in ? lfn[2 * tt] : 0, flg = in ? lfn[2 * tt + 1] : 0;
-                    const bool a = len > 0;
-                    const unsigned long long A = __ballot(a);
-                    const int mine = before + __popcll(A & ((1ull << lane) - 1ull));      // accepted before sample tt
-                    if (in) {
-                        ra.rank[tt] = mine;
-                        ra.host_summary[tt] = len; ra.host_summary[ra.W + tt] = flg; ra.host_summary[2 * ra.W + tt] = ra.par[cur][tt];
-                        if (a && (flg & 1)) first_hit = min(first_hit, tt);
-                        if (ra.room >= 0 && (long long)mine >= ra.room) t_room = min(t_room, tt);
-                    }
-                    before += __popcll(A);
-                }
-    #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    first_hit = min(first_hit, __shfl_xor(first_hit, off));
-                    t_room = min(t_room, __shfl_xor(t_room, off));
-                }
-                long long Cl = ra.W;
-                if (ra.max_commit < Cl) Cl = ra.max_commit;
-                if (t_room < Cl) Cl = t_room;
-                if (first_hit + 1 < Cl) Cl = first_hit + 1;
-                const int C = (int)(Cl < 0 ? 0 : Cl);
-                // ranks of samples at or beyond C are never used by the append (parents point backwards)
-                if (lane == 0) {
-                    ra.ctl[RC_C] = C;
-                    ra.ctl[RC_CONV + nxt] = 1;
-                    ra.host_ctrl[0] = first_hit < ra.W ? first_hit : ra.W - 1;
-                }
-            }
-            if (lane == 0) *word_r = 0ull;                                                          // for round + 2
-            // the summary (all lanes' stores, pinned host memory) before the word that announces it
-            if (converged) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __threadfence_system(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            if (lane == 0) {
-                const unsigned long long word = ((unsigned long long)(unsigned)ra.seq << 32) | (unsigned)((n_list << 16) | (n_defer & 0xffff));
-                __hip_atomic_store((unsigned long long*)(ra.host_ctrl + 2 + 2 * cur), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    };
     if (f.n_chunks > 0) {
         // nearest node of this sample from the scan's partial minima (see k_nn_reduce for the rules)
         double b = INFINITY;
@@ -1392,8 +1403,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             // workgroup ends with an atomic round trip across the chip.
             unsigned long long* word_r = (unsigned long long*)(ra.ctl + RC_PACK) + cur;
             if (lane == 0) round_before = __hip_atomic_fetch_add(word_r, round_share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            round_redo = redo;
-            if (!redo) close_round();
+            // (the look at what came back happens at the end of this function, which a workgroup that stands reaches at once)
         }
         if (!redo) {
             // nothing to recompute: this sample's row and len/flags move on unchanged
@@ -1825,7 +1835,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     }
 #endif
     }   // !round_skip
-    if (ron && round_redo) close_round();
+    if (ron) close_round(ra, lane, round_before, round_share);
 }
 
 // Rows of the in-wave cost matrix straight from the records (sharded waves: records of other ranks arrive by
