@@ -213,9 +213,15 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
                                                 double* __restrict__ pcost, int* __restrict__ pidx,
                                                 int ps_c, int ps_t, IgnPatch pt) {
     const int lane = threadIdx.x;
+    // patch entry k lives in lane k (and k + 16, ...): one vector load each, issued with the launch's first loads -- the
+    // argument block is not in any cache yet, and a lookup that went back to it per tile cost the launch ~2 us
+    int pt_idx = -1;
+    unsigned long long pt_val = 0;
     if constexpr (!TRI) {
-        if (pt.n > 0 && blockIdx.x == 0 && blockIdx.y == 0 && lane < pt.n && nv.ignore)
-            const_cast<unsigned long long*>(nv.ignore)[pt.idx[lane]] = pt.val[lane];
+        if (pt.n > 0) {
+            pt_idx = pt.idx[lane & 15]; pt_val = pt.val[lane & 15];
+            if (blockIdx.x == 0 && blockIdx.y == 0 && lane < pt.n && nv.ignore) const_cast<unsigned long long*>(nv.ignore)[pt_idx] = pt_val;
+        }
     }
     // XCD-aware tile mapping: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each
     // with its own L2.  Re-index so that XCD k owns a contiguous band of node chunks (for every sample
@@ -245,10 +251,7 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
     bool patched = false;
     if constexpr (!TRI) {
         const int w0 = i0 >> 6, w1 = (i1 - 1) >> 6;
-        if (pt.n > 0 && w1 >= pt.wmin && w0 <= pt.wmax) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) patched = patched || (k < pt.n && pt.idx[k] >= w0 && pt.idx[k] <= w1);
-        }
+        if (pt.n > 0) patched = __any(lane < pt.n && pt_idx >= w0 && pt_idx <= w1) != 0;
     }
     double xg[S::N], gtrig[2 * S::NW + 1];
 #pragma unroll
@@ -304,7 +307,12 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
                 unsigned long long w = nv.ignore[wi];
                 if (patched) {
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) w = (k < pt.n && pt.idx[k] == wi) ? pt.val[k] : w;
+                    for (int k = 0; k < 16; ++k) {
+                        const int ik = __builtin_amdgcn_readlane(pt_idx, k);
+                        const unsigned long long vk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(pt_val >> 32), k) << 32) |
+                                                      (unsigned)__builtin_amdgcn_readlane((int)pt_val, k);
+                        w = (k < pt.n && ik == wi) ? vk : w;
+                    }
                 }
                 el = ((w >> (i & 63)) & 1ull) == 0;
             } else el = true;
