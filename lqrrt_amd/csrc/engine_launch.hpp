@@ -189,6 +189,13 @@ static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
 }
 
 // NN over a node table for W samples at xs (device, [W][n]); writes id/cost and/or records.
+// the scan variants that can take an IgnPatch (the generic identity / dense-S ones; not the structured-S and per-sample-S forms)
+static bool scan_takes_patch(const lqrrt_engine* e) {
+    if (e->riccati) return false;
+    const int sm = e->d_S ? e->smode : S_IDENT;
+    return !(sm == S_BAND2 && e->model == LQRRT_MODEL_DOUBLE_INTEGRATOR) && !(sm == S_DIAG && e->model == LQRRT_MODEL_ROS_BOAT);
+}
+
 static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int W, const double* Sd,
                      bool tri, int* out_id, double* out_cost, double* rec, hipStream_t st,
                      bool profile, int* n_chunks_out = nullptr, int wave_lo = -1, bool defer_reduce = false,
@@ -213,11 +220,17 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
 #define NN_LAUNCH(DENSE, TRI)                                                                            \
     DISPATCH(e, hipExtLaunchKernelGGL((k_nn_scan<S, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
                                       e->d_pcost, e->d_pidx, ps_c, ps_t, pt))
+    // (the instantiation that looks at the patch is a launch of its own: the scan's inner loop lives at the SGPR limit, and the
+    //  plain one must not pay for what two launches in three do not need)
+#define NN_LAUNCH_PATCH(DENSE)                                                                          \
+    DISPATCH(e, hipExtLaunchKernelGGL((k_nn_scan<S, DENSE, false, true>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
+                                      e->d_pcost, e->d_pidx, ps_c, ps_t, pt))
     // structured forms of the engine's own S are instantiated only for the systems that have them
     const int sm = !S_use ? S_IDENT : (Sd ? S_DENSE : e->smode);
 #define NN_ONE(SYS, DENSE, TRI)                                                                            \
     hipExtLaunchKernelGGL((k_nn_scan<SYS, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
                           e->d_pcost, e->d_pidx, ps_c, ps_t, pt)
+    if (pt.n > 0 && (tri || Spers || Sd || !scan_takes_patch(e))) return fail(LQRRT_E_STATE, "this scan variant takes no ignore patch");
     if (Spers) {
         if (!e->riccati) return fail(LQRRT_E_ARG, "per-sample S is only instantiated for Riccati systems");
         DISPATCH(e, if constexpr (has_dare_gain<S>::value) { if (tri) NN_ONE(S, S_PERSAMPLE, true); else NN_ONE(S, S_PERSAMPLE, false); });
@@ -226,12 +239,13 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     } else if (sm == S_DIAG && e->model == LQRRT_MODEL_ROS_BOAT) {
         if (tri) NN_ONE(RosBoat, S_DIAG, true); else NN_ONE(RosBoat, S_DIAG, false);
     } else if (S_use) {
-        if (tri) { NN_LAUNCH(S_DENSE, true); } else { NN_LAUNCH(S_DENSE, false); }
+        if (tri) { NN_LAUNCH(S_DENSE, true); } else if (pt.n > 0) { NN_LAUNCH_PATCH(S_DENSE); } else { NN_LAUNCH(S_DENSE, false); }
     } else {
-        if (tri) { NN_LAUNCH(S_IDENT, true); } else { NN_LAUNCH(S_IDENT, false); }
+        if (tri) { NN_LAUNCH(S_IDENT, true); } else if (pt.n > 0) { NN_LAUNCH_PATCH(S_IDENT); } else { NN_LAUNCH(S_IDENT, false); }
     }
 #undef NN_ONE
 #undef NN_LAUNCH
+#undef NN_LAUNCH_PATCH
     if (profile) prof_end(e, st, &ev, 0, (double)W * (double)nv.count * (8.0 * e->n + 1.0));
     if (tri || defer_reduce) { HIPCHK(hipGetLastError()); return 0; }     // deferred: the steer launch reduces (SteerFuse)
     NodeView nvr = nv;

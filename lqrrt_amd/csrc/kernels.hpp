@@ -207,7 +207,7 @@ __device__ __forceinline__ double quad_cost(const double* e, const double* Sd) {
 // chunk-major (ps_t = 1), the order k_decide wants.
 // xtrig: cos/sin of the samples' angular coordinates [W][2*NW] if the caller has them (the engine computes them once
 // per sample batch), else null and they are computed here.
-template <class S, int DENSE, bool TRI>
+template <class S, int DENSE, bool TRI, bool PATCH = false>
 __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __restrict__ xs, const double* __restrict__ xtrig,
                                                 int W, const double* __restrict__ Sd, int chunk,
                                                 double* __restrict__ pcost, int* __restrict__ pidx,
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
     // argument block is not in any cache yet, and a lookup that went back to it per tile cost the launch ~2 us
     int pt_idx = -1;
     unsigned long long pt_val = 0;
-    if constexpr (!TRI) {
+    if constexpr (PATCH) {
         if (pt.n > 0) {
             pt_idx = pt.idx[lane & 15]; pt_val = pt.val[lane & 15];
             if (blockIdx.x == 0 && blockIdx.y == 0 && lane < pt.n && nv.ignore) const_cast<unsigned long long*>(nv.ignore)[pt_idx] = pt_val;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
     // does a patched ignore word cover nodes of this workgroup's chunk at all?  (a hit's path: a few words, mostly the newest
     // nodes -- nearly every workgroup skips the patch lookup below)
     bool patched = false;
-    if constexpr (!TRI) {
+    if constexpr (PATCH) {
         const int w0 = i0 >> 6, w1 = (i1 - 1) >> 6;
         if (pt.n > 0) patched = __any(lane < pt.n && pt_idx >= w0 && pt_idx <= w1) != 0;
     }
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
             else if (nv.ignore) {
                 const int wi = (int)(i >> 6);
                 unsigned long long w = nv.ignore[wi];
-                if (patched) {
+                if (PATCH && patched) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {
                         const int ik = __builtin_amdgcn_readlane(pt_idx, k);
