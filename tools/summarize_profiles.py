@@ -84,7 +84,7 @@ def main():
         shutil.copy(f, os.path.join(out, "%s_%s" % (rnd, os.path.basename(f))))
     load = lambda n: json.load(open(os.path.join(src, n)))
     fetch, write, sq_a, sq_b = load("fetch.csv.json"), load("write.csv.json"), load("sq_a.csv.json"), load("sq_b.csv.json")
-    kern = "k_nn_scan<lq::BoatAdvanced, 0, false>"
+    kern = "k_nn_scan<lq::BoatAdvanced, 0, false"      # both instantiations of the tree scan (with / without ignore patch), merged by launch count
     kf, kw = kernel(fetch, kern), kernel(write, kern)
     traffic = {
         "kernel": kern, "command": "python bench.py --steps 3 --warmup 1 --units 16 --no-cpu --no-extras (3 x 16,384 attempts in the 10k-node window)",

@@ -5,7 +5,11 @@ rows = list(csv.DictReader(open(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_ou
 def short(n):
     m = re.match(r'(?:void )?(?:lq::)?(\w+)', n)
     k = m.group(1) if m else n[:30]
-    if k == 'k_nn_scan' and re.search(r'true>\(', n.replace(' ', '')) : k += '<TRI>'
+    if k == 'k_nn_scan':                       # k_nn_scan<System, S form, TRI[, PATCH]>: the in-wave (triangular) scan is its own line
+        a = re.search(r'k_nn_scan<(.*?)>\(', n)
+        args = [x.strip() for x in a.group(1).split(',')] if a else []
+        if len(args) >= 3 and args[2] == 'true':
+            k += '<TRI>'
     return k
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name'])) for r in rows)
 ev = ev[300:3800]
