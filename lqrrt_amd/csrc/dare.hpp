@@ -35,10 +35,87 @@ __device__ __forceinline__ void mm(double* C, const double* A, const double* B, 
 // so every right-hand-side column gets the same bits whether it is solved alone or next to others.
 //   per pivot: every lane scans the column itself (n broadcast LDS reads instead of a 6-stage butterfly), lanes j < n + q
 //   divide the pivot row once, and one pass over the n (n + q) entries scales and eliminates (reads, barrier, writes).
+__device__ __forceinline__ double readlane_f64(double v, int l) {        // l wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// Gauss-Jordan elimination of [W | RHS] (n x (n + q), up to 128 entries) held in registers: entry e = r C + j in lane e % 64,
+// slot e / 64.  A pivot costs no LDS traffic and no barrier: the column scan and the pivot are v_readlane's (uniform positions),
+// the pivot-row entry and the row's multiplier of each lane two cross-lane gathers.  Same operations on the same values as the
+// LDS form in solve_inplace, entry by entry.  On return the RHS columns hold W^-1 RHS.
+template <int n, int q>
+__device__ __forceinline__ void gj_eliminate(double (&v)[(n * (n + q) + 63) / 64], int lane) {
+    constexpr int C = n + q, E = n * C, IT = (E + 63) / 64;
+    static_assert(IT <= 2, "register form: at most 128 entries");
+    int rr[IT], jj[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) { rr[k] = (lane + 64 * k) / C; jj[k] = (lane + 64 * k) % C; }
+    auto elem = [&](int e) __attribute__((always_inline)) -> double {      // entry e, e wave-uniform
+        double a = readlane_f64(v[0], e & 63);
+        if constexpr (IT > 1) { const double b = readlane_f64(v[1], e & 63); a = e >= 64 ? b : a; }
+        return a;
+    };
+    auto gather = [&](int e) __attribute__((always_inline)) -> double {    // entry e, e per lane
+        double a = __shfl(v[0], e & 63);
+        if constexpr (IT > 1) { const double b = __shfl(v[1], e & 63); a = e >= 64 ? b : a; }
+        return a;
+    };
+#pragma unroll 1
+    for (int p = 0; p < n; ++p) {
+        double best = -1.0;
+        int brow = p;
+#pragma unroll
+        for (int r = 0; r < n; ++r) {
+            if (r < p) continue;
+            const double a = fabs(elem(r * C + p));
+            if (a > best) { best = a; brow = r; }
+        }
+        brow = __builtin_amdgcn_readfirstlane(brow);
+        if (brow != p) {
+            double t[IT];
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int src = rr[k] == p ? brow * C + jj[k] : (rr[k] == brow ? p * C + jj[k] : lane + 64 * k);
+                t[k] = gather(src);
+            }
+#pragma unroll
+            for (int k = 0; k < IT; ++k) v[k] = t[k];
+        }
+        const double piv = elem(p * C + p);
+        double nv[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const double y = gather(p * C + jj[k]) / piv;                    // the scaled pivot row, column of this lane
+            const double f = gather(rr[k] * C + p);
+            double x = v[k];
+            x -= f * y;
+            nv[k] = rr[k] == p ? y : x;
+        }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) v[k] = nv[k];
+    }
+}
+
 template <int n, int q>
 __device__ __forceinline__ void solve_inplace(double* W, double* RHS, int lane) {
     constexpr int C = n + q, E = n * C, IT = (E + 63) / 64;
     static_assert(C <= 64, "one lane per column of [W | RHS]");
+    if constexpr (IT <= 2) {
+        double v[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int idx = lane + 64 * k, r = idx / C, j = idx % C;
+            v[k] = idx < E ? (j < n ? W[r * n + j] : RHS[r * q + (j - n)]) : 0.0;
+        }
+        gj_eliminate<n, q>(v, lane);
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int idx = lane + 64 * k, r = idx / C, j = idx % C;
+            if (idx < E && j >= n) RHS[r * q + (j - n)] = v[k];
+        }
+        __syncthreads();
+        return;
+    }
 #pragma unroll 1
     for (int p = 0; p < n; ++p) {
         double best = -1.0;
@@ -145,6 +222,73 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
     mm(G, Bm, X, n, m, n, false, false, lane);
     // ---- doubling
     int it = 0;
+    if constexpr (n * 3 * n <= 128) {
+        // Four passes and four barriers per iteration: (1) W = I + G H; (2) [W | A_k | G] into registers, eliminated there
+        // (gj_eliminate), T1 = W^-1 A_k and T2 = W^-1 G out; (3) the three products that only need T1 / T2 side by side; (4) the two
+        // that update H and G, accumulated in place.  A_k and its successor swap buffers instead of being copied.  Every entry is
+        // the sum the plain sequence below forms, term by term.
+        auto dot = [&](const double* Am, const double* Bq, int i, int j, bool ta, bool tb) __attribute__((always_inline)) -> double {
+            double acc = 0.0;
+#pragma unroll
+            for (int pp = 0; pp < n; ++pp) {
+                const double a = ta ? Am[pp * n + i] : Am[i * n + pp];
+                const double b = tb ? Bq[j * n + pp] : Bq[pp * n + j];
+                acc += a * b;
+            }
+            return acc;
+        };
+        double* Akc = Ak;                                  // A_k of this iteration
+        double* Akn = AG;                                  // ... of the next one
+        double* const W1 = T3;                             // H W^-1 A
+        double* const W2 = AG + n * n;                     // A W^-1 G
+        constexpr int C3 = 3 * n, E3 = n * C3, IT3 = (E3 + 63) / 64;
+        for (; it < max_iter; ++it) {
+            for (int e = lane; e < n * n; e += 64) {
+                const int i = e / n, j = e % n;
+                double acc = dot(G, Hm, i, j, false, false);
+                if (i == j) acc += 1.0;
+                W[e] = acc;                                                         // W = I + G H
+            }
+            __syncthreads();
+            double v[IT3];
+#pragma unroll
+            for (int k = 0; k < IT3; ++k) {
+                const int idx = lane + 64 * k, r = idx / C3, j = idx % C3;
+                v[k] = idx < E3 ? (j < n ? W[r * n + j] : (j < 2 * n ? Akc[r * n + (j - n)] : G[r * n + (j - 2 * n)])) : 0.0;
+            }
+            gj_eliminate<n, 2 * n>(v, lane);                                        // [T1 | T2] = W^-1 [A | G]
+#pragma unroll
+            for (int k = 0; k < IT3; ++k) {
+                const int idx = lane + 64 * k, r = idx / C3, j = idx % C3;
+                if (idx < E3 && j >= n) { if (j < 2 * n) T1[r * n + (j - n)] = v[k]; else T2[r * n + (j - 2 * n)] = v[k]; }
+            }
+            __syncthreads();
+            for (int idx = lane; idx < 3 * n * n; idx += 64) {
+                const int w = idx / (n * n), e = idx % (n * n), i = e / n, j = e % n;
+                const double acc = dot(w == 0 ? Hm : Akc, w == 1 ? T2 : T1, i, j, false, false);
+                (w == 0 ? W1 : (w == 1 ? W2 : Akn))[e] = acc;                       // H W^-1 A | A W^-1 G | A W^-1 A
+            }
+            __syncthreads();
+            double dmax = 0.0, hmax = 0.0;
+            for (int idx = lane; idx < 2 * n * n; idx += 64) {
+                const int w = idx / (n * n), e = idx % (n * n), i = e / n, j = e % n;
+                if (w == 0) {
+                    const double t3 = dot(Akc, W1, i, j, true, false);              // A' H W^-1 A
+                    const double hn = Hm[e] + t3;
+                    dmax = fmax(dmax, fabs(t3)); hmax = fmax(hmax, fabs(hn));
+                    Hm[e] = hn;
+                } else {
+                    const double t3 = dot(W2, Akc, i, j, false, true);              // A W^-1 G A'
+                    G[e] += t3;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { dmax = fmax(dmax, __shfl_xor(dmax, off)); hmax = fmax(hmax, __shfl_xor(hmax, off)); }
+            __syncthreads();
+            double* tsw = Akc; Akc = Akn; Akn = tsw;
+            if (dmax <= tol * fmax(1.0, hmax)) { ++it; break; }
+        }
+    } else
     for (; it < max_iter; ++it) {
         mm(W, G, Hm, n, n, n, false, false, lane);                             // W = G H
         for (int i = lane; i < n; i += 64) W[i * n + i] += 1.0;                 // W = I + G H
