@@ -26,6 +26,9 @@
 //   LQRRT_HOSTPROF               unset    hostprof_on              host time per wave, printed when an engine is destroyed
 // (Python side: LQRRT_LIB -- load another build of this library, lqrrt_amd/_native.py; LQRRT_FORCE_SHARDED and
 //  LQRRT_BENCH_EVENTS_EVERY -- bench.py.)
+// Compile-time (measurement builds only): -DSTEER_TIMING (device timestamps and placement counters in k_steer,
+// tools/steer_phases_bench.py), -DLQRRT_NO_KERNARG_TOUCH (k_steer without the touch of its argument block), -DABL_* (ablations,
+// tools/ablate_steer.py), -DLQRRT_USER_SYSTEM='"header"' (an out-of-tree problem as LQRRT_MODEL_USER, tools/build_user_system.py).
 #include "../../include/lqrrt_hip.h"
 #include "kernels.hpp"
 
