@@ -81,19 +81,24 @@ static int ensure_samples(lqrrt_engine* e, int64_t need_end, hipStream_t st) {
         TRY(dalloc(&e->d_flags, (size_t)CH));
         e->cand_cap = CH;
     }
+    const double tp0 = hostprof_on() ? now_us() : 0.0;
     std::vector<double> cand((size_t)CH * n);
     std::vector<unsigned char> flags(CH);
+    double tp_gen = 0, tp_gpu = 0, tp_filter = 0;
     while (e->pool_base + (int64_t)e->pool_rows_end.size() < target_end) {
+        const double ta = hostprof_on() ? now_us() : 0.0;
         // rows generated ahead while the host was waiting for repair rounds come first (same generator, same order)
         const int ahead = std::min(e->pregen_rows, CH);
         if (ahead > 0) memcpy(cand.data(), e->pregen.data(), sizeof(double) * (size_t)ahead * n);
         e->pregen_rows = 0;
         for (int r = ahead; r < CH; ++r) candidate_row(e, &cand[(size_t)r * n]);
+        const double tb = hostprof_on() ? now_us() : 0.0;
         HIPCHK(hipMemcpyAsync(e->d_cand, cand.data(), sizeof(double) * CH * n, hipMemcpyHostToDevice, st));
         DISPATCH(e, hipLaunchKernelGGL((k_feasible_batch<S>), dim3(CH), dim3(64), geo_lds_bytes(e), st, e->P, e->geo, e->d_cand, nullptr, CH, e->d_flags));
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(flags.data(), e->d_flags, CH, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        const double tc = hostprof_on() ? now_us() : 0.0;
         for (int r = 0; r < CH; ++r) {
             e->tries_carry++;
             if (flags[r] || e->tries_carry >= e->smp.tries_limit) {
@@ -103,13 +108,20 @@ static int ensure_samples(lqrrt_engine* e, int64_t need_end, hipStream_t st) {
             }
         }
         e->gen_row += CH;
+        if (hostprof_on()) { const double td = now_us(); tp_gen += tb - ta; tp_gpu += tc - tb; tp_filter += td - tc; }
     }
+    const double tp1 = hostprof_on() ? now_us() : 0.0;
     // upload [cursor, pool_end)
     const int64_t off = e->cursor - e->pool_base;
     const int64_t cnt = (int64_t)e->pool_rows_end.size() - off;
     TRY(upload_pool(e, off, cnt, st));
     e->d_pool_base = e->cursor;
     e->d_pool_count = cnt;
+    if (hostprof_on()) {
+        static int shown = 0;
+        if (shown++ < 6) fprintf(stderr, "[hostprof] refill: total %.0f us = alloc+erase %.0f | generate %.0f | copy+batch+sync %.0f | filter %.0f | upload %.0f\n",
+                                 now_us() - tp0 + 0.0, (tp1 - tp0) - tp_gen - tp_gpu - tp_filter, tp_gen, tp_gpu, tp_filter, now_us() - tp1);
+    }
     return 0;
 }
 
