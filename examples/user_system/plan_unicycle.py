@@ -10,6 +10,9 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+_here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblqrrt_unicycle.so")       # what __graft_entry__.build() leaves here
+if "LQRRT_LIB" not in os.environ and os.path.exists(_here):
+    os.environ["LQRRT_LIB"] = _here
 import lqrrt_amd as lqrrt
 
 
