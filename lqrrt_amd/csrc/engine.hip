@@ -22,6 +22,7 @@
 //   LQRRT_RCCL                   unset    rccl                     path of the librccl.so to resolve (default: the one in the process)
 //   LQRRT_POISON                 unset    dalloc                   fill every device allocation with 0xff (reads of unwritten memory show)
 //   LQRRT_TRACE                  unset    trace_on                 per-round trace on stderr
+//   LQRRT_REFILL_AHEAD           1        refill_ahead             0: the sample pool's feasibility batch and filter only when the pool runs dry
 //   LQRRT_IGNORE_PATCH           1        speculate_impl           0: the ignore words a goal hit changed are uploaded, not passed as scan arguments
 //   LQRRT_HOSTPROF               unset    hostprof_on              host time per wave, printed when an engine is destroyed
 // (Python side: LQRRT_LIB -- load another build of this library, lqrrt_amd/_native.py; LQRRT_FORCE_SHARDED and

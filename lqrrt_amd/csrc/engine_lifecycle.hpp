@@ -12,7 +12,20 @@ extern "C" int lqrrt_device_count(void) {
     return c;
 }
 
+// forgets the block prepared ahead of the next refill (the generator is being replaced, or the world it was tested against)
+static void refill_drop(lqrrt_engine* e) {
+    if (e->rf_stage == 2 && e->rf_event) (void)hipEventSynchronize(e->rf_event);
+    e->rf_stage = 0;
+}
+
 static void free_all(lqrrt_engine* e) {
+    refill_drop(e);
+    if (e->rf_event) (void)hipEventDestroy(e->rf_event);
+    if (e->rf_stream) (void)hipStreamDestroy(e->rf_stream);
+    if (e->h_cand_pin) (void)hipHostFree(e->h_cand_pin);
+    if (e->h_flags_pin) (void)hipHostFree(e->h_flags_pin);
+    if (e->d_cand2) (void)hipFree(e->d_cand2);
+    if (e->d_flags2) (void)hipFree(e->d_flags2);
     void* ptrs[] = {e->d_vps, e->d_obs, e->d_oc, e->d_og, e->d_ogc, e->d_cell_start, e->d_cell_items, e->d_S, e->tv.state, e->tv.trig, e->tv.werr, e->tv.K, e->tv.pID, e->tv.elen,
                     e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_M,
                     e->d_pidx, e->d_par_done, e->d_par_want, e->d_list,
@@ -206,7 +219,7 @@ extern "C" int lqrrt_engine_set_resolution(lqrrt_engine* e, const lqrrt_resoluti
         MT g = e->mt_base;
         for (int64_t i = 0; i < (e->committed_row - e->base_row) * (int64_t)(e->n + 1); ++i) (void)g.next_double();
         e->mt_base = g; e->base_row = e->committed_row;
-        e->mt_gen = g; e->gen_row = e->committed_row; e->pregen_rows = 0;
+        e->mt_gen = g; e->gen_row = e->committed_row; e->pregen_rows = 0; refill_drop(e);
         e->tries_carry = 0; e->d_pool_count = 0;
     }
     return 0;
@@ -222,7 +235,7 @@ static void invalidate_samples(lqrrt_engine* e) {
     MT g = e->mt_base;
     for (int64_t i = 0; i < (e->committed_row - e->base_row) * (int64_t)(e->n + 1); ++i) (void)g.next_double();
     e->mt_base = g; e->base_row = e->committed_row;
-    e->mt_gen = g; e->gen_row = e->committed_row; e->pregen_rows = 0;
+    e->mt_gen = g; e->gen_row = e->committed_row; e->pregen_rows = 0; refill_drop(e);
     e->tries_carry = 0; e->d_pool_count = 0;
 }
 
@@ -280,7 +293,7 @@ extern "C" int lqrrt_engine_set_mt19937(lqrrt_engine* e, const uint32_t* key624,
     memcpy(e->mt_gen.key, key624, sizeof(uint32_t) * 624);
     e->mt_gen.pos = pos;
     e->mt_base = e->mt_gen;
-    e->pregen_rows = 0;
+    e->pregen_rows = 0; refill_drop(e);
     e->base_row = e->gen_row = e->committed_row = 0;
     e->pool.clear(); e->pool_rows_end.clear();
     e->pool_base = e->cursor;

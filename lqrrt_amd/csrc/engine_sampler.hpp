@@ -40,10 +40,101 @@ static const int SAMPLER_BLOCK = 16384;
 // the GPU works through repair rounds.  This generates up to `rows` candidates of the NEXT refill during such a wait.
 static void pregenerate_candidates(lqrrt_engine* e, int rows) {
     if (e->explicit_samples || !e->has_sampler || !e->has_goal || e->pregen_rows >= SAMPLER_BLOCK) return;
+    if (e->rf_stage == 1) return;                                 // the full block in `pregen` is being copied out: leave it alone
     if (e->pregen.size() < (size_t)SAMPLER_BLOCK * e->n) e->pregen.resize((size_t)SAMPLER_BLOCK * e->n);
     const int end = std::min(SAMPLER_BLOCK, e->pregen_rows + rows);
     for (int r = e->pregen_rows; r < end; ++r) candidate_row(e, &e->pregen[(size_t)r * e->n]);
     e->pregen_rows = end;
+}
+
+// A refill stops the GPU for ~250 us (feasibility batch 90 us, host filter 70 us, upload 60 us; LQRRT_HOSTPROF) while the host idles
+// for ~85 us of every wave waiting for repair rounds.  Called in those waits, never blocking: once a whole block of candidates has
+// been generated ahead it is copied to pinned memory (a slice per call), tested on a stream of its own while the rounds go on,
+// and filtered (a slice per call) -- the same rows, flags and tries rule as the refill's own loop, which then only appends.
+static int refill_ahead(lqrrt_engine* e) {
+    static const bool on = [] { const char* v = getenv("LQRRT_REFILL_AHEAD"); return !(v && atoi(v) == 0); }();
+    if (!on || e->explicit_samples || !e->has_sampler || !e->has_goal) return 0;
+    const int CH = SAMPLER_BLOCK, n = e->n, SLICE = 2048;
+    if (e->rf_stage == 0) {
+        if (e->pregen_rows < CH) return 0;
+        if (!e->rf_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&e->rf_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&e->rf_event, hipEventDisableTiming));
+            HIPCHK(hipHostMalloc((void**)&e->h_cand_pin, sizeof(double) * (size_t)CH * MAXN, hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void**)&e->h_flags_pin, (size_t)CH, hipHostMallocDefault));
+            TRY(dalloc(&e->d_cand2, (size_t)CH * MAXN));
+            TRY(dalloc(&e->d_flags2, (size_t)CH));
+        }
+        e->rf_stage = 1; e->rf_pos = 0;
+    }
+    if (e->rf_stage == 1) {
+        const int end = std::min(CH, e->rf_pos + 2 * SLICE);
+        memcpy(e->h_cand_pin + (size_t)e->rf_pos * n, e->pregen.data() + (size_t)e->rf_pos * n, sizeof(double) * (size_t)(end - e->rf_pos) * n);
+        e->rf_pos = end;
+        if (end < CH) return 0;
+        HIPCHK(hipMemcpyAsync(e->d_cand2, e->h_cand_pin, sizeof(double) * (size_t)CH * n, hipMemcpyHostToDevice, e->rf_stream));
+        DISPATCH(e, hipLaunchKernelGGL((k_feasible_batch<S>), dim3(CH), dim3(64), geo_lds_bytes(e), e->rf_stream, e->P, e->geo, e->d_cand2, nullptr, CH, e->d_flags2));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(e->h_flags_pin, e->d_flags2, CH, hipMemcpyDeviceToHost, e->rf_stream));
+        HIPCHK(hipEventRecord(e->rf_event, e->rf_stream));
+        e->pregen_rows = 0;                                       // `pregen` is free for the block after this one
+        e->rf_stage = 2;
+        return 0;
+    }
+    if (e->rf_stage == 2) {
+        const hipError_t q = hipEventQuery(e->rf_event);
+        (void)hipGetLastError();                                  // (hipErrorNotReady is an answer, not an error to find later)
+        if (q == hipErrorNotReady) return 0;
+        if (q != hipSuccess) return fail(LQRRT_E_HIP, "feasibility batch of the block prepared ahead failed: %s", hipGetErrorString(q));
+        e->rf_stage = 3; e->rf_pos = 0; e->rf_carry = e->tries_carry;
+        e->rf_rows.clear(); e->rf_rows_end.clear();
+        return 0;
+    }
+    if (e->rf_stage == 3) {
+        const int end = std::min(CH, e->rf_pos + SLICE);
+        for (int r = e->rf_pos; r < end; ++r) {
+            e->rf_carry++;
+            if (e->h_flags_pin[r] || e->rf_carry >= e->smp.tries_limit) {
+                e->rf_rows.insert(e->rf_rows.end(), e->h_cand_pin + (size_t)r * n, e->h_cand_pin + (size_t)r * n + n);
+                e->rf_rows_end.push_back(r + 1);
+                e->rf_carry = 0;
+            }
+        }
+        e->rf_pos = end;
+        if (end == CH) e->rf_stage = 4;
+    }
+    return 0;
+}
+
+// the refill's side of it: whatever stage the block prepared ahead is in, finish it now and append its rows (it is the next block
+// of the candidate stream: `pregen` rows, if any, come after it)
+static int refill_take_prepared(lqrrt_engine* e) {
+    const int CH = SAMPLER_BLOCK, n = e->n;
+    if (e->rf_stage == 1) { e->rf_stage = 0; return 0; }          // still in `pregen`, untouched: the refill's own loop takes it from there
+    if (e->rf_stage == 2) {
+        HIPCHK(hipEventSynchronize(e->rf_event));
+        e->rf_stage = 3; e->rf_pos = 0; e->rf_carry = e->tries_carry;
+        e->rf_rows.clear(); e->rf_rows_end.clear();
+    }
+    if (e->rf_stage == 3) {
+        for (int r = e->rf_pos; r < CH; ++r) {
+            e->rf_carry++;
+            if (e->h_flags_pin[r] || e->rf_carry >= e->smp.tries_limit) {
+                e->rf_rows.insert(e->rf_rows.end(), e->h_cand_pin + (size_t)r * n, e->h_cand_pin + (size_t)r * n + n);
+                e->rf_rows_end.push_back(r + 1);
+                e->rf_carry = 0;
+            }
+        }
+        e->rf_stage = 4;
+    }
+    if (e->rf_stage == 4) {
+        e->pool.insert(e->pool.end(), e->rf_rows.begin(), e->rf_rows.end());
+        for (int off : e->rf_rows_end) e->pool_rows_end.push_back(e->gen_row + off);
+        e->tries_carry = e->rf_carry;
+        e->gen_row += CH;
+        e->rf_stage = 0;
+    }
+    return 0;
 }
 
 static int ensure_samples(lqrrt_engine* e, int64_t need_end, hipStream_t st) {
@@ -86,6 +177,8 @@ static int ensure_samples(lqrrt_engine* e, int64_t need_end, hipStream_t st) {
     std::vector<unsigned char> flags(CH);
     double tp_gen = 0, tp_gpu = 0, tp_filter = 0;
     while (e->pool_base + (int64_t)e->pool_rows_end.size() < target_end) {
+        if (e->rf_stage >= 2) { TRY(refill_take_prepared(e)); continue; }
+        if (e->rf_stage == 1) TRY(refill_take_prepared(e));
         const double ta = hostprof_on() ? now_us() : 0.0;
         // rows generated ahead while the host was waiting for repair rounds come first (same generator, same order)
         const int ahead = std::min(e->pregen_rows, CH);
@@ -129,6 +222,7 @@ extern "C" int lqrrt_engine_push_samples(lqrrt_engine* e, const double* xs_host,
     // explicit sample stream (a user xrand_gen function, planner.py:213-216): appended after what is queued
     if (!e || (count > 0 && !xs_host) || count < 0) return fail(LQRRT_E_ARG, "bad argument");
     if (!e->explicit_samples) {
+        refill_drop(e);
         e->pool.clear(); e->pool_rows_end.clear();
         e->pool_base = e->cursor; e->d_pool_count = 0; e->tries_carry = 0;
         e->explicit_samples = true;

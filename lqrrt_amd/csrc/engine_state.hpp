@@ -131,6 +131,19 @@ struct lqrrt_engine {
     int tries_carry = 0;          // tries already spent on the sample under construction
     std::vector<double> pregen;   // candidate rows generated ahead of the next refill while the host waits for the GPU
     int pregen_rows = 0;          // (they advance mt_gen exactly as the refill would; dropped whenever mt_gen is replaced)
+    // One block of candidates whose feasibility batch and filter run AHEAD of the refill that needs it, in the host's waits for the
+    // repair rounds and on a stream of its own (engine_sampler.hpp refill_ahead): the refill then finds the rows ready.
+    int rf_stage = 0;             // 0 none | 1 copying the block to pinned memory | 2 batch in flight | 3 filtering | 4 ready
+    int rf_pos = 0;               // rows copied (stage 1) / filtered (stage 3)
+    int rf_carry = 0;             // tries_carry as the block's filter leaves it
+    double* h_cand_pin = nullptr;         // pinned [SAMPLER_BLOCK][n]
+    unsigned char* h_flags_pin = nullptr; // pinned [SAMPLER_BLOCK]
+    double* d_cand2 = nullptr;
+    unsigned char* d_flags2 = nullptr;
+    hipStream_t rf_stream = nullptr;
+    hipEvent_t rf_event = nullptr;
+    std::vector<double> rf_rows;          // the block's accepted rows ...
+    std::vector<int> rf_rows_end;         // ... and the candidate row (1-based, within the block) each of them ends at
     double* d_pool_trig = nullptr; // cos/sin of their angular coordinates [count][2*nw] (k_sample_trig)
     double* d_pool = nullptr;     // device mirror of the samples [cursor_at_upload ..)
     int64_t d_pool_base = 0, d_pool_count = 0;

@@ -303,6 +303,7 @@ static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_
             const int seq_next = e->seq;
             int* word = e->h_round + 2 + 2 * (r & 1);
             pregenerate_candidates(e, 96);                    // the GPU is busy with round r (and r + 1 is queued)
+            TRY(refill_ahead(e));
             const double hw0 = hostprof_on() ? now_us() : 0.0;
             TRY(wait_word(e, st, word, seq_r));
             if (hostprof_on()) g_hp.wait += now_us() - hw0;
