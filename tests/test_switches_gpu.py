@@ -1,0 +1,56 @@
+"""Speed levers are never results: the exact-mode loop grown to 7,000 nodes of demo_boat_advanced (about 25,000 attempts, 250
+waves, 1,200 repair rounds -- long enough for several sample-pool blocks to be prepared ahead and for dozens of goal hits) gives the
+same tree, bit for bit, whatever the environment switches say.  Every setting runs in a process of its own: the switches are
+read once."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+SCRIPT = r"""
+import hashlib, sys
+sys.path.insert(0, %r)
+import numpy as np
+import lqrrt_amd
+from lqrrt_amd.engine import Engine
+s = lqrrt_amd.systems.SYSTEMS["boat_advanced"](0)
+eng = Engine(s, capacity=7000 + 1024 + 64, max_wave=1024)
+kw = s.plan_kwargs
+eng.set_resolution(kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer))
+space = np.array(s.sample_space, dtype=np.float64)
+eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), np.array(s.goal_bias, dtype=np.float64), 10)
+st = np.random.RandomState(1).get_state()
+eng.set_mt19937(st[1], st[2])
+eng.tree_reset(s.x0)
+stats = eng.extend(1024, node_limit=7000)
+h = hashlib.sha256()
+for a in (eng.states(), eng.gains(), eng.parents()):
+    h.update(np.ascontiguousarray(a).tobytes())
+print("TREE", eng.size, stats.attempts, stats.goal_hits, h.hexdigest())
+""" % ROOT
+
+
+def _run(env_extra):
+    env = dict(os.environ)
+    for k in ("LQRRT_REFILL_AHEAD", "LQRRT_IGNORE_PATCH", "LQRRT_FUSED_ROUNDS", "LQRRT_STEER_WAVEFRONTS"):
+        env.pop(k, None)
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("TREE")][-1]
+    return line
+
+
+def test_switches_do_not_change_the_tree():
+    base = _run({})
+    size, attempts, hits = (int(x) for x in base.split()[1:4])
+    assert size > 7000 and attempts > 20000 and hits > 10            # the run is long enough to go through every mechanism
+    for env in ({"LQRRT_REFILL_AHEAD": "0"}, {"LQRRT_IGNORE_PATCH": "0"}, {"LQRRT_FUSED_ROUNDS": "0"},
+                {"LQRRT_STEER_WAVEFRONTS": "3"}, {"LQRRT_REFILL_AHEAD": "0", "LQRRT_IGNORE_PATCH": "0", "LQRRT_STEER_WAVEFRONTS": "2"}):
+        assert _run(env) == base, env
