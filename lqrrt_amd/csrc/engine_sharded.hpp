@@ -226,7 +226,7 @@ extern "C" int lqrrt_engine_extend_sharded(lqrrt_engine* e, lqrrt_comm* c, int s
         if (node_limit >= 0 && (int64_t)e->N > node_limit) { acc.stop_reason = LQRRT_STOP_NODES; break; }
         if (until_size > 0 && e->N >= until_size) { acc.stop_reason = LQRRT_STOP_TARGET; break; }
         // (every rank computes the same W: the controller only looks at replicated state)
-        int W = e->sync_mode ? std::min(wave, e->maxW) : pick_wave(e, wave, false);
+        int W = e->sync_mode ? std::min(wave, e->maxW) : pick_wave(e, wave);
         int64_t cap_attempts = max_attempts >= 0 ? max_attempts - acc.attempts : (int64_t)W;
         if ((int64_t)W > cap_attempts) W = (int)cap_attempts;
         if (e->explicit_samples) {

@@ -155,7 +155,7 @@ __global__ void k_par_from_records(const double* __restrict__ rec, RecLayout L, 
     if (t < W) par_done[t] = (int)rec[(size_t)t * L.R + L.off_parent];
 }
 
-static int pick_wave(const lqrrt_engine* e, int wave_cap, bool single_engine_loop = true) {
+static int pick_wave(const lqrrt_engine* e, int wave_cap) {
     // conflicts (true parent born inside the wave) scale ~ W/N: keep W a fraction of the tree
     int W = e->N / 6;
     W = std::max(W, 8);
@@ -168,8 +168,8 @@ static int pick_wave(const lqrrt_engine* e, int wave_cap, bool single_engine_loo
     // brought -- demo_boat_novice at 5k nodes +28 %, the headline +2.6 %, nothing slower (tools/wave_cap_configs.py,
     // profiles/r03_wave_cap.txt).  LQRRT_EXACT_WAVE_MAX=1024 restores the old behaviour.
     static const int exact_max = getenv("LQRRT_EXACT_WAVE_MAX") ? atoi(getenv("LQRRT_EXACT_WAVE_MAX")) : 256;
-    // (the sharded loops keep their waves: a collective per wave is what they amortise, and nobody has measured them on 8 GPUs)
-    if (single_engine_loop && !e->sync_mode && !e->riccati && exact_max >= 8) W = std::min(W, exact_max);
+    // (the sharded loops too: their gathered waves go through the same rounds; one collective per ~130 us wave either way)
+    if (!e->sync_mode && !e->riccati && exact_max >= 8) W = std::min(W, exact_max);
     if (W >= 64) W = (W / 64) * 64;
     return W;
 }
