@@ -43,7 +43,11 @@ def test_bench_line_fields():
     assert 1500.0 < d["effective_mhz"] < 2600.0
     ck = d["steer_kernel"]["clock"]
     assert 3.5 < ck["cycles_per_dependent_fp64_fma"] < 9.0 and 1.0 < ck["ns_per_independent_fp64_fma"] < 5.0
-    assert 8 <= d["config"]["mean_wave"] <= d["config"]["wave_cap"] == 1024
+    # the cap in force (exact-mode controller: the fused rounds' 256), not the command line's upper bound
+    assert 8 <= d["config"]["mean_wave"] <= d["config"]["wave_cap"] == 256 and d["config"]["wave_cap_cli"] == 1024
+    rp = d["repeats"]
+    assert rp["regions"] == 3 and rp["min"] <= rp["median"] <= rp["max"] and rp["min"] <= d["value"] <= rp["max"]
+    assert rp["max"] < 1.5 * rp["min"]                              # back-to-back regions on one box agree
     # whatever is copied from a committed profile says so
     assert d["roofline"]["traffic"] is None or d["roofline"]["traffic_static_from"].startswith("profiles/")
 
@@ -73,3 +77,26 @@ def test_bench_config5_workload():
     assert d["value"] > 1e4 and d["cpu_baseline"]["c_oracle_value"] > 0
     d = _run(["--workload", "cfg5", "--units", "4", "--no-cpu", "--no-extras"], env={"LQRRT_FORCE_SHARDED": "1"})
     assert d["value"] > 1e4
+
+
+def test_bench_gpus_2_spawns_its_own_ranks_or_fails_loudly():
+    """`python bench.py --gpus 2` without a launcher (the form of the driver's N = 1 command): two ranks over RCCL when the box has
+    two devices, otherwise a non-zero exit that says why -- never an N = 1 line under an N = 2 command."""
+    import torch
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--units", "16"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    if torch.cuda.device_count() >= 2:
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+        assert d["n_gpus"] == 2 and "x2" in d["config"]["parallelism"] and d["value"] > 1e4
+    else:
+        assert out.returncode != 0
+        assert "--gpus 2" in out.stderr and "only 1 HIP device" in out.stderr
+        assert not any(l.lstrip().startswith("{") for l in out.stdout.splitlines())
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu"], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
