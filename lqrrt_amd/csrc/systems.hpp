@@ -257,27 +257,46 @@ __device__ __forceinline__ bool hull_hits(const GeoL& g, double px, double py, d
 
 struct BoatCommon {
     static constexpr int N = 6, M = 3, NW = 1;
-    __host__ __device__ static constexpr int wd(int) { return 2; }
+    __host__ __device__ __forceinline__ static constexpr int wd(int) { return 2; }
 
     // K = [kp R(h)' | kd] with diagonal kp, kd (demo_boat_advanced.py:139-151)
-    __device__ static void gain_pd(const double* kp, const double* kd, const double* trig, double* K) {
+    __device__ __forceinline__ static void gain_pd(const double* kp, const double* kd, const double* trig, double* K) {
         const double c = trig[0], s = trig[1];
         K[0] = kp[0] * c;    K[1] = kp[0] * s;  K[2] = kp[0] * 0.0;  K[3] = kd[0]; K[4] = 0.0;   K[5] = 0.0;
         K[6] = kp[1] * (-s); K[7] = kp[1] * c;  K[8] = kp[1] * 0.0;  K[9] = 0.0;   K[10] = kd[1]; K[11] = 0.0;
         K[12] = kp[2] * 0.0; K[13] = kp[2] * 0.0; K[14] = kp[2] * 1.0; K[15] = 0.0; K[16] = 0.0;  K[17] = kd[2];
     }
 
-    // "Heading controller trying to keep us car-like" (demo_boat_advanced.py:101-108)
-    __device__ static double rudder_term(double gainv, const double* x, double c, double s) {
-#ifdef ABL_NORUDDER
-        return 0.0;
-#endif
+    // "Heading controller trying to keep us car-like" (demo_boat_advanced.py:101-108): gain * wrap(atan2(R v) - h).  The angle
+    // between the world-frame velocity R(h) v and the heading h IS the direction of the body-frame velocity v, so for a boat that
+    // moves forward faster than vmin the torque is gain * atan2(v_y, v_x): ONE elementary function on the rollout's only true
+    // dependency chain (x_k -> torque -> x_k+1) instead of the reference's atan2 -> sincos -> atan2.  The two forms differ by
+    // rounding only; the contract is "topology exact, states within tolerance", and the REFERENCE's fixtures judge it
+    // (tests/test_teacher_gpu.py: every decision and edge length of the 10k-node run exact, end states as close as before) --
+    // not the C oracle, which follows this rule in lockstep (oracle/lqrrt_oracle.c rudder_term) to stay the bit-for-bit net.
+    // The reference's own sequence is kept where the problem is ill-conditioned or the short form is another function:
+    //   |v|^2 <= vmin2  a nearly stopped boat turns a velocity difference dv into a torque difference ~ gain dv / |v|
+    //   v_x < 0         only a seed state can have it (the planning dynamics clamp it away); near v_y = 0 the forms may take
+    //                   different sides of the +-pi cut
+    //   v = 0           atan2 of signed zeros, where the reference's form gives wrap(-h).
+    // vmin2 is a parameter of the system (lqrrt_amd.systems.*.torque_vmin, default 0.01 m/s; inf: the reference's sequence always).
+    __device__ __forceinline__ static bool torque_direct(double vmin2, const double* x) {
+        return x[3] >= 0.0 && x[3] * x[3] + x[4] * x[4] > vmin2;
+    }
+    __device__ __forceinline__ static double rudder_ref(double gainv, const double* x, double c, double s) {
         const double vw0 = c * x[3] + (-s) * x[4];
         const double vw1 = s * x[3] + c * x[4];
         const double ang = lq_atan2(vw1, vw0);
         double cg, sg;
         lq_sincos(ang, &sg, &cg);
         return gainv * wrap_err(cg, sg, c, s);
+    }
+    __device__ __forceinline__ static double rudder_term(double gainv, double vmin2, const double* x, double c, double s) {
+#ifdef ABL_NORUDDER
+        return 0.0;
+#endif
+        if (torque_direct(vmin2, x)) return gainv * lq_atan2(x[4], x[3]);
+        return rudder_ref(gainv, x, c, s);
     }
 
     // One rollout step evaluates five elementary functions on the critical path: the heading error of erf
@@ -291,8 +310,10 @@ struct BoatCommon {
     //   out: e2 = erf heading component, rud = gain * heading error of the direction, trn = trig(h')
     //   (yb, xb) = arguments of the direction atan2: the world-frame velocity (rudder_term) or, for the ROS
     //   "stare at a point" behaviour, the vector to the focus point.
-    __device__ static void packed_heading(double gainv, const double* ttrig, const double* x, const double* trig,
-                                          double dt, int lane, double yb, double xb, double& e2, double& rud, double* trn) {
+    //   direct: the heading torque is gainv * atan2(x[4], x[3]) (torque_direct above; wave-uniform): then the erf atan2 and the
+    //   torque atan2 share the lanes and only the next heading's sine/cosine is left -- 1 + 1 elementary functions.
+    __device__ __forceinline__ static void packed_heading(double gainv, const double* ttrig, const double* x, const double* trig,
+                                          double dt, int lane, double yb, double xb, bool direct, double& e2, double& rud, double* trn) {
         const bool odd = (lane & 1) != 0;
         const double c = trig[0], s = trig[1];
         const double ya = ttrig[1] * c - ttrig[0] * s, xa = ttrig[0] * c + ttrig[1] * s;     // wrap_err(target, x)
@@ -302,10 +323,17 @@ struct BoatCommon {
 #ifdef ABL_NOTRIG
         e2 = ya; rud = yb * 1e-3; trn[1] = s; trn[0] = c; return;
 #endif
+        const double hn = x[2] + x[5] * dt;                      // euler(): xn[2] = x[2] + xdot[2]*dt, xdot[2] = x[5]
+        if (__builtin_amdgcn_readfirstlane((int)direct)) {
+            const double a = lq_atan2(odd ? x[4] : ya, odd ? x[3] : xa);
+            e2 = quad_bcast<0>(a);
+            rud = gainv * quad_bcast<1>(a);
+            lq_sincos(hn, &trn[1], &trn[0]);
+            return;
+        }
         const double a = lq_atan2(odd ? yb : ya, odd ? xb : xa);
         e2 = quad_bcast<0>(a);
         const double ang = quad_bcast<1>(a);
-        const double hn = x[2] + x[5] * dt;                      // euler(): xn[2] = x[2] + xdot[2]*dt, xdot[2] = x[5]
         double sn, cs;
         lq_sincos(odd ? hn : ang, &sn, &cs);
         const double sg = quad_bcast<0>(sn), cg = quad_bcast<0>(cs);
@@ -315,11 +343,11 @@ struct BoatCommon {
     }
 
     // erf and u = K e around packed_heading (planner.py:386-387 in the order of the sequential code)
-    __device__ static void packed_erf_effort(double gainv, const double* xt, const double* ttrig, const double* x,
+    __device__ __forceinline__ static void packed_erf_effort(double gainv, const double* xt, const double* ttrig, const double* x,
                                              const double* trig, const double* K, double dt, int lane, double yb, double xb,
-                                             double* e, double* u, double& rud, double* trn) {
+                                             bool direct, double* e, double* u, double& rud, double* trn) {
         double e2;
-        packed_heading(gainv, ttrig, x, trig, dt, lane, yb, xb, e2, rud, trn);
+        packed_heading(gainv, ttrig, x, trig, dt, lane, yb, xb, direct, e2, rud, trn);
 #pragma unroll
         for (int d = 0; d < 6; ++d) e[d] = xt[d] - x[d];
         e[2] = e2;
@@ -338,7 +366,7 @@ struct BoatCommon {
     // Each piece performs exactly the arithmetic of the sequential code on the same arguments: bits unchanged.
     // Main wavefront, while the helper works on the heading torque: erf (planner.py:386), u = K e (:387) and the
     // cos/sin of the next heading (h' = h + vh dt only needs the old state).
-    __device__ static void duo_effort(const double* xt, const double* ttrig, const double* x, const double* trig,
+    __device__ __forceinline__ static void duo_effort(const double* xt, const double* ttrig, const double* x, const double* trig,
                                       const double* K, double dt, double* e, double* u, double* trn) {
         const double c = trig[0], s = trig[1];
 #pragma unroll
@@ -354,7 +382,7 @@ struct BoatCommon {
         lq_sincos(x[2] + x[5] * dt, &trn[1], &trn[0]);           // euler(): xn[2] = x[2] + xdot[2]*dt, xdot[2] = x[5]
     }
     // (three wavefronts: the same without the cos/sin, which the checking wavefront provides)
-    __device__ static void trio_effort(const double* xt, const double* ttrig, const double* x, const double* trig,
+    __device__ __forceinline__ static void trio_effort(const double* xt, const double* ttrig, const double* x, const double* trig,
                                        const double* K, double* e, double* u) {
         const double c = trig[0], s = trig[1];
 #pragma unroll
@@ -369,7 +397,7 @@ struct BoatCommon {
         }
     }
     // (four wavefronts: the angle error arrives too)
-    __device__ static void quad_effort(const double* xt, const double* x, const double* K, double e2, double* e, double* u) {
+    __device__ __forceinline__ static void quad_effort(const double* xt, const double* x, const double* K, double e2, double* e, double* u) {
 #pragma unroll
         for (int d = 0; d < 6; ++d) e[d] = xt[d] - x[d];
         e[2] = e2;
@@ -382,7 +410,7 @@ struct BoatCommon {
         }
     }
     // Helper wavefront: gain * heading error of the direction (yb, xb) -- atan2, sincos, atan2 in a row
-    __device__ static double duo_rudder(double gainv, double yb, double xb, double c, double s) {
+    __device__ __forceinline__ static double duo_rudder(double gainv, double yb, double xb, double c, double s) {
         const double ang = lq_atan2(yb, xb);
         double cg, sg;
         lq_sincos(ang, &sg, &cg);
@@ -390,7 +418,7 @@ struct BoatCommon {
     }
 
     // xdot = [R v ; invM*(u - D*v)], xnext = x + xdot*dt  (demo_boat_advanced.py:114-117)
-    __device__ static void euler(const double* invM, const double* Dpos, const double* Dneg,
+    __device__ __forceinline__ static void euler(const double* invM, const double* Dpos, const double* Dneg,
                                  const double* x, double c, double s, const double* u, double dt, double* xn) {
         double xdot[6];
         xdot[0] = c * x[3] + (-s) * x[4];
@@ -407,7 +435,7 @@ struct BoatCommon {
     }
 
     // "not turning in place" + "not driving backwards" (demo_boat_advanced.py:120-128)
-    __device__ static void carlike(const double* x, double vpos0, double vneg0, double* xn) {
+    __device__ __forceinline__ static void carlike(const double* x, double vpos0, double vneg0, double* xn) {
         if (x[3] > 0.0)      xn[5] = clipd(fabs(xn[3] / vpos0), 0.0, 1.0) * xn[5];
         else if (x[3] < 0.0) xn[5] = clipd(fabs(xn[3] / vneg0), 0.0, 1.0) * xn[5];
         if (xn[3] < 0.0) xn[3] = 0.0;
@@ -417,34 +445,32 @@ struct BoatCommon {
 struct BoatAdvanced : BoatCommon {
     // params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 B[3][4] | 21 invB[4][3] | 33 thrust_max[4]
     //         37 rudder | 38 velmax_pos0 | 39 velmax_neg0 | 40 kp[3] | 43 kd[3]
-    //         46 velmax_pos_plan[3] | 49 velmax_neg_plan[3]
-    __device__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
+    //         46 velmax_pos_plan[3] | 49 velmax_neg_plan[3] | 52 torque_vmin^2 (rudder_term)
+    __device__ __forceinline__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
         gain_pd(P + 40, P + 43, trig, K);
     }
     static constexpr bool PACKED = true;
-    __device__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
-        u[2] = u[2] + rudder_term(P[37], x, trig[0], trig[1]);
+    static constexpr int NP = 53;                    // parameters in use (k_steer's chain rollout keeps them in registers)
+    __device__ __forceinline__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+        u[2] = u[2] + rudder_term(P[37], P[52], x, trig[0], trig[1]);
         thrust_and_integrate(P, x, trig, u, dt, xn);
     }
     // erf + u = K e + step + trig of the new state with the elementary functions packed across lanes
-    __device__ static void step_packed(const double* P, const double* xt, const double* ttrig, const double* x,
+    __device__ __forceinline__ static void step_packed(const double* P, const double* xt, const double* ttrig, const double* x,
                                        const double* trig, const double* K, double dt, int lane,
                                        double* e, double* u, double* xn, double* trn) {
         const double c = trig[0], s = trig[1];
         const double vw0 = c * x[3] + (-s) * x[4];
         const double vw1 = s * x[3] + c * x[4];
         double rud;
-        packed_erf_effort(P[37], xt, ttrig, x, trig, K, dt, lane, vw1, vw0, e, u, rud, trn);
+        packed_erf_effort(P[37], xt, ttrig, x, trig, K, dt, lane, vw1, vw0, torque_direct(P[52], x), e, u, rud, trn);
         double uc[3] = {u[0], u[1], u[2] + rud};
         thrust_and_integrate(P, x, trig, uc, dt, xn);
     }
-    __device__ static double duo_chain(const double* P, const double* x, const double* trig) {
-        const double c = trig[0], s = trig[1];
-        const double vw0 = c * x[3] + (-s) * x[4];
-        const double vw1 = s * x[3] + c * x[4];
-        return duo_rudder(P[37], vw1, vw0, c, s);
+    __device__ __forceinline__ static double duo_chain(const double* P, const double* x, const double* trig) {
+        return rudder_term(P[37], P[52], x, trig[0], trig[1]);
     }
-    __device__ static void duo_finish(const double* P, const double* x, const double* trig, const double* u, double rud, double dt, double* xn) {
+    __device__ __forceinline__ static void duo_finish(const double* P, const double* x, const double* trig, const double* u, double rud, double dt, double* xn) {
         double uc[3] = {u[0], u[1], u[2] + rud};
         thrust_and_integrate(P, x, trig, uc, dt, xn);
     }
@@ -452,7 +478,7 @@ struct BoatAdvanced : BoatCommon {
     // (the first two terms of invB.u, drag, the position update, the constants) while the torque wavefront is still
     // busy, the rest after it.  Same operations in the same order as thrust_and_integrate / euler / carlike.
     static constexpr bool TRIO_SPLIT = true;
-    struct TrioPre { double ta[4], b2[4], tmax[4], Bm[12], Dv[3], invM[3], xn012[3], vp, vn; };
+    struct TrioPre { double ta[4], b2[4], tmax[4], Bm[12], Dv[3], invM[3], xn012[3], vp, vn, Dp[3], Dn[3]; };
     __device__ __forceinline__ static void trio_pre(const double* P, const double* x, const double* trig, const double* u, double dt, TrioPre& q) {
         const double c = trig[0], s = trig[1];
 #pragma unroll
@@ -476,16 +502,43 @@ struct BoatAdvanced : BoatCommon {
         }
         q.vp = P[38]; q.vn = P[39];
     }
-    // the members of TrioPre that do not depend on the step (chain-owner rollout: the torque wavefront keeps them in registers
-    // and gets ta / Dv / xn012 of each step from the main wavefront)
+    // the members of TrioPre that do not depend on the step (chain-owner rollout: the torque wavefront keeps them in registers,
+    // computes Dv / xn012 of each step itself -- they only need the state it owns -- and gets ta and u2 from the main wavefront)
     __device__ __forceinline__ static void trio_consts(const double* P, TrioPre& q) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { q.b2[j] = P[21 + 3 * j + 2]; q.tmax[j] = P[33 + j]; }
 #pragma unroll
         for (int i = 0; i < 12; ++i) q.Bm[i] = P[9 + i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) q.invM[i] = P[i];
+        for (int i = 0; i < 3; ++i) { q.invM[i] = P[i]; q.Dp[i] = P[3 + i]; q.Dn[i] = P[6 + i]; }
         q.vp = P[38]; q.vn = P[39];
+    }
+    // trio_pre's torque- and effort-free part: drag products and the position update of step k (same operations, same order)
+    __device__ __forceinline__ static void trio_state(TrioPre& q, const double* x, double c, double s, double dt) {
+        double xdot[3];
+        xdot[0] = c * x[3] + (-s) * x[4];
+        xdot[1] = s * x[3] + c * x[4];
+        xdot[2] = x[5];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            q.xn012[i] = x[i] + xdot[i] * dt;
+            const double v = x[3 + i];
+            const double D = (v >= 0.0) ? q.Dp[i] : q.Dn[i];
+            q.Dv[i] = D * v;
+        }
+    }
+    // trio_pre's effort part: the first two terms of invB.u (ib = invB[j][0], invB[j][1] for j = 0..3, kept in registers)
+    __device__ __forceinline__ static void trio_ib(const double* P, double* ib) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ib[2 * j] = P[21 + 3 * j]; ib[2 * j + 1] = P[21 + 3 * j + 1]; }
+    }
+    __device__ __forceinline__ static void trio_ta(const double* ib, const double* u, double* ta) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double a = ib[2 * j] * u[0];
+            a += ib[2 * j + 1] * u[1];
+            ta[j] = a;
+        }
     }
     __device__ __forceinline__ static void trio_post(const TrioPre& q, const double* x, const double* u, double rud, double dt, double* xn) {
         const double u2 = u[2] + rud;
@@ -508,7 +561,7 @@ struct BoatAdvanced : BoatCommon {
         }
         carlike(x, q.vp, q.vn, xn);
     }
-    __device__ static void thrust_and_integrate(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+    __device__ __forceinline__ static void thrust_and_integrate(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
         const double c = trig[0], s = trig[1];
         // u = B.dot(clip(invB.dot(u), -thrust_max, thrust_max))   (demo_boat_advanced.py:111)
         double t[4];
@@ -531,7 +584,7 @@ struct BoatAdvanced : BoatCommon {
         euler(P + 0, P + 3, P + 6, x, c, s, us, dt, xn);
         carlike(x, P[38], P[39], xn);
     }
-    __device__ static bool feasible(const double* P, const Geo& g, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
+    __device__ __forceinline__ static bool feasible(const double* P, const Geo& g, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
         // planning speed box first (demo_boat_advanced.py:211-213)
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -543,44 +596,42 @@ struct BoatAdvanced : BoatCommon {
 
 struct BoatIntermediate : BoatCommon {
     // params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 u_max[3] | 12 rudder | 13 velmax_pos0
-    //         14 velmax_neg0 | 15 kp[3] | 18 kd[3]
-    __device__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
+    //         14 velmax_neg0 | 15 kp[3] | 18 kd[3] | 21 torque_vmin^2 (rudder_term)
+    __device__ __forceinline__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
         gain_pd(P + 15, P + 18, trig, K);
     }
     static constexpr bool PACKED = true;
-    __device__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
-        u[2] = u[2] + rudder_term(P[12], x, trig[0], trig[1]);
+    static constexpr int NP = 22;
+    __device__ __forceinline__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+        u[2] = u[2] + rudder_term(P[12], P[21], x, trig[0], trig[1]);
         saturate_and_integrate(P, x, trig, u, dt, xn);
     }
-    __device__ static void step_packed(const double* P, const double* xt, const double* ttrig, const double* x,
+    __device__ __forceinline__ static void step_packed(const double* P, const double* xt, const double* ttrig, const double* x,
                                        const double* trig, const double* K, double dt, int lane,
                                        double* e, double* u, double* xn, double* trn) {
         const double c = trig[0], s = trig[1];
         const double vw0 = c * x[3] + (-s) * x[4];
         const double vw1 = s * x[3] + c * x[4];
         double rud;
-        packed_erf_effort(P[12], xt, ttrig, x, trig, K, dt, lane, vw1, vw0, e, u, rud, trn);
+        packed_erf_effort(P[12], xt, ttrig, x, trig, K, dt, lane, vw1, vw0, torque_direct(P[21], x), e, u, rud, trn);
         double uc[3] = {u[0], u[1], u[2] + rud};
         saturate_and_integrate(P, x, trig, uc, dt, xn);
     }
-    __device__ static double duo_chain(const double* P, const double* x, const double* trig) {
-        const double c = trig[0], s = trig[1];
-        const double vw0 = c * x[3] + (-s) * x[4];
-        const double vw1 = s * x[3] + c * x[4];
-        return duo_rudder(P[12], vw1, vw0, c, s);
+    __device__ __forceinline__ static double duo_chain(const double* P, const double* x, const double* trig) {
+        return rudder_term(P[12], P[21], x, trig[0], trig[1]);
     }
-    __device__ static void duo_finish(const double* P, const double* x, const double* trig, const double* u, double rud, double dt, double* xn) {
+    __device__ __forceinline__ static void duo_finish(const double* P, const double* x, const double* trig, const double* u, double rud, double dt, double* xn) {
         double uc[3] = {u[0], u[1], u[2] + rud};
         saturate_and_integrate(P, x, trig, uc, dt, xn);
     }
-    __device__ static void saturate_and_integrate(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+    __device__ __forceinline__ static void saturate_and_integrate(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)          // per-axis saturation (demo_boat_intermediate.py:74-77)
             if (fabs(u[i]) > P[9 + i]) u[i] = P[9 + i] * (u[i] > 0.0 ? 1.0 : -1.0);
         euler(P + 0, P + 3, P + 6, x, trig[0], trig[1], u, dt, xn);
         carlike(x, P[13], P[14], xn);
     }
-    __device__ static bool feasible(const double*, const Geo& g, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
+    __device__ __forceinline__ static bool feasible(const double*, const Geo& g, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
         if (g.og) return !grid_hits(g, gl, x[0], x[1], trig[0], trig[1], lane);
         return !hull_hits(gl, x[0], x[1], trig[0], trig[1], false, lane);
     }
@@ -616,12 +667,13 @@ struct RosBoat : BoatCommon {
     // params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 B[3][4] | 21 invB[4][3] | 33 thrust_max[4] | 37 rudder gain
     //         38 rudder mode (0 none, 1 stare at focus point: boat.py:34-42, 2 along the velocity: car.py:36-43)
     //         39 focus[2] | 41 saturation (0 even downscaling: boat.py:44-48, 1 per-thruster clip: car.py:46)
-    //         42 no-reverse rule (car.py:54-56) | 43 kp[3] | 46 kd[3]
-    __device__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
+    //         42 no-reverse rule (car.py:54-56) | 43 kp[3] | 46 kd[3] | 49 torque_vmin^2 (rudder_term, mode 2)
+    __device__ __forceinline__ static void gain(const double* P, const double*, const double* trig, const double*, double* K) {
         gain_pd(P + 43, P + 46, trig, K);
     }
     static constexpr bool PACKED = true;
-    __device__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+    static constexpr int NP = 50;
+    __device__ __forceinline__ static void step(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
         const double c = trig[0], s = trig[1];
         const int rmode = (int)P[38];
         if (rmode == 1) {            // u[2] is REPLACED, not incremented (boat.py:42)
@@ -630,11 +682,11 @@ struct RosBoat : BoatCommon {
             lq_sincos(ang, &sg, &cg);
             u[2] = P[37] * wrap_err(cg, sg, c, s);
         } else if (rmode == 2) {     // car.py:43
-            u[2] = rudder_term(P[37], x, c, s);
+            u[2] = rudder_term(P[37], P[49], x, c, s);
         }
         thrust_and_integrate(P, x, trig, u, dt, xn);
     }
-    __device__ static void step_packed(const double* P, const double* xt, const double* ttrig, const double* x,
+    __device__ __forceinline__ static void step_packed(const double* P, const double* xt, const double* ttrig, const double* x,
                                        const double* trig, const double* K, double dt, int lane,
                                        double* e, double* u, double* xn, double* trn) {
         const int rmode = (int)P[38];
@@ -659,24 +711,24 @@ struct RosBoat : BoatCommon {
         if (rmode == 1) { yb = P[40] - x[1]; xb = P[39] - x[0]; }
         else { xb = c * x[3] + (-s) * x[4]; yb = s * x[3] + c * x[4]; }
         double rud;
-        packed_erf_effort(P[37], xt, ttrig, x, trig, K, dt, lane, yb, xb, e, u, rud, trn);
+        packed_erf_effort(P[37], xt, ttrig, x, trig, K, dt, lane, yb, xb, rmode == 2 && torque_direct(P[49], x), e, u, rud, trn);
         double uc[3] = {u[0], u[1], rud};           // both behaviours REPLACE the yaw effort (boat.py:42, car.py:43)
         thrust_and_integrate(P, x, trig, uc, dt, xn);
     }
-    __device__ static double duo_chain(const double* P, const double* x, const double* trig) {
+    __device__ __forceinline__ static double duo_chain(const double* P, const double* x, const double* trig) {
         const int rmode = (int)P[38];
         if (rmode == 0) return 0.0;                 // no heading term
         const double c = trig[0], s = trig[1];
         double yb, xb;
-        if (rmode == 1) { yb = P[40] - x[1]; xb = P[39] - x[0]; }
-        else { xb = c * x[3] + (-s) * x[4]; yb = s * x[3] + c * x[4]; }
+        if (rmode == 2) return rudder_term(P[37], P[49], x, c, s);
+        yb = P[40] - x[1]; xb = P[39] - x[0];
         return duo_rudder(P[37], yb, xb, c, s);
     }
-    __device__ static void duo_finish(const double* P, const double* x, const double* trig, const double* u, double rud, double dt, double* xn) {
+    __device__ __forceinline__ static void duo_finish(const double* P, const double* x, const double* trig, const double* u, double rud, double dt, double* xn) {
         double uc[3] = {u[0], u[1], (int)P[38] == 0 ? u[2] : rud};
         thrust_and_integrate(P, x, trig, uc, dt, xn);
     }
-    __device__ static void thrust_and_integrate(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
+    __device__ __forceinline__ static void thrust_and_integrate(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
         const double c = trig[0], s = trig[1];
         double t[4];
 #pragma unroll
@@ -721,7 +773,7 @@ struct RosBoat : BoatCommon {
         euler(P + 0, P + 3, P + 6, x, c, s, us, dt, xn);
         if ((int)P[42] && xn[3] < 0.0) xn[3] = fabs(x[3]);
     }
-    __device__ static bool feasible(const double*, const Geo& g, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
+    __device__ __forceinline__ static bool feasible(const double*, const Geo& g, const GeoL& gl, const double* x, const double*, const double* trig, int lane) {
         if (g.og) return !grid_hits(g, gl, x[0], x[1], trig[0], trig[1], lane);   // lqrrt_node.py:719-745
         if (g.O == 0) return true;                                            // no map yet: anywhere is valid (:726-727)
         return !hull_hits(gl, x[0], x[1], trig[0], trig[1], false, lane);

@@ -27,6 +27,7 @@ problem, a *system object* that
   DoubleIntegrator  BASELINE.json config 5 (not in the reference)
 """
 import ctypes as C
+import os
 
 import numpy as np
 import numpy.linalg as npl
@@ -64,6 +65,11 @@ def obstacle_grid(seed, goal, x0, clearance, spacing=12, lo=5, hi=60):
 
 
 # --------------------------------------------------------------------------- plugin handles
+
+# Speed (m/s) above which the boats' heading torque is evaluated in its one-atan2 form (csrc/systems.hpp rudder_term); the
+# environment variable is a measurement lever (A/B of the threshold on one box), the attribute `torque_vmin` of a system the API.
+_TORQUE_VMIN = float(os.environ.get("LQRRT_TORQUE_VMIN", "0.01"))
+
 
 class _Plugin(object):
     """A callable bound to a native system; `kind` in dynamics|lqr|erf|is_feasible."""
@@ -219,8 +225,13 @@ class BoatAdvanced(_Boat):
     4-thruster boat with per-thruster saturation and a planning speed box.
     params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 B[3][4] | 21 invB[4][3] | 33 thrust_max[4] |
             37 rudder | 38 velmax_pos0 | 39 velmax_neg0 | 40 kp[3] | 43 kd[3] |
-            46 velmax_pos_plan[3] | 49 velmax_neg_plan[3]
+            46 velmax_pos_plan[3] | 49 velmax_neg_plan[3] | 52 torque_vmin^2
+    `torque_vmin` (m/s, default 0.01): above this speed the heading torque of demo_boat_advanced.py:101-108,
+    rudder * wrap(atan2(R v) - h), is evaluated as rudder * atan2(v_y, v_x) of the body-frame velocity (the same angle, one
+    elementary function instead of three); at or below it -- where the dynamics amplify rounding differences -- and for
+    v_x < 0 the reference's own sequence runs.  np.inf: the reference's sequence everywhere (csrc/systems.hpp rudder_term).
     """
+    torque_vmin = _TORQUE_VMIN
     model = nat.MODEL_BOAT_ADVANCED
     plan_kwargs = dict(horizon=2, dt=0.1, FPR=0.9)          # demo_boat_advanced.py:245-249
 
@@ -261,15 +272,17 @@ class BoatAdvanced(_Boat):
     def params(self):
         return np.concatenate((self.invM, self.D_pos, self.D_neg, self.B.ravel(), self.invB.ravel(),
                                self.thrust_max, [self.magic_rudder, self.velmax_pos[0], self.velmax_neg[0]],
-                               np.diag(self.kp), np.diag(self.kd), self.velmax_pos_plan, self.velmax_neg_plan))
+                               np.diag(self.kp), np.diag(self.kd), self.velmax_pos_plan, self.velmax_neg_plan,
+                               [self.torque_vmin ** 2]))
 
 
 class BoatIntermediate(_Boat):
     """
     Wrench-saturated boat with the heading "rudder" and a dense hull grid.
     params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 u_max[3] | 12 rudder | 13 velmax_pos0 |
-            14 velmax_neg0 | 15 kp[3] | 18 kd[3]
+            14 velmax_neg0 | 15 kp[3] | 18 kd[3] | 21 torque_vmin^2 (see BoatAdvanced)
     """
+    torque_vmin = _TORQUE_VMIN
     model = nat.MODEL_BOAT_INTERMEDIATE
     plan_kwargs = dict(horizon=2, dt=0.1, FPR=0.5)          # demo_boat_intermediate.py:228-232
 
@@ -300,7 +313,7 @@ class BoatIntermediate(_Boat):
     def params(self):
         return np.concatenate((self.invM, self.D_pos, self.D_neg, self.u_max,
                                [self.rudder, self.velmax_pos[0], self.velmax_neg[0]],
-                               np.diag(self.kp), np.diag(self.kd)))
+                               np.diag(self.kp), np.diag(self.kd), [self.torque_vmin ** 2]))
 
 
 class BoatNovice(_Boat):
@@ -348,8 +361,10 @@ class RosBoat(_Boat):
     They are meant to be planned with horizon=(0.1, 3) (adaptive-horizon heuristic) and FPR=0, and with the
     occupancy-grid feasibility of the node (set_occupancy_grid); without a map everything is feasible.
     params: 0 invM[3] | 3 D_pos[3] | 6 D_neg[3] | 9 B[3][4] | 21 invB[4][3] | 33 thrust_max[4] | 37 rudder |
-            38 rudder mode | 39 focus[2] | 41 saturation mode | 42 no-reverse | 43 kp[3] | 46 kd[3]
+            38 rudder mode | 39 focus[2] | 41 saturation mode | 42 no-reverse | 43 kp[3] | 46 kd[3] |
+            49 torque_vmin^2 ('car' behaviour: see BoatAdvanced)
     """
+    torque_vmin = _TORQUE_VMIN
     model = nat.MODEL_ROS_BOAT
     plan_kwargs = dict(horizon=(0.1, 3), dt=0.1, FPR=0)     # behaviors/params.py:31-33
 
@@ -420,7 +435,7 @@ class RosBoat(_Boat):
         focus = self.focus[:2] if self.focus is not None else [0.0, 0.0]
         return np.concatenate((self.invM, self.D_pos, self.D_neg, self.B.ravel(), self.invB.ravel(), self.thrust_max,
                                [self.rudder, self.rudder_mode], focus, [self.sat_mode, self.no_reverse],
-                               np.diag(self.kp), np.diag(self.kd)))
+                               np.diag(self.kp), np.diag(self.kd), [self.torque_vmin ** 2]))
 
 
 # --------------------------------------------------------------------------- car

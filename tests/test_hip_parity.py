@@ -13,8 +13,10 @@ demo_boat_advanced is the exception that needs a weaker statement: its dynamics 
 differences by orders of magnitude per step when the boat is nearly stopped with saturated
 thrusters (DESIGN.md "Conditioning"), so NO implementation with a different libm reproduces the
 reference run beyond the first such edge -- NumPy itself differs between CPUs.  For that problem
-the FREE-RUNNING fixtures pin the tree up to the first chaotic divergence (parents exact for the 200-node
-fixture, >= 150 nodes of common prefix on the longer ones, unaffected nodes to 1e-9); the full-size claim
+the FREE-RUNNING fixtures are only a conditioning smoke test (>= 150 nodes of common prefix with the reference's
+run, unaffected nodes to 1e-9; since round 4 the heading torque of a moving boat is one atan2 instead of the
+reference's atan2 -> sincos -> atan2, csrc/systems.hpp rudder_term, and the first ulp-triggered divergence of the
+free run moved from decision 1381 to decision 1264 of the 200-node fixture, node 152); the full-size claim
 against the reference itself is teacher-forced -- every one of the 36,936 decisions of the reference's
 10k-node run replayed from the reference's own tree (tests/test_teacher_gpu.py) -- and the bit-exact
 comparison against the sequential C oracle (tests/test_hip_vs_coracle.py, same portable libm) covers the
@@ -103,9 +105,12 @@ TRAJ = [("boat_intermediate", "300", 256), ("boat_novice", "300", 256), ("car", 
         ("car", "guide", 64), ("boat_intermediate", "guide", 16)]
 
 
-@pytest.mark.parametrize("tag,wave,min_prefix", [("200", 64, 201), ("200", 1024, 201), ("3000", 1024, 150), ("10k", 1024, 150)])
-def test_boat_advanced_golden_prefix(golden_dir, tag, wave, min_prefix):
-    """Chaotic problem: agreement with the reference run up to the first ulp-triggered divergence."""
+@pytest.mark.parametrize("tag,wave,min_prefix", [("200", 64, 150), ("200", 1024, 150), ("3000", 1024, 150), ("10k", 1024, 150)])
+def test_boat_advanced_free_run_conditioning_smoke(golden_dir, tag, wave, min_prefix):
+    """NOT parity evidence -- a conditioning smoke test.  Chaotic problem: the free run agrees with the reference's run up to
+    the first ulp-triggered divergence and the test only asks that this is not earlier than node 150.  The parity statement
+    for this problem is teacher forcing (tests/test_teacher_gpu.py: every decision of the reference replayed from the
+    reference's own tree) plus bit-equality with the sequential C oracle (tests/test_hip_vs_coracle.py)."""
     g = _load(golden_dir, "traj_boat_advanced_%s.npz" % tag)
     s = _system("boat_advanced")
     p = _planner(s, int(g["max_nodes"]), wave_size=wave)
@@ -123,6 +128,24 @@ def test_boat_advanced_golden_prefix(golden_dir, tag, wave, min_prefix):
         assert p.stats["attempts"] == int(g["iterations"])
         assert p.stats["candidates"] == int(g["n_candidates"])
         assert np.mean(p._engine.edge_lengths() == g["edge_len"]) > 0.98
+
+
+@pytest.mark.parametrize("wave", [64, 1024])
+def test_boat_advanced_reference_torque_sequence_reproduces_the_200_node_run(golden_dir, wave):
+    """torque_vmin = inf: the reference's atan2 -> sincos -> atan2 at every speed.  The free run then still reproduces the whole
+    parent array of the reference's 200-node run, as it did before the one-atan2 form existed -- so what the default changes on
+    this fixture is rounding (where the first ulp-triggered divergence falls), not the function."""
+    g = _load(golden_dir, "traj_boat_advanced_200.npz")
+    s = _system("boat_advanced")
+    s.torque_vmin = np.inf
+    p = _planner(s, int(g["max_nodes"]), wave_size=wave)
+    np.random.seed(1)
+    assert p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10) is False
+    np.testing.assert_array_equal(np.array(p.tree.pID, dtype=np.int32), g["pID"])
+    assert p.stats["attempts"] == int(g["iterations"]) and p.stats["candidates"] == int(g["n_candidates"])
+    err = np.abs(p.tree.state - g["state"]).max(axis=1)
+    assert np.median(err) < 1e-12 and np.mean(err < ATOL) > 0.8
+    assert np.mean(p._engine.edge_lengths() == g["edge_len"]) > 0.98
 
 
 @pytest.mark.parametrize("name,tag,wave", TRAJ)
