@@ -33,6 +33,20 @@
 #define LQ_HD static inline
 #endif
 
+/* One Horner step p*w + c with a single rounding.  On the host this is the C standard's fma().  On gfx950 it is the same
+ * operation (v_fma_f64 is the IEEE-754 fusedMultiplyAdd), spelled out: left to itself the compiler emits the two-address form,
+ * v_mov_b64 tmp, c ; v_fmac_f64 tmp, p, w -- one extra instruction per coefficient, on a wavefront whose speed IS its
+ * instruction count (one instruction per ~6 cycles whatever it is). */
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ double lq_fma(double p, double w, double c) {
+    double r;
+    __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(w), "v"(c));
+    return r;
+}
+#else
+#define lq_fma(p, w, c) fma((p), (w), (c))
+#endif
+
 #define LQ_PI_HI     0x1.921fb54442d18p+1
 #define LQ_PI_LO     0x1.1a62633145c07p-53
 #define LQ_PI_2_HI   0x1.921fb54442d18p+0
@@ -79,23 +93,23 @@ LQ_HD void lq_sincos(double x, double* sn, double* cs) {
     const double z = r * r;
     /* sin r = r + r z (s3 + z (s5 + ... + z s17)) */
     double ps = 0x1.952c77030ad4ap-49;                          /* 1/17! */
-    ps = fma(ps, z, -0x1.ae7f3e733b81fp-41);                    /* -1/15! */
-    ps = fma(ps, z, 0x1.6124613a86d09p-33);                     /* 1/13! */
-    ps = fma(ps, z, -0x1.ae64567f544e4p-26);                    /* -1/11! */
-    ps = fma(ps, z, 0x1.71de3a556c734p-19);                     /* 1/9! */
-    ps = fma(ps, z, -0x1.a01a01a01a01ap-13);                    /* -1/7! */
-    ps = fma(ps, z, 0x1.1111111111111p-7);                      /* 1/5! */
-    ps = fma(ps, z, -0x1.5555555555555p-3);                     /* -1/3! */
+    ps = lq_fma(ps, z, -0x1.ae7f3e733b81fp-41);                    /* -1/15! */
+    ps = lq_fma(ps, z, 0x1.6124613a86d09p-33);                     /* 1/13! */
+    ps = lq_fma(ps, z, -0x1.ae64567f544e4p-26);                    /* -1/11! */
+    ps = lq_fma(ps, z, 0x1.71de3a556c734p-19);                     /* 1/9! */
+    ps = lq_fma(ps, z, -0x1.a01a01a01a01ap-13);                    /* -1/7! */
+    ps = lq_fma(ps, z, 0x1.1111111111111p-7);                      /* 1/5! */
+    ps = lq_fma(ps, z, -0x1.5555555555555p-3);                     /* -1/3! */
     const double hz = 0.5 * z;
     const double ksin = r + (r * z * ps + rt * (1.0 - hz));
     /* cos r = 1 - z/2 + z^2 (c4 + z (c6 + ... + z c16)) */
     double pc = 0x1.ae7f3e733b81fp-45;                          /* 1/16! */
-    pc = fma(pc, z, -0x1.93974a8c07c9dp-37);                    /* -1/14! */
-    pc = fma(pc, z, 0x1.1eed8eff8d898p-29);                     /* 1/12! */
-    pc = fma(pc, z, -0x1.27e4fb7789f5cp-22);                    /* -1/10! */
-    pc = fma(pc, z, 0x1.a01a01a01a01ap-16);                     /* 1/8! */
-    pc = fma(pc, z, -0x1.6c16c16c16c17p-10);                    /* -1/6! */
-    pc = fma(pc, z, 0x1.5555555555555p-5);                      /* 1/4! */
+    pc = lq_fma(pc, z, -0x1.93974a8c07c9dp-37);                    /* -1/14! */
+    pc = lq_fma(pc, z, 0x1.1eed8eff8d898p-29);                     /* 1/12! */
+    pc = lq_fma(pc, z, -0x1.27e4fb7789f5cp-22);                    /* -1/10! */
+    pc = lq_fma(pc, z, 0x1.a01a01a01a01ap-16);                     /* 1/8! */
+    pc = lq_fma(pc, z, -0x1.6c16c16c16c17p-10);                    /* -1/6! */
+    pc = lq_fma(pc, z, 0x1.5555555555555p-5);                      /* 1/4! */
     const double one_m = 1.0 - hz;
     const double kcos = one_m + (((1.0 - one_m) - hz) + (z * z * pc - r * rt));
     double s = ksin, c = kcos;
@@ -122,16 +136,16 @@ LQ_HD double lq_atan2(double y, double x) {
     const double z = big ? (t - 1.0) / (t + 1.0) : t;
     const double w = z * z;
     double p = -0x1.3a31a1d5ffde0p-6;
-    p = fma(p, w, 0x1.4162b9ab69c5ap-5);
-    p = fma(p, w, -0x1.a0999a234950fp-5);
-    p = fma(p, w, 0x1.dfe6491089bd5p-5);
-    p = fma(p, w, -0x1.10fa77ab514f0p-4);
-    p = fma(p, w, 0x1.3b126305dc4dep-4);
-    p = fma(p, w, -0x1.745d0b28a2eeep-4);
-    p = fma(p, w, 0x1.c71c71853d607p-4);
-    p = fma(p, w, -0x1.24924924361fep-3);
-    p = fma(p, w, 0x1.999999999934cp-3);
-    p = fma(p, w, -0x1.5555555555555p-2);
+    p = lq_fma(p, w, 0x1.4162b9ab69c5ap-5);
+    p = lq_fma(p, w, -0x1.a0999a234950fp-5);
+    p = lq_fma(p, w, 0x1.dfe6491089bd5p-5);
+    p = lq_fma(p, w, -0x1.10fa77ab514f0p-4);
+    p = lq_fma(p, w, 0x1.3b126305dc4dep-4);
+    p = lq_fma(p, w, -0x1.745d0b28a2eeep-4);
+    p = lq_fma(p, w, 0x1.c71c71853d607p-4);
+    p = lq_fma(p, w, -0x1.24924924361fep-3);
+    p = lq_fma(p, w, 0x1.999999999934cp-3);
+    p = lq_fma(p, w, -0x1.5555555555555p-2);
     const double corr = z * w * p;                               /* atan z - z */
     double a = big ? LQ_PI_4_HI + (z + (corr + LQ_PI_4_LO)) : z + corr;
     a = swap ? LQ_PI_2_HI - (a - LQ_PI_2_LO) : a;
@@ -159,19 +173,19 @@ LQ_HD double lq_tanh(double x) {
     double r = fma(-k, LQ_LN2_HI, y);
     r = fma(-k, LQ_LN2_LO, r);
     double q = 0x1.ae7f3e733b81fp-41;                          /* 1/15! */
-    q = fma(q, r, 0x1.93974a8c07c9dp-37);                      /* 1/14! */
-    q = fma(q, r, 0x1.6124613a86d09p-33);                      /* 1/13! */
-    q = fma(q, r, 0x1.1eed8eff8d898p-29);                      /* 1/12! */
-    q = fma(q, r, 0x1.ae64567f544e4p-26);                      /* 1/11! */
-    q = fma(q, r, 0x1.27e4fb7789f5cp-22);                      /* 1/10! */
-    q = fma(q, r, 0x1.71de3a556c734p-19);                      /* 1/9! */
-    q = fma(q, r, 0x1.a01a01a01a01ap-16);                      /* 1/8! */
-    q = fma(q, r, 0x1.a01a01a01a01ap-13);                      /* 1/7! */
-    q = fma(q, r, 0x1.6c16c16c16c17p-10);                      /* 1/6! */
-    q = fma(q, r, 0x1.1111111111111p-7);                      /* 1/5! */
-    q = fma(q, r, 0x1.5555555555555p-5);                      /* 1/4! */
-    q = fma(q, r, 0x1.5555555555555p-3);                      /* 1/3! */
-    q = fma(q, r, 0x1.0000000000000p-1);                      /* 1/2! */
+    q = lq_fma(q, r, 0x1.93974a8c07c9dp-37);                      /* 1/14! */
+    q = lq_fma(q, r, 0x1.6124613a86d09p-33);                      /* 1/13! */
+    q = lq_fma(q, r, 0x1.1eed8eff8d898p-29);                      /* 1/12! */
+    q = lq_fma(q, r, 0x1.ae64567f544e4p-26);                      /* 1/11! */
+    q = lq_fma(q, r, 0x1.27e4fb7789f5cp-22);                      /* 1/10! */
+    q = lq_fma(q, r, 0x1.71de3a556c734p-19);                      /* 1/9! */
+    q = lq_fma(q, r, 0x1.a01a01a01a01ap-16);                      /* 1/8! */
+    q = lq_fma(q, r, 0x1.a01a01a01a01ap-13);                      /* 1/7! */
+    q = lq_fma(q, r, 0x1.6c16c16c16c17p-10);                      /* 1/6! */
+    q = lq_fma(q, r, 0x1.1111111111111p-7);                      /* 1/5! */
+    q = lq_fma(q, r, 0x1.5555555555555p-5);                      /* 1/4! */
+    q = lq_fma(q, r, 0x1.5555555555555p-3);                      /* 1/3! */
+    q = lq_fma(q, r, 0x1.0000000000000p-1);                      /* 1/2! */
     const double p = fma(r * r, q, r);                           /* expm1(r) */
     const double s = ldexp(1.0, (int)k);
     const double num = fma(-s, p, 1.0 - s);

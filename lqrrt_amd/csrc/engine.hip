@@ -11,8 +11,8 @@
 // levers, and the parity tests run with several of them forced):
 //   switch                       default  read by                  effect
 //   LQRRT_FUSED_ROUNDS           1        fused_rounds_enabled     0: k_decide + re-steer + k_append instead of fused repair rounds
-//   LQRRT_STEER_WAVEFRONTS       auto     steer_wavefronts         2|3|4: wavefronts per rollout of the heading-torque boats
-//   LQRRT_STEER_QUAD_MAX / _TRIO_MAX  256 / 512  steer_wavefronts  launch sizes up to which 4 / 3 wavefronts are used (the chain rollouts)
+//   LQRRT_STEER_WAVEFRONTS       auto     steer_wavefronts         2|3: wavefronts per rollout of the heading-torque boats (3: the chain rollout)
+//   LQRRT_STEER_TRIO_MAX         512      steer_wavefronts         launch sizes up to which 3 wavefronts are used
 //   LQRRT_CTL_CUT / _MIN / _LO / _HI  1.0 / 128 / 2 / 10  tune_wave   wave-size controller
 //   LQRRT_EXACT_WAVE_MAX         256      pick_wave                largest exact-mode wave the controller chooses (1024: as before round 3)
 //   LQRRT_MATRIX_MAX_W           256      lqrrt_wave_speculate     largest wave that keeps an in-wave cost matrix

@@ -264,18 +264,16 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     return 0;
 }
 
-// Wavefronts per rollout (kernels.hpp, DuoLds; round 4: the chain rollouts, one barrier per step).  The boats with the heading
-// torque use three -- chain / heading / checker -- up to 512 problems per launch (1024 SIMDs: beyond 341 some wavefronts share a
-// SIMD), two beyond that; the system with the split step (the headline's) uses four -- effort / chain / heading / checker --
-// while every wavefront of the launch can have a SIMD of its own (256 problems: the fused rounds' waves).  Other systems use one
-// or two.  LQRRT_STEER_WAVEFRONTS=2|3|4 forces a form (tests/test_fuzz_gpu.py runs the fuzzer with each).
+// Wavefronts per rollout (kernels.hpp, DuoLds): the boats with the heading torque use three -- the chain rollout: chain /
+// heading / checker, one barrier per step -- up to 512 problems per launch (1024 SIMDs: beyond 341 some wavefronts share a
+// SIMD, which still pays up to ~600 on the bench), two beyond that; other systems use one or two.
+// LQRRT_STEER_WAVEFRONTS=2|3 forces a form (tests/test_fuzz_gpu.py runs the fuzzer with each).
 template <class S> static int steer_wavefronts(int count) {
     if (steer_wavefronts_max<S>() <= 2) return steer_wavefronts_max<S>();
     static const int forced = getenv("LQRRT_STEER_WAVEFRONTS") ? atoi(getenv("LQRRT_STEER_WAVEFRONTS")) : 0;
-    if (forced >= 2 && forced <= 4) return forced;
+    if (forced >= 2 && forced <= 3) return forced;
     static const int trio_max = getenv("LQRRT_STEER_TRIO_MAX") ? atoi(getenv("LQRRT_STEER_TRIO_MAX")) : 512;
-    static const int quad_max = getenv("LQRRT_STEER_QUAD_MAX") ? atoi(getenv("LQRRT_STEER_QUAD_MAX")) : 256;
-    return (count <= quad_max && has_trio_split<S>::value) ? 4 : count <= trio_max ? 3 : 2;
+    return count <= trio_max ? 3 : 2;
 }
 template <class S, bool DENSE, int NWF>
 static void launch_steer_nwf(lqrrt_engine* e, int count, size_t lds, hipStream_t st, const EvPair& ev, const double* xs, const int* list,
@@ -293,9 +291,6 @@ static void launch_steer_kernel(lqrrt_engine* e, int count, size_t lds, hipStrea
     } else if constexpr (steer_wavefronts_max<S>() == 2) {
         if (f.Sd) launch_steer_nwf<S, true, 2>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
         else launch_steer_nwf<S, false, 2>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
-    } else if (nwf == 4) {
-        if (f.Sd) launch_steer_nwf<S, true, 4>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
-        else launch_steer_nwf<S, false, 4>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
     } else if (nwf == 3) {
         if (f.Sd) launch_steer_nwf<S, true, 3>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
         else launch_steer_nwf<S, false, 3>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);

@@ -696,86 +696,48 @@ __device__ __forceinline__ void round_decide(const RoundArgs& ra, int cur, const
     if (want < 0 && ra.changed[cur][~want]) need = true;
 }
 
-// Two wavefronts per rollout for the boats with the heading torque (S::PACKED; pieces in systems.hpp "duo_"):
-//   main wavefront (0)              helper wavefront (1)
-//   prologue (nearest / decision)   stages parameters, tolerances and geometry into LDS
-//   ---------------------------- barrier S ----------------------------------------------
-//   step k, phase 1: erf, K e,      reads packet k-1 (state x_k, its trig, e and u of the step that produced it);
-//     trig and gain of x_k+1          the heading-torque chain atan2 -> sincos -> atan2 on x_k  -> rud
-//   ---------------------------- barrier Y_k ------------------------------------------------
-//   phase 2: + rud, thrusters,      checks packet k-1 exactly like the sequential loop: feasibility, error growth,
-//     integration -> packet k         convergence, horizon; records it in the edge history or raises `stop`
-//   ---------------------------- barrier X_k+1: both read `stop` ---------------------------
-// The main wavefront runs one step ahead of the verdict; it applies the convergence / horizon test itself (`fin`) so that
-// the common ending does not cost a thrown-away step, only the helper's last check.  A barrier
-// hand-off costs ~50 ns (tools/micro/barrier.hip), a step ~800 instructions of ~2.6 ns: 2.1 -> ~1.3 us per step.
-// With three wavefronts (NWF = 3, used while every wavefront of the launch can have a SIMD of its own: two wavefronts on one
-// SIMD slow each other down by ~40 %) the helper's two jobs are separated and the checker also takes the cos/sin of the
-// next heading and the gain off the main wavefront:
-//   main (0): erf, K e | + rud, thrusters, integration      torque (1): the chain | -
-//   checker (2): the tests on step k-1 | cos/sin of heading k+1 and K_k+1 (they only need x_k), handed over in tr / Kb
-// With four (NWF = 4, launches small enough for 4 SIMDs per problem) a fourth wavefront takes the cos/sin of the next heading
-// and the gain from the checker and also the erf angle of the next step (atan2 of target vs next heading: it needs nothing
-// but x_k either), so that the main wavefront's phase 1 is K e and the torque-independent half of the finish step.
-// Every other system with an analytic gain uses two wavefronts in the plain way: the main wavefront computes the steps
-// (erf, K e, dynamics, cos/sin, gain), the second one runs the sequential loop's tests one step behind (one barrier per
-// step, packets double-buffered by step parity).  Riccati systems keep one wavefront (their gain uses the whole wavefront).
-// Systems opt in (S::TWO_WAVEFRONTS): it pays where the tests are a real share of a step (car +18 %, boat_novice and the
-// 12-state integrator +2 %), not for the pendulum (no obstacles: -4 %).
+// Wavefronts per rollout.  A rollout is a serial recurrence that owns its SIMD, where an instruction costs ~6 cycles whatever it
+// is (tools/micro/issue.hip): a step is as long as the instruction count of its longest wavefront, so the work of a step is
+// spread over the SIMDs of the CU as far as its dependencies allow.
+//   * The boats with the heading torque (S::PACKED; pieces in systems.hpp "duo_" / "*_effort") run THREE wavefronts per rollout
+//     while every wavefront of the launch can have a SIMD of its own, the CHAIN rollout (round 4; scheme at its code in k_steer):
+//     chain / heading / checker, ONE barrier per step.  Rounds 2-3 split the step itself over up to four wavefronts (main /
+//     torque / checker / next heading, two barriers per step) because the heading torque -- atan2 -> sincos -> atan2 -- was ~60 %
+//     of the dependency chain; with the torque of a moving boat down to one atan2 (systems.hpp rudder_term) the whole chain
+//     x_k -> e -> u -> torque -> x_k+1 is ~330 instructions, and every way of splitting it was measured slower than keeping it on
+//     one wavefront: a hand-over between wavefronts costs what ~40 instructions cost, whether it is a barrier (profiles/
+//     r04_ab_chain.txt: four wavefronts with an LDS sequence word between effort and chain +3 %, a barrier-free dataflow
+//     pipeline of four wavefronts -12 %; tools/experiments/r04_dataflow.patch).
+//   * Larger launches of those boats use TWO wavefronts (two wavefronts that share a SIMD slow each other down by ~40 %):
+//       main wavefront (0)              helper wavefront (1)
+//       prologue (nearest / decision)   stages parameters, tolerances and geometry into LDS
+//       ---------------------------- barrier S ----------------------------------------------
+//       step k, phase 1: erf, K e,      reads packet k-1 (state x_k, its trig, e and u of the step that produced it);
+//         trig and gain of x_k+1          the heading torque on x_k  -> rud
+//       ---------------------------- barrier Y_k ------------------------------------------------
+//       phase 2: + rud, thrusters,      checks packet k-1 exactly like the sequential loop: feasibility, error growth,
+//         integration -> packet k         convergence, horizon; records it in the edge history or raises `stop`
+//       ---------------------------- barrier X_k+1: both read `stop` ---------------------------
+//     The main wavefront runs one step ahead of the verdict; it applies the convergence / horizon test itself (`fin`) so that
+//     the common ending does not cost a thrown-away step, only the helper's last check.
+//   * Every other system with an analytic gain uses two wavefronts in the plain way: the main wavefront computes the steps
+//     (erf, K e, dynamics, cos/sin, gain), the second one runs the sequential loop's tests one step behind (one barrier per
+//     step, packets double-buffered by step parity).  Systems opt in (S::TWO_WAVEFRONTS): it pays where the tests are a real
+//     share of a step (car +18 %, boat_novice and the 12-state integrator +2 %), not for the pendulum (no obstacles: -4 %).
+//   * Riccati systems keep one wavefront (their gain uses the whole wavefront).
 template <class S, class = void> struct wants_two : std::false_type {};
 template <class S> struct wants_two<S, std::enable_if_t<S::TWO_WAVEFRONTS>> : std::true_type {};
-template <class S> constexpr int steer_wavefronts_max() { return is_packed<S>::value ? 4 : wants_two<S>::value ? 2 : 1; }
+template <class S> constexpr int steer_wavefronts_max() { return is_packed<S>::value ? 3 : wants_two<S>::value ? 2 : 1; }
 struct DuoLds {
-    double pk[2 * MAXN + 4 + MAXM];      // xn | trn | e | u   of the newest step
-    double rud;
+    double pk[2 * MAXN + 4 + MAXM];      // two wavefronts (boats): xn | trn | e | u   of the newest step
+    double rud;                          //   the heading torque of the step in flight
     int go, stop, cnt, steps, grew, truncated;
-    int fin;                             // the newest step ends the edge by convergence or horizon if it is feasible at all
-    double tr[2][2];                     // NWF = 3: cos/sin of heading k in tr[k & 1]
-    double Kb[2][MAXM * MAXN];           // NWF = 3: gain K_k in Kb[k & 1]
-    double eu[2][MAXN + MAXM];           // NWF = 3: e | u of step k in eu[k & 1] (written before the torque is known)
-    int finp[2];                         // NWF = 3: step k is not computed (`fin` of step k-1), in finp[k & 1]
-    double pk2[2][2 * MAXN + 4 + MAXM];  // plain two-wavefront rollout: xn | trn | e | u of step k in pk2[k & 1]
-    double e2b[2];                       // NWF = 4: erf angle of step k in e2b[k & 1]
-    double tt[2];                        // NWF = 4: cos/sin of the target's heading
-    double pre[12];                      // (round 3's chain-owner rollout: ta[4] | Dv[3] | xn012[3] | u[2] of step k)
-    double pre2[2][6];                   // four-wavefront chain rollout: ta[4] | u2 of step p in pre2[p & 1], effort -> chain wavefront
-    int pre_seq[2];                      //   p + 1 once pre2[p & 1] is complete (written after it; LDS executes a wavefront's accesses in order)
-    int feas_seq[2];                     //   ((p + 1) << 1) | feasible once the checker is through with x_p
+    int fin;                             //   the newest step ends the edge by convergence or horizon if it is feasible at all
+    double pk2[2][2 * MAXN + 4 + MAXM];  // plain two-wavefront rollout: xn | trn | e | u of step k in pk2[k & 1]; chain rollout: x_p+1 | e_p | u_p in pk2[(p+1) & 1]
+    double tr[2][2];                     // chain rollout: cos/sin of heading p in tr[p & 1]
+    double e2b[2];                       //   erf angle of step p in e2b[p & 1]
+    double tt[2];                        //   cos/sin of the target's heading
 };
-struct NoSplit { struct TrioPre {}; };
-template <class S, class = void> struct has_trio_split : std::false_type {};
-template <class S> struct has_trio_split<S, std::enable_if_t<S::TRIO_SPLIT>> : std::true_type {};
-
-// Hand-overs between wavefronts of one workgroup inside a barrier period (four-wavefront chain rollout): LDS words written AFTER
-// the data they announce.  The instructions are spelled out because (a) the order of the accesses IS the protocol -- the LDS unit
-// executes one wavefront's accesses in order, so "data, then word" on the producer and "word, then data" on the consumer need no
-// wait in between -- and the compiler is free to reorder plain accesses; (b) `volatile` through a generic pointer turns into
-// system-coherent FLAT accesses with a wait behind each one (~1 us for a five-double hand-over, measured).
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
-}
-__device__ __forceinline__ void lds_publish5(unsigned data, unsigned word, const double* v, int seq) {
-    asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %0, %3 offset:8\n\tds_write_b64 %0, %4 offset:16\n\t"
-                 "ds_write_b64 %0, %5 offset:24\n\tds_write_b64 %0, %6 offset:32\n\tds_write_b32 %1, %7"
-                 :: "v"(data), "v"(word), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(seq) : "memory");
-}
-__device__ __forceinline__ int lds_take5(unsigned data, unsigned word, double* v) {
-    int sq;
-    double a, b, c, d, e;
-    asm volatile("ds_read_b32 %0, %7\n\tds_read_b64 %1, %6\n\tds_read_b64 %2, %6 offset:8\n\tds_read_b64 %3, %6 offset:16\n\t"
-                 "ds_read_b64 %4, %6 offset:24\n\tds_read_b64 %5, %6 offset:32\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(sq), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e) : "v"(data), "v"(word) : "memory");
-    v[0] = a; v[1] = b; v[2] = c; v[3] = d; v[4] = e;
-    return __builtin_amdgcn_readfirstlane(sq);
-}
-__device__ __forceinline__ void lds_post(unsigned word, int value) {
-    asm volatile("ds_write_b32 %0, %1" :: "v"(word), "v"(value) : "memory");
-}
-__device__ __forceinline__ int lds_peek(unsigned word) {
-    int v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(word) : "memory");
-    return __builtin_amdgcn_readfirstlane(v);
-}
 
 // The sequential loop's tests on the step that produced xn (planner.py:393-433); true when the edge ends here
 // rec_later != null: the step's verdict only; when it says "record", *rec_later is set and the caller writes the history entry
@@ -932,7 +894,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     STEER_TS(0);
     BLK_T(blk_t0);
     constexpr bool DUO = NWF >= 2;
-    static_assert(NWF <= 2 || is_packed<S>::value, "the three- and four-wavefront splits need the duo_* pieces of the system");
+    static_assert(NWF <= 2 || is_packed<S>::value, "the chain rollout needs the duo_* / *_effort pieces of the system");
     constexpr bool PLAIN2 = NWF == 2 && !is_packed<S>::value;
     extern __shared__ double hist[];
     double* hx = hist;
@@ -945,111 +907,11 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     __shared__ DuoLds duo;
     double* htr = hist + (size_t)r.H * (S::N + S::M) + geo_lds_doubles(g);   // DUO: cos/sin of every recorded state
     constexpr int PKN = S::N + 2 * S::NW;                                    // plain two-wavefront packet: offset of e
-    // Chain-owner rollout (four wavefronts, systems with the split step): the only true dependency chain of a step is
-    //   x_k -> heading torque (atan2, sincos, atan2) -> x_k+1 ,
-    // so the wavefront that computes the torque also finishes the step and keeps the state in registers: nothing on the
-    // chain crosses a wavefront boundary except u_k and the torque-free half of the step, which the main wavefront has
-    // long put into LDS (duo.pre).  Two barriers per step: Y_k (effort, next heading, feasibility answer are there) and
-    // X_k+1 (x_k+1 and the verdict on x_k are there; everybody leaves here when the edge has ended).  The checking
-    // wavefront is off the chain: feasibility before Y, book-keeping and the history entry after it.
-    constexpr bool QX = NWF == 4 && has_trio_split<S>::value;
 #ifdef STEER_TIMING
     __shared__ int hw_l[4];
     __shared__ int cu_prev_l;
     if ((threadIdx.x & 63) == 0) hw_l[threadIdx.x >> 6] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
 #endif
-    if constexpr (QX) {
-        // Four-wavefront chain rollout (round 4; systems with the split step = the headline system).  One barrier per step as in
-        // the three-wavefront form below, but the chain wavefront is relieved of everything that is not on the chain
-        //   x_p -> heading torque (one atan2 for a moving boat) -> thrusters, integration -> x_p+1 :
-        //   effort (0, the wavefront of the prologue): x_p, cos/sin and erf angle of heading p from LDS; K = lqr(x_p), e, u = K e and
-        //                the torque-free terms of invB.u -> pre2[p & 1] + sequence word; then the sequential loop's book-keeping for
-        //                step p-1 (error growth, convergence, horizon, history entry or `stop`) once the checker's answer is there
-        //   chain (1):   torque, drag products, position update from the state it keeps in registers; picks up pre2 when it needs
-        //                it (the effort wavefront is ~60 instructions into its step by then: the sequence word is a formality, the
-        //                poll loop runs once), finishes the step -> x_p+1 into pk2[(p+1) & 1]
-        //   heading (2): cos/sin of heading p+1 and the erf angle there (they only need two components of x_p)
-        //   checker (3): feasibility of x_p -> feas_seq[p & 1]
-        // Hand-overs inside a period go through LDS words written AFTER the data they announce (a wavefront's LDS accesses execute in
-        // order; all four wavefronts of a workgroup are resident, so a poll cannot starve its producer); everything else is
-        // published by the period's barrier.
-        if (threadIdx.x >= 192) {
-            // ---------------- checking wavefront: feasibility only
-            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
-            for (int i = lane; i < MAXP; i += 64) Pl[i] = P.p[i];
-            if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
-            const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
-            __syncthreads();                                                // S
-            if (!duo.go) return;
-            for (int p = 1;; ++p) {
-                __syncthreads();                                            // B_p: x_p is there
-                if (duo.stop) return;
-                STEP_TS(cs0);
-                double xn[S::N], trn[2];
-                const double* pk = duo.pk2[p & 1];
-#pragma unroll
-                for (int d = 0; d < S::N; ++d) xn[d] = pk[d];
-                trn[0] = duo.tr[p & 1][0]; trn[1] = duo.tr[p & 1][1];
-                const bool ok = uniform_true(S::feasible(Pl, g, gl, xn, xn, trn, lane));    // (these systems' tests do not read the effort)
-                lds_post(lds_addr(&duo.feas_seq[p & 1]), ((p + 1) << 1) | (ok ? 1 : 0));
-                STEP_TS(cs1);
-                STEP_ACC(5, cs0, cs1);
-            }
-        }
-        if (threadIdx.x >= 128) {
-            // ---------------- heading wavefront: what step p + 1 needs and only depends on two components of x_p
-            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;
-            __syncthreads();                                                // S
-            if (!duo.go) return;
-            const double tt0 = duo.tt[0], tt1 = duo.tt[1];
-            for (int p = 0;; ++p) {
-                STEP_TS(ds0);
-                const double hn = duo.pk2[p & 1][2] + duo.pk2[p & 1][5] * r.dt;        // euler(): xn[2] = x[2] + x[5] dt
-                double tn[2];
-                lq_sincos(hn, &tn[1], &tn[0]);
-                duo.tr[(p + 1) & 1][0] = tn[0]; duo.tr[(p + 1) & 1][1] = tn[1];
-                // erf's angle error of step p + 1 (planner.py:386): wrap_err(target, next heading)
-                duo.e2b[(p + 1) & 1] = lq_atan2(tt1 * tn[0] - tt0 * tn[1], tt0 * tn[0] + tt1 * tn[1]);
-                STEP_TS(ds1);
-                STEP_ACC(7, ds0, ds1);
-                __syncthreads();                                            // B_p+1
-                if (duo.stop) return;
-            }
-        }
-        if (threadIdx.x >= 64) {
-            // ---------------- chain wavefront: owns the state
-            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;
-            __syncthreads();                                                // S
-            if (!duo.go) return;
-            typename S::TrioPre q;
-            S::trio_consts(Pl, q);
-            const double rgain = Pl[37], vmin2 = Pl[52];
-            double xk[S::N];
-#pragma unroll
-            for (int d = 0; d < S::N; ++d) xk[d] = duo.pk2[0][d];
-            for (int p = 0;; ++p) {
-                STEP_TS(ps0);
-                const double c = duo.tr[p & 1][0], sn = duo.tr[p & 1][1];
-                const double rud = S::rudder_term(rgain, vmin2, xk, c, sn);   // the heading torque (demo_boat_advanced.py:101-108)
-                S::trio_state(q, xk, c, sn, r.dt);                          // drag products, position update: they only need x_p
-                STEP_TS(ps1);
-                double u[S::M], xn[S::N], got[5];
-                u[0] = 0.0; u[1] = 0.0;
-                while (lds_take5(lds_addr(duo.pre2[p & 1]), lds_addr(&duo.pre_seq[p & 1]), got) != p + 1) {}   // (normally there long ago)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) q.ta[j] = got[j];
-                u[2] = got[4];
-                S::trio_post(q, xk, u, rud, r.dt, xn);                      // planner.py:390
-                double* pk = duo.pk2[(p + 1) & 1];
-#pragma unroll
-                for (int d = 0; d < S::N; ++d) { pk[d] = xn[d]; xk[d] = xn[d]; }
-                STEP_TS(ps2);
-                STEP_ACC(6, ps0, ps1); STEP_ACC(2, ps1, ps2);
-                __syncthreads();                                            // B_p+1
-                if (duo.stop) return;
-            }
-        }
-    }
     // Chain rollout (three wavefronts, every system with the heading-torque pieces; round 4).  With the torque of a moving boat
     // down to one atan2 the dependency chain of a step, x_k -> torque -> x_k+1, is ~230 instructions INCLUDING erf, u = K e and
     // the whole finish step: shorter than any split of it over two wavefronts plus the two barriers that split needs.  So one
@@ -1113,102 +975,6 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
                 STEP_ACC(7, ds0, ds1);
                 __syncthreads();                                            // B_p+1
                 if (duo.stop) return;
-            }
-        }
-    }
-    if constexpr (NWF == 4 && !QX) {
-        if (threadIdx.x >= 192) {
-            // ---------------- next-heading wavefront: what step k + 1 needs and only depends on x_k
-            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;
-            __syncthreads();                                                // S
-            if (!duo.go) return;
-            const double tt0 = duo.tt[0], tt1 = duo.tt[1];
-            for (int k = 0;; ++k) {
-                STEP_TS(ds0);
-                const bool alive = !duo.finp[k & 1];
-                double tn[2];
-                if (alive) {
-                    // cos/sin of the next heading (euler(): xn[2] = x[2] + x[5] dt) and the gain there (planner.py:436)
-                    double Kn[S::M * S::N], xk[S::N];
-#pragma unroll
-                    for (int d = 0; d < S::N; ++d) xk[d] = duo.pk[d];
-                    lq_sincos(xk[2] + xk[5] * r.dt, &tn[1], &tn[0]);
-                    S::gain(Pl, xk, tn, xk, Kn);
-                    duo.tr[(k + 1) & 1][0] = tn[0]; duo.tr[(k + 1) & 1][1] = tn[1];
-#pragma unroll
-                    for (int j = 0; j < S::M * S::N; ++j) duo.Kb[(k + 1) & 1][j] = Kn[j];
-                }
-                STEP_TS(ds1);
-                STEP_ACC(7, ds0, ds1);
-                __syncthreads();                                            // Y_k
-                if (duo.stop) return;
-                // erf's angle error of step k + 1 (planner.py:386): wrap_err(target, next heading)
-                if (alive) duo.e2b[(k + 1) & 1] = lq_atan2(tt1 * tn[0] - tt0 * tn[1], tt0 * tn[0] + tt1 * tn[1]);
-                __syncthreads();                                            // X_k+1
-            }
-        }
-    }
-    if constexpr (NWF == 4 && !QX) {
-        if (threadIdx.x >= 128) {
-            // ---------------- checking wavefront
-            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
-            for (int i = lane; i < MAXP; i += 64) Pl[i] = P.p[i];
-            if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
-            const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
-            __syncthreads();                                                // S
-            if (!duo.go) return;
-            double tolr[S::N], last[S::N];
-#pragma unroll
-            for (int d = 0; d < S::N; ++d) { tolr[d] = tol_l[d]; last[d] = INFINITY; }           // planner.py:377
-            int cnt = 0, steps = 0;
-            for (int k = 0;; ++k) {
-                double xn[S::N], trn[2], e[S::N], u[S::M];
-                STEP_TS(cs0);
-#pragma unroll
-                for (int d = 0; d < S::N; ++d) { xn[d] = duo.pk[d]; e[d] = duo.eu[(k + 1) & 1][d]; }
-                trn[0] = duo.tr[k & 1][0]; trn[1] = duo.tr[k & 1][1];
-#pragma unroll
-                for (int j = 0; j < S::M; ++j) u[j] = duo.eu[(k + 1) & 1][S::N + j];
-                const bool fin = duo.finp[k & 1] != 0;
-                bool stop = false, rec_now = false;
-                if (k >= 1) stop = rollout_check<S>(Pl, g, gl, r, xn, trn, e, u, lane, cnt, steps, last, tolr, hx, hu, htr, duo, &rec_now);
-                STEP_TS(cs1);
-                STEP_ACC(5, cs0, cs1);
-                __syncthreads();                                            // Y_k
-                if (duo.stop) return;
-                if (rec_now) { rollout_record<S>(xn, trn, u, cnt, hx, hu, htr); ++cnt; }   // (nobody reads the history before the loop ends)
-                if (NWF == 3 && !fin && !stop) {
-                    // what the main wavefront needs for step k + 1 and only depends on x_k: cos/sin of the next heading
-                    // (euler(): xn[2] = x[2] + x[5] dt) and the gain there (planner.py:436)
-                    double tn[2], Kn[S::M * S::N];
-                    lq_sincos(xn[2] + xn[5] * r.dt, &tn[1], &tn[0]);
-                    S::gain(Pl, xn, tn, u, Kn);
-                    duo.tr[(k + 1) & 1][0] = tn[0]; duo.tr[(k + 1) & 1][1] = tn[1];
-#pragma unroll
-                    for (int j = 0; j < S::M * S::N; ++j) duo.Kb[(k + 1) & 1][j] = Kn[j];
-                }
-                __syncthreads();                                            // X_k+1
-            }
-        }
-        if (threadIdx.x >= 64) {
-            // ---------------- torque wavefront
-            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;
-            __syncthreads();                                                // S
-            if (!duo.go) return;
-            for (int k = 0;; ++k) {
-                STEP_TS(ps0);
-                if (!duo.finp[k & 1]) {
-                    double xk[S::N], tk[2];
-#pragma unroll
-                    for (int d = 0; d < S::N; ++d) xk[d] = duo.pk[d];
-                    tk[0] = duo.tr[k & 1][0]; tk[1] = duo.tr[k & 1][1];
-                    duo.rud = S::duo_chain(Pl, xk, tk);
-                }
-                STEP_TS(ps1);
-                STEP_ACC(6, ps0, ps1);
-                __syncthreads();                                            // Y_k
-                if (duo.stop) return;
-                __syncthreads();                                            // X_k+1
             }
         }
     }
@@ -1536,85 +1302,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     BLK_T(blk_tq);
     int cnt = 0, steps = 0;
     bool grew = false, truncated = false;
-    if constexpr (QX) {
-        // effort wavefront of the four-wavefront chain rollout (scheme at the helpers' code above)
-        duo.go = 1; duo.stop = 0; duo.cnt = 0; duo.steps = 0; duo.grew = 0; duo.truncated = 0;
-        duo.pre_seq[0] = 0; duo.pre_seq[1] = 0; duo.feas_seq[0] = 0; duo.feas_seq[1] = 0;
-#pragma unroll
-        for (int d = 0; d < S::N; ++d) duo.pk2[0][d] = x[d];
-        duo.tr[0][0] = trig[0]; duo.tr[0][1] = trig[1];
-        duo.tt[0] = ttrig[0]; duo.tt[1] = ttrig[1];
-        __syncthreads();                                             // S
-        BLK_T(blk_t1);
-#ifdef STEER_TIMING
-        if (threadIdx.x == 0) {
-            const int mode = f.n_chunks > 0 ? 0 : (ron ? 1 : 2);
-            atomicAdd(&g_pro_acc[mode * 5 + 0], blk_tp - blk_t0); atomicAdd(&g_pro_acc[mode * 5 + 1], blk_tq - blk_tp);
-            atomicAdd(&g_pro_acc[mode * 5 + 2], blk_t1 - blk_tq); atomicAdd(&g_pro_acc[mode * 5 + 3], 1ull);
-        }
-#endif
-        double Pc[S::NP];                                            // model constants in registers (see the three-wavefront form)
-#pragma unroll
-        for (int i = 0; i < S::NP; ++i) Pc[i] = Pl[i];
-        double tolr[S::N], last[S::N], ib[8], ep[S::N], up[S::M];
-#pragma unroll
-        for (int d = 0; d < S::N; ++d) { tolr[d] = tol_l[d]; last[d] = INFINITY; ep[d] = 0.0; }     // planner.py:377
-#pragma unroll
-        for (int j = 0; j < S::M; ++j) up[j] = 0.0;
-        S::trio_ib(Pc, ib);
-        const GeoL gl_none{};                                        // (feasibility comes from the checker)
-        bool stopped = false;
-        for (int p = 0;; ++p) {
-            STEP_TS(ms0);
-            double e[S::N], u[S::M], ta[4];
-            if (p >= 1) {
-                const double* pk = duo.pk2[p & 1];
-#pragma unroll
-                for (int d = 0; d < S::N; ++d) x[d] = pk[d];
-                trig[0] = duo.tr[p & 1][0]; trig[1] = duo.tr[p & 1][1];
-                const double e2 = duo.e2b[p & 1];
-                S::gain(Pc, x, trig, x, K);                                       // planner.py:436: K = lqr(x_p)
-                S::quad_effort(xt, x, K, e2, e, u);                               // planner.py:386-387
-            } else {
-                S::trio_effort(xt, ttrig, x, trig, K, e, u);                      // (the parent's own gain)
-            }
-            S::trio_ta(ib, u, ta);
-            {
-                const double out[5] = {ta[0], ta[1], ta[2], ta[3], u[2]};
-                lds_publish5(lds_addr(duo.pre2[p & 1]), lds_addr(&duo.pre_seq[p & 1]), out, p + 1);
-            }
-            STEP_TS(ms1);
-            if (p >= 1) {
-                // the sequential loop's tests on step p - 1, which produced x_p (planner.py:393-433)
-                int fz;
-                do { fz = lds_peek(lds_addr(&duo.feas_seq[p & 1])); } while ((fz >> 1) != p + 1);
-                const bool feas_ok = (fz & 1) != 0;
-                bool rec_now = false;
-                stopped = rollout_check<S>(Pl, g, gl_none, r, x, trig, ep, up, lane, cnt, steps, last, tolr, hx, hu, htr, duo, &rec_now, &feas_ok);
-                if (rec_now) { rollout_record<S>(x, trig, up, cnt, hx, hu, htr); ++cnt; }
-            }
-#pragma unroll
-            for (int d = 0; d < S::N; ++d) ep[d] = e[d];
-#pragma unroll
-            for (int j = 0; j < S::M; ++j) up[j] = u[j];
-            STEP_TS(ms2);
-            __syncthreads();                                         // B_p+1: x_p+1 is there; so is `stop`
-            STEP_TS(ms4);
-            STEP_ACC(0, ms0, ms1); STEP_ACC(1, ms1, ms2); STEP_ACC(4, ms2, ms4); STEP_ACC(3, ms0, ms0 + 1);
-            if (stopped) break;
-        }
-        cnt = duo.cnt; steps = duo.steps; grew = duo.grew != 0;
-        truncated = true;                                            // the node comes from the history
-#ifdef STEER_TIMING
-        if (threadIdx.x == 0 && steps >= 20) {
-            const unsigned long long t2 = wall_clock64();
-            atomicAdd(&g_blk_acc[1], t2 - blk_t1); atomicMax(&g_blk_acc[4], t2 - blk_t1);
-            atomicAdd(&g_blk_acc[5], blk_t1 - blk_t0); atomicMax(&g_blk_acc[6], blk_t1 - blk_t0);
-            atomicAdd(&g_blk_acc[2], 1ull);
-            atomicAdd(&g_loop_hist[min(31, (int)((t2 - blk_t1) / 200))], 1ull);      // 2 us buckets
-        }
-#endif
-    } else if constexpr (CH) {
+    if constexpr (CH) {
         // the chain wavefront (scheme at the helpers' code above)
         duo.go = 1; duo.stop = 0; duo.cnt = 0; duo.steps = 0; duo.grew = 0; duo.truncated = 0;
 #pragma unroll
@@ -1658,77 +1346,6 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             STEP_TS(ms4);
             STEP_ACC(0, ms0, ms1); STEP_ACC(4, ms1, ms4); STEP_ACC(3, ms0, ms0 + 1);
             if (duo.stop) break;
-        }
-        cnt = duo.cnt; steps = duo.steps; grew = duo.grew != 0;
-        truncated = true;                                            // x / trig / K ran ahead: the node comes from the history
-#ifdef STEER_TIMING
-        if (threadIdx.x == 0 && steps >= 20) {
-            const unsigned long long t2 = wall_clock64();
-            atomicAdd(&g_blk_acc[1], t2 - blk_t1); atomicMax(&g_blk_acc[4], t2 - blk_t1);
-            atomicAdd(&g_blk_acc[5], blk_t1 - blk_t0); atomicMax(&g_blk_acc[6], blk_t1 - blk_t0);
-            atomicAdd(&g_blk_acc[2], 1ull);
-            atomicAdd(&g_loop_hist[min(31, (int)((t2 - blk_t1) / 200))], 1ull);      // 2 us buckets
-        }
-#endif
-    } else if constexpr (NWF >= 3) {
-        duo.go = 1; duo.stop = 0; duo.cnt = 0; duo.steps = 0; duo.grew = 0; duo.truncated = 0; duo.finp[0] = 0; duo.finp[1] = 0;
-#pragma unroll
-        for (int d = 0; d < S::N; ++d) duo.pk[d] = x[d];
-        duo.tr[0][0] = trig[0]; duo.tr[0][1] = trig[1];
-        if constexpr (NWF == 4) { duo.tt[0] = ttrig[0]; duo.tt[1] = ttrig[1]; }
-        __syncthreads();                                             // S
-        BLK_T(blk_t1);
-#ifdef STEER_TIMING
-        if (threadIdx.x == 0) {
-            const int mode = f.n_chunks > 0 ? 0 : (ron ? 1 : 2);
-            atomicAdd(&g_pro_acc[mode * 5 + 0], blk_tp - blk_t0); atomicAdd(&g_pro_acc[mode * 5 + 1], blk_tq - blk_tp);
-            atomicAdd(&g_pro_acc[mode * 5 + 2], blk_t1 - blk_tq); atomicAdd(&g_pro_acc[mode * 5 + 3], 1ull);
-        }
-#endif
-        double tolr[S::N];
-#pragma unroll
-        for (int d = 0; d < S::N; ++d) tolr[d] = tol_l[d];
-        bool live = true;
-        for (int k = 0;; ++k) {
-            double e[S::N], u[S::M], xn[S::N];
-            bool live_next = live;
-            [[maybe_unused]] typename std::conditional_t<has_trio_split<S>::value, S, NoSplit>::TrioPre pre;
-            STEP_TS(ms0);
-            if (live) {
-                if (k >= 1) {                                        // from the checker: cos/sin of this heading, K = lqr(x_k)
-                    trig[0] = duo.tr[k & 1][0]; trig[1] = duo.tr[k & 1][1];
-#pragma unroll
-                    for (int j = 0; j < S::M * S::N; ++j) K[j] = duo.Kb[k & 1][j];
-                }
-                if (NWF == 4 && k >= 1) S::quad_effort(xt, x, K, duo.e2b[k & 1], e, u);
-                else S::trio_effort(xt, ttrig, x, trig, K, e, u);                  // planner.py:386-387
-#pragma unroll
-                for (int d = 0; d < S::N; ++d) duo.eu[k & 1][d] = e[d];
-#pragma unroll
-                for (int j = 0; j < S::M; ++j) duo.eu[k & 1][S::N + j] = u[j];
-                // planner.py:428 as the checker will apply it to this step if every step so far is feasible: steps = k + 1
-                bool conv = true;
-#pragma unroll
-                for (int d = 0; d < S::N; ++d) conv = conv && (fabs(e[d]) <= tolr[d]);
-                if (k + 1 > r.H || uniform_true(conv)) { duo.finp[(k + 1) & 1] = 1; live_next = false; }
-                if constexpr (has_trio_split<S>::value) S::trio_pre(Pl, x, trig, u, r.dt, pre);
-            }
-            STEP_TS(ms1);
-            __syncthreads();                                         // Y_k: the heading torque of this step and the verdict on
-            if (duo.stop) break;                                     //      step k-1 are there
-            STEP_TS(ms2);
-            if (live) {
-                const double rud = duo.rud;
-                if constexpr (has_trio_split<S>::value) S::trio_post(pre, x, u, rud, r.dt, xn);
-                else S::duo_finish(Pl, x, trig, u, rud, r.dt, xn);                // planner.py:390
-#pragma unroll
-                for (int d = 0; d < S::N; ++d) { duo.pk[d] = xn[d]; x[d] = xn[d]; }
-            }
-            STEP_TS(ms3);
-            __syncthreads();                                         // X_k+1: state, cos/sin and gain of x_k+1 are there
-            STEP_TS(ms4);
-            STEP_ACC(0, ms0, ms1); STEP_ACC(1, ms1, ms2); STEP_ACC(2, ms2, ms3); STEP_ACC(4, ms3, ms4); STEP_ACC(3, ms0, ms0 + 1);
-            live = live_next;
         }
         cnt = duo.cnt; steps = duo.steps; grew = duo.grew != 0;
         truncated = true;                                            // x / trig / K ran ahead: the node comes from the history

@@ -381,7 +381,7 @@ struct BoatCommon {
         }
         lq_sincos(x[2] + x[5] * dt, &trn[1], &trn[0]);           // euler(): xn[2] = x[2] + xdot[2]*dt, xdot[2] = x[5]
     }
-    // (three wavefronts: the same without the cos/sin, which the checking wavefront provides)
+    // (chain rollout, first step: the same without the cos/sin, which the heading wavefront provides)
     __device__ __forceinline__ static void trio_effort(const double* xt, const double* ttrig, const double* x, const double* trig,
                                        const double* K, double* e, double* u) {
         const double c = trig[0], s = trig[1];
@@ -396,7 +396,7 @@ struct BoatCommon {
             u[i] = a;
         }
     }
-    // (four wavefronts: the angle error arrives too)
+    // (chain rollout, later steps: the angle error arrives too)
     __device__ __forceinline__ static void quad_effort(const double* xt, const double* x, const double* K, double e2, double* e, double* u) {
 #pragma unroll
         for (int d = 0; d < 6; ++d) e[d] = xt[d] - x[d];
@@ -473,93 +473,6 @@ struct BoatAdvanced : BoatCommon {
     __device__ __forceinline__ static void duo_finish(const double* P, const double* x, const double* trig, const double* u, double rud, double dt, double* xn) {
         double uc[3] = {u[0], u[1], u[2] + rud};
         thrust_and_integrate(P, x, trig, uc, dt, xn);
-    }
-    // duo_finish in two halves for the three-wavefront rollout: everything that does not need the heading torque
-    // (the first two terms of invB.u, drag, the position update, the constants) while the torque wavefront is still
-    // busy, the rest after it.  Same operations in the same order as thrust_and_integrate / euler / carlike.
-    static constexpr bool TRIO_SPLIT = true;
-    struct TrioPre { double ta[4], b2[4], tmax[4], Bm[12], Dv[3], invM[3], xn012[3], vp, vn, Dp[3], Dn[3]; };
-    __device__ __forceinline__ static void trio_pre(const double* P, const double* x, const double* trig, const double* u, double dt, TrioPre& q) {
-        const double c = trig[0], s = trig[1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            double a = P[21 + 3 * j] * u[0];
-            a += P[21 + 3 * j + 1] * u[1];
-            q.ta[j] = a; q.b2[j] = P[21 + 3 * j + 2]; q.tmax[j] = P[33 + j];
-        }
-#pragma unroll
-        for (int i = 0; i < 12; ++i) q.Bm[i] = P[9 + i];
-        double xdot[3];
-        xdot[0] = c * x[3] + (-s) * x[4];
-        xdot[1] = s * x[3] + c * x[4];
-        xdot[2] = x[5];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            q.xn012[i] = x[i] + xdot[i] * dt;
-            const double v = x[3 + i];
-            const double D = (v >= 0.0) ? P[3 + i] : P[6 + i];
-            q.Dv[i] = D * v; q.invM[i] = P[i];
-        }
-        q.vp = P[38]; q.vn = P[39];
-    }
-    // the members of TrioPre that do not depend on the step (chain-owner rollout: the torque wavefront keeps them in registers,
-    // computes Dv / xn012 of each step itself -- they only need the state it owns -- and gets ta and u2 from the main wavefront)
-    __device__ __forceinline__ static void trio_consts(const double* P, TrioPre& q) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { q.b2[j] = P[21 + 3 * j + 2]; q.tmax[j] = P[33 + j]; }
-#pragma unroll
-        for (int i = 0; i < 12; ++i) q.Bm[i] = P[9 + i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { q.invM[i] = P[i]; q.Dp[i] = P[3 + i]; q.Dn[i] = P[6 + i]; }
-        q.vp = P[38]; q.vn = P[39];
-    }
-    // trio_pre's torque- and effort-free part: drag products and the position update of step k (same operations, same order)
-    __device__ __forceinline__ static void trio_state(TrioPre& q, const double* x, double c, double s, double dt) {
-        double xdot[3];
-        xdot[0] = c * x[3] + (-s) * x[4];
-        xdot[1] = s * x[3] + c * x[4];
-        xdot[2] = x[5];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            q.xn012[i] = x[i] + xdot[i] * dt;
-            const double v = x[3 + i];
-            const double D = (v >= 0.0) ? q.Dp[i] : q.Dn[i];
-            q.Dv[i] = D * v;
-        }
-    }
-    // trio_pre's effort part: the first two terms of invB.u (ib = invB[j][0], invB[j][1] for j = 0..3, kept in registers)
-    __device__ __forceinline__ static void trio_ib(const double* P, double* ib) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { ib[2 * j] = P[21 + 3 * j]; ib[2 * j + 1] = P[21 + 3 * j + 1]; }
-    }
-    __device__ __forceinline__ static void trio_ta(const double* ib, const double* u, double* ta) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            double a = ib[2 * j] * u[0];
-            a += ib[2 * j + 1] * u[1];
-            ta[j] = a;
-        }
-    }
-    __device__ __forceinline__ static void trio_post(const TrioPre& q, const double* x, const double* u, double rud, double dt, double* xn) {
-        const double u2 = u[2] + rud;
-        double t[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            double a = q.ta[j];
-            a += q.b2[j] * u2;
-            t[j] = clipd(a, -q.tmax[j], q.tmax[j]);
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            double a = q.Bm[4 * i] * t[0];
-            a += q.Bm[4 * i + 1] * t[1];
-            a += q.Bm[4 * i + 2] * t[2];
-            a += q.Bm[4 * i + 3] * t[3];
-            const double xdot = q.invM[i] * (a - q.Dv[i]);
-            xn[3 + i] = x[3 + i] + xdot * dt;
-            xn[i] = q.xn012[i];
-        }
-        carlike(x, q.vp, q.vn, xn);
     }
     __device__ __forceinline__ static void thrust_and_integrate(const double* P, const double* x, const double* trig, double* u, double dt, double* xn) {
         const double c = trig[0], s = trig[1];

@@ -52,5 +52,5 @@ def test_switches_do_not_change_the_tree():
     size, attempts, hits = (int(x) for x in base.split()[1:4])
     assert size > 7000 and attempts > 20000 and hits > 10            # the run is long enough to go through every mechanism
     for env in ({"LQRRT_REFILL_AHEAD": "0"}, {"LQRRT_IGNORE_PATCH": "0"}, {"LQRRT_FUSED_ROUNDS": "0"},
-                {"LQRRT_STEER_WAVEFRONTS": "3"}, {"LQRRT_REFILL_AHEAD": "0", "LQRRT_IGNORE_PATCH": "0", "LQRRT_STEER_WAVEFRONTS": "2"}):
+                {"LQRRT_STEER_WAVEFRONTS": "2"}, {"LQRRT_REFILL_AHEAD": "0", "LQRRT_IGNORE_PATCH": "0", "LQRRT_STEER_WAVEFRONTS": "2"}):
         assert _run(env) == base, env
