@@ -14,7 +14,9 @@
  *     "host" pointers are ordinary process memory;
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream); launches are
  *     asynchronous on it unless the function returns data to the host;
- *   - an engine handle owns its device buffers; handles are independent (no globals).
+ *   - an engine handle owns its device buffers; handles are independent.  Process-wide state is limited to: the RCCL entry
+ *     points, resolved once under std::call_once (lqrrt_comm_*), the environment switches, each read once, and the
+ *     accumulators of the LQRRT_HOSTPROF / STEER_TIMING measurement builds (debug levers, not thread-safe, off by default).
  *
  * Layouts (all in HBM)
  *   tree state   : SoA, component d of node i at state[d*capacity + i]   (coalesced scans)

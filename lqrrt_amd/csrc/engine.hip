@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <dlfcn.h>
+#include <mutex>
 #include <chrono>
 
 #include <algorithm>

@@ -14,32 +14,40 @@ struct RcclApi {
     int (*GetUniqueId)(lq_nccl_uid*) = nullptr;
     int (*CommInitRank)(void**, int, lq_nccl_uid, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommAbort)(void*) = nullptr;                         // optional
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string error;
 };
+// Resolved once per process, whichever thread asks first (std::call_once: two planner threads may create communicators at the
+// same time).  LQRRT_RCCL names the library to use and wins over a copy that happens to be loaded already (PyTorch's): that is
+// how tests/stub_rccl/libstub_rccl.so gets two ranks onto a one-GPU box.
 static RcclApi* rccl() {
     static RcclApi api;
-    static bool tried = false;
-    if (tried) return &api;
-    tried = true;
-    const char* names[] = {getenv("LQRRT_RCCL"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    for (const char* nm : names) {                            // first: a copy that is already in the process
-        if (!nm) continue;
-        api.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-        if (api.lib) break;
-    }
-    for (const char* nm : names) {
-        if (api.lib) break;
-        if (nm) api.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-    }
-    if (!api.lib) { api.error = "librccl.so not found (set LQRRT_RCCL)"; return &api; }
-    api.GetUniqueId = (int (*)(lq_nccl_uid*))dlsym(api.lib, "ncclGetUniqueId");
-    api.CommInitRank = (int (*)(void**, int, lq_nccl_uid, int))dlsym(api.lib, "ncclCommInitRank");
-    api.CommDestroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
-    api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllGather");
-    api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
-    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) api.error = "librccl.so lacks the nccl* entry points";
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (const char* forced = getenv("LQRRT_RCCL")) {
+            api.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!api.lib) { api.error = std::string("LQRRT_RCCL: cannot load ") + forced; return; }
+        }
+        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* nm : names) {                        // first: a copy that is already in the process
+            if (api.lib) break;
+            api.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        }
+        for (const char* nm : names) {
+            if (api.lib) break;
+            api.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!api.lib) { api.error = "librccl.so not found (set LQRRT_RCCL)"; return; }
+        api.GetUniqueId = (int (*)(lq_nccl_uid*))dlsym(api.lib, "ncclGetUniqueId");
+        api.CommInitRank = (int (*)(void**, int, lq_nccl_uid, int))dlsym(api.lib, "ncclCommInitRank");
+        api.CommDestroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
+        api.CommAbort = (int (*)(void*))dlsym(api.lib, "ncclCommAbort");
+        api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllGather");
+        api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) api.error = "librccl.so lacks the nccl* entry points";
+    });
     return &api;
 }
 
@@ -123,6 +131,7 @@ static double shard_tail_fraction() {
 // records, prepared for the repair rounds (k_shard_unpack_prep).  Payload per rank: per * (header + 1) + tail doubles.
 static int allgather_nodes(lqrrt_engine* e, lqrrt_comm* c, int W, int per, int hd, int tb, hipStream_t st) {
     const size_t blk = (size_t)per * hd + tb;
+    if (c->kind == LQRRT_COMM_RCCL && !c->nccl) return fail(LQRRT_E_STATE, "the communicator was aborted after a rank failed");
     if (c->kind == LQRRT_COMM_RCCL && c->world > 1) {
         NCCLCHK(rccl()->AllGather(e->d_blk + (size_t)c->rank * blk, e->d_blk, blk * sizeof(double), /*ncclUint8*/ 1, c->nccl, st));
     } else if (c->kind == LQRRT_COMM_RCCL) {
@@ -196,6 +205,7 @@ static int tree_sharded_wave(lqrrt_engine* e, lqrrt_comm* c, int W, hipStream_t 
             TRY(lqrrt_wave_scan_nodes(e, W, lo, hi, e->d_blk + (size_t)g * 2 * W, st));
         }
     } else {
+        if (!c->nccl) return fail(LQRRT_E_STATE, "the communicator was aborted after a rank failed");
         NCCLCHK(rccl()->AllGather(e->d_blk + (size_t)c->rank * 2 * W, e->d_blk, (size_t)2 * W * sizeof(double), 1, c->nccl, st));
     }
     return lqrrt_wave_steer_candidates(e, W, G, e->d_blk, st);
@@ -240,12 +250,20 @@ extern "C" int lqrrt_engine_extend_sharded(lqrrt_engine* e, lqrrt_comm* c, int s
             lim = (lim < 0) ? l2 : std::min(lim, l2);
         }
         lqrrt_extend_stats ws;
+        int rc;
         if (scheme == LQRRT_SHARD_SAMPLES) {
-            TRY(sample_sharded_wave(e, c, W, st));
-            TRY(commit_impl(e, W, cap_attempts, lim, pruning, &ws, stream, true));
+            rc = sample_sharded_wave(e, c, W, st);
+            if (rc == 0) rc = commit_impl(e, W, cap_attempts, lim, pruning, &ws, stream, true);
         } else {
-            TRY(tree_sharded_wave(e, c, W, st));
-            TRY(commit_impl(e, W, cap_attempts, lim, pruning, &ws, stream, false));
+            rc = tree_sharded_wave(e, c, W, st);
+            if (rc == 0) rc = commit_impl(e, W, cap_attempts, lim, pruning, &ws, stream, false);
+        }
+        if (rc != 0) {
+            // A rank that fails here (capacity, a repair that does not converge, a dead stream) leaves its peers inside the next
+            // wave's collective: abort the communicator so that they come back with an error instead of hanging.  The handle
+            // stays valid for lqrrt_comm_destroy; every further collective on it fails.
+            if (c->kind == LQRRT_COMM_RCCL && c->world > 1 && c->nccl && rccl()->CommAbort) { (void)rccl()->CommAbort(c->nccl); c->nccl = nullptr; }
+            return rc;
         }
         acc.attempts += ws.attempts; acc.accepted += ws.accepted; acc.waves += 1;
         acc.fix_rounds += ws.fix_rounds; acc.resteers += ws.resteers; acc.goal_hits += ws.goal_hits;

@@ -43,6 +43,7 @@ static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, 
     static const bool patch_on = [] { const char* v = getenv("LQRRT_IGNORE_PATCH"); return !(v && atoi(v) == 0); }();
     // (small waves only: the copy it replaces is a fixed ~5 us, the lookup costs the patched scan ~2 us at 100 samples and more at
     //  1024 -- synchronous mode is 4 % faster with the upload, profiles/r03_ab_round.txt)
+    bool patch_rides = false;             // (the host's view of the device bitmap changes only once the scan that carries it is enqueued)
     if (patch_on && e->ign_dirty && e->ign_patch_valid && cnt > 0 && W <= 256 && !e->ign_patch.empty() && scan_takes_patch(e)) {
         patch.n = (int)e->ign_patch.size();
         patch.wmin = patch.wmax = e->ign_patch[0];
@@ -50,7 +51,7 @@ static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, 
             patch.idx[k] = e->ign_patch[k]; patch.val[k] = e->h_ign[e->ign_patch[k]];
             patch.wmin = std::min(patch.wmin, patch.idx[k]); patch.wmax = std::max(patch.wmax, patch.idx[k]);
         }
-        e->ign_dirty = false; e->ign_patch_valid = false; e->ign_hi = e->N;
+        patch_rides = true;
     } else {
         TRY(flush_ignore(e, st, false));
     }
@@ -73,6 +74,7 @@ static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, 
         TRY(launch_nn(e, nv, xs + (size_t)lo * e->n, cnt, nullptr, false, nullptr, nullptr,
                       e->d_rec + (size_t)lo * e->L.R, st, true, &n_chunks, lo, true, xtr ? xtr + (size_t)lo * 2 * e->nw : nullptr,
                       e->riccati ? wave_sample_S(e) + (size_t)lo * e->n * e->n : nullptr, false, &patch));
+        if (patch_rides) { e->ign_dirty = false; e->ign_patch_valid = false; e->ign_hi = e->N; }   // workgroup (0, 0) of that scan stores the words
         const double hp2 = hostprof_on() ? now_us() : 0.0;
         SteerFuse f;
         memset(&f, 0, sizeof f);

@@ -1672,6 +1672,12 @@ __global__ __launch_bounds__(64) void k_shard_unpack_prep(double* __restrict__ r
         } else if (len > 0) {
             mark_stale = 1;
         }
+    } else {
+        // the owner of a sample whose edge did not fit its tail (offset -2) re-steers it like everybody else: the rounds, their
+        // re-steer counts and with them the wave-size controller have to be the same on every rank (the next wave's all-gather
+        // counts follow from W), even though the owner's local record is complete
+        const double* h = blk + (size_t)g * blk_stride + (size_t)j * hd;
+        if ((int)h[L.off_len] > 0 && (int)h[L.off_xseq] < 0) mark_stale = 1;
     }
     __threadfence();
     const int len = (int)my[L.off_len];

@@ -28,14 +28,27 @@ import numpy as np
 class NativeComm(object):
     """Communicator of the native sharded loop (include/lqrrt_hip.h lqrrt_comm_*).  `dist` given: an RCCL communicator of its
     own for this world -- rank 0 creates the unique id, the 128 bytes travel through torch.distributed (any backend), every
-    rank joins.  `dist` None: the loopback double (one process plays `rank` of `world`; tests)."""
+    rank joins.  `uid` given (128 bytes from lqrrt_comm_unique_id / NativeComm.unique_id() on rank 0, carried by the caller's
+    own means): the same without torch.distributed.  Neither: the loopback double (one process plays `rank` of `world`; tests)."""
 
-    def __init__(self, rank, world, device=0, dist=None):
+    @staticmethod
+    def unique_id():
+        from . import _native as nat
+        uid = np.zeros(128, dtype=np.uint8)
+        nat.check(nat.lib().lqrrt_comm_unique_id(uid.ctypes.data_as(C.c_void_p)))
+        return uid.tobytes()
+
+    def __init__(self, rank, world, device=0, dist=None, uid=None):
         from . import _native as nat
         self._nat = nat
         self.rank, self.world = int(rank), int(world)
         h = C.c_void_p()
-        if dist is None:
+        if uid is not None:
+            uid = np.frombuffer(bytes(uid), dtype=np.uint8).copy()
+            if uid.size != 128:
+                raise ValueError("uid must be the 128 bytes of lqrrt_comm_unique_id")
+            nat.check(nat.lib().lqrrt_comm_create(uid.ctypes.data_as(C.c_void_p), self.rank, self.world, int(device), C.byref(h)))
+        elif dist is None:
             nat.check(nat.lib().lqrrt_comm_create_loopback(self.rank, self.world, C.byref(h)))
         else:
             import torch
@@ -64,13 +77,27 @@ class NativeComm(object):
 
 class NativeSharded(object):
     """Sharded waves without a host language in the loop: engine.extend_sharded runs speculate -> ncclAllGather -> commit on one
-    stream for as many waves as the call covers.  Same interface as ShardedWave / TreeShardedWave (`wave`)."""
+    stream for as many waves as the call covers.
+
+    NOT the one-wave-per-call interface of ShardedWave / TreeShardedWave: `extend_to(wave_cap, max_attempts, ...)` commits up to
+    `max_attempts` attempts over however many waves that takes (`wave_cap` bounds a wave) and returns their aggregated
+    ExtendStats (`waves` says how many).  Callers that need a per-wave hook -- a rewind window, stop-on-goal handling of their own
+    -- pass max_attempts <= wave_cap or use the Python classes below.  `wave` is kept as an alias for bench.py's loop, which
+    treats all three classes as "commit up to this many attempts"."""
 
     def __init__(self, engine, comm, scheme="sample"):
         self.e, self.comm, self.scheme = engine, comm, scheme
 
+    def extend_to(self, wave_cap, max_attempts, node_limit=-1, pruning=True):
+        if max_attempts is None or max_attempts < 0:
+            if node_limit is None or node_limit < 0:
+                raise ValueError("NativeSharded: unbounded call (max_attempts < 0 and no node_limit): it would run until the tree "
+                                 "capacity is exhausted; bound it or use extend(wave, until_size=...)")
+            max_attempts = -1
+        return self.e.extend_sharded(self.comm, self.scheme, wave_cap, max_attempts=max_attempts, node_limit=node_limit, pruning=pruning)
+
     def wave(self, want, max_commit, node_limit=-1, pruning=True):
-        return self.e.extend_sharded(self.comm, self.scheme, want, max_attempts=max_commit, node_limit=node_limit, pruning=pruning)
+        return self.extend_to(want, max_commit, node_limit=node_limit, pruning=pruning)
 
     def extend(self, wave, **kw):
         return self.e.extend_sharded(self.comm, self.scheme, wave, **kw)

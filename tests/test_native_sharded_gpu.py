@@ -67,8 +67,11 @@ def test_loopback_rank_matches_single_engine(name, nodes, wave, world, rank, sch
 
 
 def test_loopback_tail_overflow_resteers(monkeypatch):
-    """LQRRT_SHARD_TAIL=0: only one edge fits into a block's tail, every other accepted sample of another rank arrives
-    without its edge and is re-steered by the receiver -- same tree, edges included."""
+    """LQRRT_SHARD_TAIL=0: only one edge fits into a block's tail, every other accepted sample arrives without its edge and is
+    re-steered in the first round -- by the receivers AND by its owner (whose own record is complete).  Same tree as the single
+    engine, edges included, for every emulated rank.  (WHICH edge fits is decided by an atomic in the producing launch, so two
+    loopback processes that each recompute all blocks may see different overflow sets; that every rank of ONE world runs the same
+    rounds -- ADVICE r03 -- is asserted where the ranks share their blocks: the two-process test below, run with the tail at 0.)"""
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
         import numpy as np, sys
@@ -76,12 +79,16 @@ def test_loopback_tail_overflow_resteers(monkeypatch):
         import test_native_sharded_gpu as t
         from lqrrt_amd.parallel import NativeComm
         _, ref = t._make("boat_advanced", 1300, 256); ref.extend(256, node_limit=1000)
-        _, eng = t._make("boat_advanced", 1300, 256)
-        c = NativeComm(1, 4); st = eng.extend_sharded(c, "sample", 256, node_limit=1000)
-        t._same_tree(eng, ref); print("resteers", st.resteers, "OK")
+        for rank in range(4):
+            _, eng = t._make("boat_advanced", 1300, 256)
+            c = NativeComm(rank, 4); st = eng.extend_sharded(c, "sample", 256, node_limit=1000)
+            t._same_tree(eng, ref)
+            assert st.resteers > 0
+            c.close()
+        print("OK")
     """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
     env = dict(os.environ, LQRRT_SHARD_TAIL="0")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
@@ -118,3 +125,96 @@ def test_rccl_world_of_one_both_schemes():
         torch.cuda.synchronize()
         _same_tree(eng, ref)
         comm.close()
+
+
+_TWO_RANK_CHILD = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import test_native_sharded_gpu as t
+from lqrrt_amd.parallel import NativeComm
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+uid = bytes.fromhex(os.environ["LQRRT_TEST_UID"])
+comm = NativeComm(rank, world, device=0, uid=uid)          # lqrrt_comm_create -> ncclCommInitRank of the library LQRRT_RCCL names
+out = []
+for name, nodes, wave, scheme, sync in (("boat_advanced", 1500, 256, "sample", False), ("car", 900, 256, "sample", False),
+                                         ("boat_advanced", 1200, 256, "tree", False), ("boat_advanced", 2500, 512, "sample", True)):
+    _, ref = t._make(name, nodes + wave + 8, wave, sync=sync)
+    kw = dict(max_attempts=6 * wave) if sync else dict(node_limit=nodes)
+    rs = ref.extend(wave, **kw)
+    _, eng = t._make(name, nodes + wave + 8, wave, sync=sync)
+    st = eng.extend_sharded(comm, scheme, wave, **kw)
+    assert (st.attempts, st.accepted, st.goal_hits) == (rs.attempts, rs.accepted, rs.goal_hits), (name, scheme)
+    t._same_tree(eng, ref)
+    out.append((st.waves, st.fix_rounds, st.resteers, st.attempts))
+comm.close()
+print("RANK", rank, "STATS", out, "OK")
+"""
+
+
+@pytest.mark.parametrize("tail", ["default", "0"])
+def test_two_processes_through_the_collective_entry_point(tail):
+    """Two ranks in two PROCESSES run lqrrt_engine_extend_sharded against each other on this one GPU: the library's RCCL entry
+    points are resolved from tests/stub_rccl/libstub_rccl.so (LQRRT_RCCL), an all-gather over POSIX shared memory -- real RCCL
+    refuses two ranks on one device, and the loopback communicator skips ncclAllGather altogether.  What only this test executes:
+    the in-place all-gather offsets of a rank > 0, the per-rank tail cursor across waves, a rank that only ever sees the other
+    rank's samples through the blocks, and the same W / round sequence on both sides (or the collective would not match up).
+    Sample-sharded (fused rounds, car and boat), tree-sharded, synchronous mode; each rank == the single engine, bit for bit.
+    tail = "0": LQRRT_SHARD_TAIL=0, nearly every accepted edge overflows its block's tail and is re-steered -- by the receiver and,
+    since round 4, by the owner too, so that fix_rounds / resteers and with them the wave-size controller stay replicated."""
+    import subprocess, sys
+    import ctypes as C
+    stub = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub_rccl", "libstub_rccl.so")
+    if not os.path.exists(stub):
+        pytest.fail("tests/stub_rccl/libstub_rccl.so is missing: __graft_entry__.build() compiles it")
+    lib = C.CDLL(stub)
+    uid = (C.c_char * 128)()
+    assert lib.ncclGetUniqueId(uid) == 0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _TWO_RANK_CHILD % dict(root=root, tests=os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LQRRT_RCCL=stub, LQRRT_TEST_UID=bytes(uid).hex())
+    if tail != "default":
+        env["LQRRT_SHARD_TAIL"] = tail
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank hung")
+        outs.append((p.returncode, o, e))
+    for rc, o, e in outs:
+        assert rc == 0 and "OK" in o, o[-1500:] + e[-2500:]
+    stats = [o.split("STATS")[1].split("OK")[0].strip() for _, o, _ in outs]
+    assert stats[0] == stats[1], stats                # same waves / rounds / re-steers on both ranks
+
+
+def test_legacy_repair_path_for_waves_beyond_256():
+    """The repair path that is still shipped for waves beyond the fused rounds' 256 samples and for Riccati systems -- k_decide +
+    in-wave scan of the records + listed re-steers -- in the single-engine loop and in a gathered wave (with the
+    exact-mode cap of 256 in force nothing reached it any more).  LQRRT_EXACT_WAVE_MAX=1024 lifts the cap, LQRRT_MATRIX_MAX_W=0
+    takes the in-wave matrix (and with it the fused rounds) away from the smaller waves too, so every wave of the run uses it."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import numpy as np
+        import test_native_sharded_gpu as t
+        import coracle, lqrrt_amd
+        from lqrrt_amd.parallel import NativeComm
+        s, ref = t._make("boat_advanced", 3200, 1024)
+        rs = ref.extend(1024, node_limit=2000)
+        assert rs.fix_rounds > 50 and rs.resteers > 200, (rs.fix_rounds, rs.resteers)
+        o = coracle.make(s, 3200, seed=1); o.extend(max_nodes=2000)
+        assert ref.size == o.size and np.array_equal(ref.parents(), o.parents()) and np.array_equal(ref.states(), o.states())
+        _, eng = t._make("boat_advanced", 3200, 1024)
+        c = NativeComm(1, 4); eng.extend_sharded(c, "sample", 1024, node_limit=2000)
+        t._same_tree(eng, ref); print("OK", rs.attempts, rs.waves)
+    """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
+           os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LQRRT_EXACT_WAVE_MAX="1024", LQRRT_MATRIX_MAX_W="0"), capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
