@@ -16,8 +16,9 @@
 namespace lq {
 
 // C[r x c] = A[r x k] * B[k x c]   (ta/tb: use the transpose of the stored operand)
+template <int NT = 64>
 __device__ __forceinline__ void mm(double* C, const double* A, const double* B, int r, int k, int c, bool ta, bool tb, int lane) {
-    for (int idx = lane; idx < r * c; idx += 64) {
+    for (int idx = lane; idx < r * c; idx += NT) {
         const int i = idx / c, j = idx % c;
         double acc = 0.0;
         for (int p = 0; p < k; ++p) {
@@ -96,22 +97,26 @@ __device__ __forceinline__ void gj_eliminate(double (&v)[(n * (n + q) + 63) / 64
     }
 }
 
-template <int n, int q>
-__device__ __forceinline__ void solve_inplace(double* W, double* RHS, int lane) {
+template <int n, int q, int NT = 64>
+__device__ __forceinline__ void solve_inplace(double* W, double* RHS, int tid) {
     constexpr int C = n + q, E = n * C, IT = (E + 63) / 64;
     static_assert(C <= 64, "one lane per column of [W | RHS]");
+    static_assert(NT == 64 || IT <= 2, "larger workgroups: register form only (their first wavefront solves, the others wait)");
+    const int lane = tid & 63;
     if constexpr (IT <= 2) {
-        double v[IT];
+        if (tid < 64) {
+            double v[IT];
 #pragma unroll
-        for (int k = 0; k < IT; ++k) {
-            const int idx = lane + 64 * k, r = idx / C, j = idx % C;
-            v[k] = idx < E ? (j < n ? W[r * n + j] : RHS[r * q + (j - n)]) : 0.0;
-        }
-        gj_eliminate<n, q>(v, lane);
+            for (int k = 0; k < IT; ++k) {
+                const int idx = lane + 64 * k, r = idx / C, j = idx % C;
+                v[k] = idx < E ? (j < n ? W[r * n + j] : RHS[r * q + (j - n)]) : 0.0;
+            }
+            gj_eliminate<n, q>(v, lane);
 #pragma unroll
-        for (int k = 0; k < IT; ++k) {
-            const int idx = lane + 64 * k, r = idx / C, j = idx % C;
-            if (idx < E && j >= n) RHS[r * q + (j - n)] = v[k];
+            for (int k = 0; k < IT; ++k) {
+                const int idx = lane + 64 * k, r = idx / C, j = idx % C;
+                if (idx < E && j >= n) RHS[r * q + (j - n)] = v[k];
+            }
         }
         __syncthreads();
         return;
@@ -170,24 +175,36 @@ struct DareLds {
     double Rm[m * m], X[m * n], Y[m * n], Z[m * m];
     double AG[n * 2 * n];                                         // [A_k | G]: both right-hand sides of one elimination
     double red[2];
+    double redw[8];                                               // four wavefronts: their maxima of a doubling iteration
 };
 
-// lqr(x, u) of the API contract for one (x0, u0), computed by the calling wavefront (all 64 lanes must call; x0 / u0 are
-// wave-uniform per-thread arrays): A, B by central differences of S::step, S by doubling, K = (R + B'SB)^-1 B'SA.
+// lqr(x, u) of the API contract for one (x0, u0), computed by the calling workgroup of NT = 64 or 256 threads (all of them must
+// call; x0 / u0 are uniform per-thread arrays; `tid` = thread index in the workgroup): A, B by central differences of S::step, S by
+// doubling, K = (R + B'SB)^-1 B'SA.
 // P: model parameters; Qd (n x n), Rd (m x m): weights (any address space).  Results are left in the work space:
 // L.T1 = S (symmetrised), L.Y = K (m x n), L.A / L.Bm = the linearisation.  Returns the doubling iterations used.
 // Every sum runs in a fixed order inside ONE lane (mm, solve_inplace), so the result does not depend on the lane
 // count and oracle/lqrrt_oracle.c restates it sequentially (two eliminations there, one here: same bits per column).
-template <class S>
+// NT = 256 (round 4; the rollouts of Riccati systems, k_steer<S, DENSE, 4>): four wavefronts on four SIMDs.  A lone wavefront pays
+// ~6 cycles per instruction whatever it does, and one doubling iteration at n = 6 is ~700 instructions, two thirds of them the
+// Gauss-Jordan elimination of [I + G H | A_k | G] (108 entries = two register slots per lane).  With four wavefronts every matrix
+// pass has one entry per lane, and the elimination is done FOUR times side by side, each wavefront with [I + G H | n/2 of the 2n
+// right-hand-side columns] in ONE register slot: the pivoting only looks at I + G H, so all four take the same pivots, and a
+// right-hand-side column gets the same bits whoever solves it (gj_eliminate).  Same entries, same sums, same order: the bits of
+// the 64-thread form (which lqrrt_lqr_dare_batch and the per-sample S table keep using), asserted on the GPU
+// (tests/test_dare_gpu.py).
+template <class S, int NT = 64>
 __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const double* u0, const double* Qd, const double* Rd,
-                                        double dt, double eps, int max_iter, double tol, DareLds<S::N, S::M>& L, int lane) {
+                                        double dt, double eps, int max_iter, double tol, DareLds<S::N, S::M>& L, int tid) {
+    static_assert(NT == 64 || NT == 256, "one or four wavefronts");
+    const int lane = tid & 63;
     constexpr int n = S::N, m = S::M;
     double *A = L.A, *Bm = L.Bm, *Ak = L.Ak, *G = L.G, *Hm = L.Hm, *W = L.W, *T1 = L.T1, *T2 = L.T2, *T3 = L.T3;
     double *Rm = L.Rm, *X = L.X, *Y = L.Y, *Z = L.Z, *red = L.red, *AG = L.AG;
     __syncthreads();                                             // the previous user of the work space is done
     // ---- central differences: lane j < n perturbs state j, lanes n..n+m-1 perturb effort j-n; lanes 32.. take the minus side
     static_assert(n + m <= 32, "plus and minus sides of the difference quotients share the wavefront");
-    {
+    if (tid < 64) {
         const int col = lane & 31;
         const bool minus = lane >= 32;
         double xo[n];
@@ -210,16 +227,16 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
             if (!minus && col < n + m) { if (col < n) A[d * n + col] = v; else Bm[d * m + (col - n)] = v; }
         }
     }
-    for (int i = lane; i < m * m; i += 64) Rm[i] = Rd[i];
-    for (int i = lane; i < n * n; i += 64) Hm[i] = Qd[i];
+    for (int i = tid; i < m * m; i += NT) Rm[i] = Rd[i];
+    for (int i = tid; i < n * n; i += NT) Hm[i] = Qd[i];
     __syncthreads();
-    for (int i = lane; i < n * n; i += 64) Ak[i] = A[i];
+    for (int i = tid; i < n * n; i += NT) Ak[i] = A[i];
     // ---- G0 = B R^-1 B'
-    for (int i = lane; i < m * n; i += 64) X[i] = Bm[(i % n) * m + (i / n)];     // X = B' (m x n)
-    for (int i = lane; i < m * m; i += 64) Z[i] = Rm[i];
+    for (int i = tid; i < m * n; i += NT) X[i] = Bm[(i % n) * m + (i / n)];     // X = B' (m x n)
+    for (int i = tid; i < m * m; i += NT) Z[i] = Rm[i];
     __syncthreads();
-    solve_inplace<m, n>(Z, X, lane);                                           // X = R^-1 B'
-    mm(G, Bm, X, n, m, n, false, false, lane);
+    solve_inplace<m, n, NT>(Z, X, tid);                                        // X = R^-1 B'
+    mm<NT>(G, Bm, X, n, m, n, false, false, tid);
     // ---- doubling
     int it = 0;
     if constexpr (n * 3 * n <= 128) {
@@ -242,35 +259,47 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
         double* const W1 = T3;                             // H W^-1 A
         double* const W2 = AG + n * n;                     // A W^-1 G
         constexpr int C3 = 3 * n, E3 = n * C3, IT3 = (E3 + 63) / 64;
+        constexpr int QW = n / 2, CW = n + QW, EW = n * CW;          // NT = 256: columns of [W | its share of A_k | G] per wavefront
+        static_assert(NT == 64 || (n % 2 == 0 && EW <= 64), "four wavefronts: n/2 right-hand-side columns each, one register slot");
         for (; it < max_iter; ++it) {
-            for (int e = lane; e < n * n; e += 64) {
+            for (int e = tid; e < n * n; e += NT) {
                 const int i = e / n, j = e % n;
                 double acc = dot(G, Hm, i, j, false, false);
                 if (i == j) acc += 1.0;
                 W[e] = acc;                                                         // W = I + G H
             }
             __syncthreads();
-            double v[IT3];
+            if constexpr (NT == 64) {
+                double v[IT3];
 #pragma unroll
-            for (int k = 0; k < IT3; ++k) {
-                const int idx = lane + 64 * k, r = idx / C3, j = idx % C3;
-                v[k] = idx < E3 ? (j < n ? W[r * n + j] : (j < 2 * n ? Akc[r * n + (j - n)] : G[r * n + (j - 2 * n)])) : 0.0;
-            }
-            gj_eliminate<n, 2 * n>(v, lane);                                        // [T1 | T2] = W^-1 [A | G]
+                for (int k = 0; k < IT3; ++k) {
+                    const int idx = lane + 64 * k, r = idx / C3, j = idx % C3;
+                    v[k] = idx < E3 ? (j < n ? W[r * n + j] : (j < 2 * n ? Akc[r * n + (j - n)] : G[r * n + (j - 2 * n)])) : 0.0;
+                }
+                gj_eliminate<n, 2 * n>(v, lane);                                    // [T1 | T2] = W^-1 [A | G]
 #pragma unroll
-            for (int k = 0; k < IT3; ++k) {
-                const int idx = lane + 64 * k, r = idx / C3, j = idx % C3;
-                if (idx < E3 && j >= n) { if (j < 2 * n) T1[r * n + (j - n)] = v[k]; else T2[r * n + (j - 2 * n)] = v[k]; }
+                for (int k = 0; k < IT3; ++k) {
+                    const int idx = lane + 64 * k, r = idx / C3, j = idx % C3;
+                    if (idx < E3 && j >= n) { if (j < 2 * n) T1[r * n + (j - n)] = v[k]; else T2[r * n + (j - 2 * n)] = v[k]; }
+                }
+            } else {
+                // wavefront w solves columns [w QW, (w+1) QW) of [A_k | G]: w = 0, 1 give T1, w = 2, 3 give T2
+                const int w = tid >> 6, r = lane / CW, j = lane % CW;
+                const int col = w * QW + (j - n);                                   // column of [A_k | G] (j >= n)
+                double v[1];
+                v[0] = lane < EW ? (j < n ? W[r * n + j] : (col < n ? Akc[r * n + col] : G[r * n + (col - n)])) : 0.0;
+                gj_eliminate<n, QW>(v, lane);
+                if (lane < EW && j >= n) { if (col < n) T1[r * n + col] = v[0]; else T2[r * n + (col - n)] = v[0]; }
             }
             __syncthreads();
-            for (int idx = lane; idx < 3 * n * n; idx += 64) {
+            for (int idx = tid; idx < 3 * n * n; idx += NT) {
                 const int w = idx / (n * n), e = idx % (n * n), i = e / n, j = e % n;
                 const double acc = dot(w == 0 ? Hm : Akc, w == 1 ? T2 : T1, i, j, false, false);
                 (w == 0 ? W1 : (w == 1 ? W2 : Akn))[e] = acc;                       // H W^-1 A | A W^-1 G | A W^-1 A
             }
             __syncthreads();
             double dmax = 0.0, hmax = 0.0;
-            for (int idx = lane; idx < 2 * n * n; idx += 64) {
+            for (int idx = tid; idx < 2 * n * n; idx += NT) {
                 const int w = idx / (n * n), e = idx % (n * n), i = e / n, j = e % n;
                 if (w == 0) {
                     const double t3 = dot(Akc, W1, i, j, true, false);              // A' H W^-1 A
@@ -284,11 +313,19 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { dmax = fmax(dmax, __shfl_xor(dmax, off)); hmax = fmax(hmax, __shfl_xor(hmax, off)); }
-            __syncthreads();
+            if constexpr (NT > 64) {                                                // (a maximum does not care about the order)
+                if (lane == 0) { L.redw[2 * (tid >> 6)] = dmax; L.redw[2 * (tid >> 6) + 1] = hmax; }
+            }
+            __syncthreads();                                                        // H, G (and the wavefronts' maxima) are there
+            if constexpr (NT > 64) {                                                // (redw is next written three barriers from here)
+#pragma unroll
+                for (int w = 0; w < NT / 64; ++w) { dmax = fmax(dmax, L.redw[2 * w]); hmax = fmax(hmax, L.redw[2 * w + 1]); }
+            }
             double* tsw = Akc; Akc = Akn; Akn = tsw;
             if (dmax <= tol * fmax(1.0, hmax)) { ++it; break; }
         }
-    } else
+    } else {
+    static_assert(NT == 64 || n * 3 * n <= 128, "the four-wavefront form exists for the register elimination only");
     for (; it < max_iter; ++it) {
         mm(W, G, Hm, n, n, n, false, false, lane);                             // W = G H
         for (int i = lane; i < n; i += 64) W[i * n + i] += 1.0;                 // W = I + G H
@@ -316,14 +353,26 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
         __syncthreads();
         if (red[0] <= tol * fmax(1.0, red[1])) { ++it; break; }
     }
+    }
     // ---- symmetrise, K = (R + B'SB)^-1 B'SA
-    for (int i = lane; i < n * n; i += 64) T1[i] = 0.5 * (Hm[i] + Hm[(i % n) * n + (i / n)]);
+    for (int i = tid; i < n * n; i += NT) T1[i] = 0.5 * (Hm[i] + Hm[(i % n) * n + (i / n)]);
     __syncthreads();
-    mm(X, Bm, T1, m, n, n, true, false, lane);                                 // X = B' S     (m x n)
-    mm(Z, X, Bm, m, n, m, false, false, lane);                                 // Z = B' S B   (m x m)
-    for (int i = lane; i < m * m; i += 64) Z[i] += Rm[i];
-    mm(Y, X, A, m, n, n, false, false, lane);                                  // Y = B' S A   (m x n)
-    solve_inplace<m, n>(Z, Y, lane);                                           // Y = K
+    mm<NT>(X, Bm, T1, m, n, n, true, false, tid);                              // X = B' S     (m x n)
+    for (int idx = tid; idx < m * m + m * n; idx += NT) {                      // Z = R + B' S B (m x m) and Y = B' S A (m x n) side by side
+        if (idx < m * m) {
+            const int i = idx / m, j = idx % m;
+            double acc = 0.0;
+            for (int pp = 0; pp < n; ++pp) acc += X[i * n + pp] * Bm[pp * m + j];
+            Z[idx] = acc + Rm[idx];
+        } else {
+            const int e = idx - m * m, i = e / n, j = e % n;
+            double acc = 0.0;
+            for (int pp = 0; pp < n; ++pp) acc += X[i * n + pp] * A[pp * n + j];
+            Y[e] = acc;
+        }
+    }
+    __syncthreads();
+    solve_inplace<m, n, NT>(Z, Y, tid);                                        // Y = K
     __syncthreads();
     return it;
 }

@@ -269,6 +269,14 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
 // SIMD, which still pays up to ~600 on the bench), two beyond that; other systems use one or two.
 // LQRRT_STEER_WAVEFRONTS=2|3 forces a form (tests/test_fuzz_gpu.py runs the fuzzer with each).
 template <class S> static int steer_wavefronts(int count) {
+    if constexpr (has_dare_gain<S>::value) {
+        // Riccati systems with n >= 6: four wavefronts share the gain (kernels.hpp COOP; boat_novice_lqr +23 %) unless
+        // LQRRT_DARE_WAVEFRONTS=1; at n = 4 the matrix passes fit one wavefront's lanes anyway and the four-wavefront
+        // barriers only cost (pendulum_lqr -10 %, profiles/r04_riccati_ab.txt): one wavefront unless LQRRT_DARE_WAVEFRONTS=4
+        static const int dw = getenv("LQRRT_DARE_WAVEFRONTS") ? atoi(getenv("LQRRT_DARE_WAVEFRONTS")) : 0;
+        (void)count;
+        return dw == 1 ? 1 : (dw == 4 || S::N >= 6) ? 4 : 1;
+    }
     if (steer_wavefronts_max<S>() <= 2) return steer_wavefronts_max<S>();
     static const int forced = getenv("LQRRT_STEER_WAVEFRONTS") ? atoi(getenv("LQRRT_STEER_WAVEFRONTS")) : 0;
     if (forced >= 2 && forced <= 3) return forced;
@@ -285,7 +293,15 @@ template <class S>
 static void launch_steer_kernel(lqrrt_engine* e, int count, size_t lds, hipStream_t st, const EvPair& ev, const double* xs, const int* list,
                                 int lo, const int* par, const int* list_count, const SteerFuse& f, const RoundArgs& ra) {
     const int nwf = steer_wavefronts<S>(count);
-    if constexpr (steer_wavefronts_max<S>() == 1) {
+    if constexpr (has_dare_gain<S>::value) {
+        if (nwf == 4) {
+            if (f.Sd) launch_steer_nwf<S, true, 4>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
+            else launch_steer_nwf<S, false, 4>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
+        } else {
+            if (f.Sd) launch_steer_nwf<S, true, 1>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
+            else launch_steer_nwf<S, false, 1>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
+        }
+    } else if constexpr (steer_wavefronts_max<S>() == 1) {
         if (f.Sd) launch_steer_nwf<S, true, 1>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
         else launch_steer_nwf<S, false, 1>(e, count, lds, st, ev, xs, list, lo, par, list_count, f, ra);
     } else if constexpr (steer_wavefronts_max<S>() == 2) {

@@ -110,18 +110,19 @@ template <class S> struct NoLds {};
 template <class S> using GainLds = std::conditional_t<has_dare_gain<S>::value, DareLds<S::N, S::M>, NoLds<S>>;
 
 // K = lqr(x, u)[1].  Analytic gains are evaluated redundantly by every lane; a Riccati gain is computed by the whole
-// wavefront in LDS (all 64 lanes must call with the same x, u) and then read back by every lane.
-template <class S>
+// workgroup of NT = 64 or 256 threads in LDS (all of them must call with the same x, u; `tid` = thread index in the workgroup)
+// and then read back by every lane.
+template <class S, int NT = 64>
 __device__ __forceinline__ void system_gain(const double* P, const double* x, const double* trig, const double* u, double dt,
-                                            GainLds<S>& L, int lane, double* K) {
+                                            GainLds<S>& L, int tid, double* K) {
     if constexpr (has_dare_gain<S>::value) {
         if constexpr (dare_zero_effort<S>::value) {
             double u0[S::M];
 #pragma unroll
             for (int j = 0; j < S::M; ++j) u0[j] = 0.0;
-            dare_lqr<S>(P, x, u0, P + S::P_Q, P + S::P_R, dt, P[S::P_EPS], 64, 1e-14, L, lane);
+            dare_lqr<S, NT>(P, x, u0, P + S::P_Q, P + S::P_R, dt, P[S::P_EPS], 64, 1e-14, L, tid);
         } else {
-            dare_lqr<S>(P, x, u, P + S::P_Q, P + S::P_R, dt, P[S::P_EPS], 64, 1e-14, L, lane);
+            dare_lqr<S, NT>(P, x, u, P + S::P_Q, P + S::P_R, dt, P[S::P_EPS], 64, 1e-14, L, tid);
         }
 #pragma unroll
         for (int j = 0; j < S::M * S::N; ++j) K[j] = L.Y[j];
@@ -724,10 +725,11 @@ __device__ __forceinline__ void round_decide(const RoundArgs& ra, int cur, const
 //     (erf, K e, dynamics, cos/sin, gain), the second one runs the sequential loop's tests one step behind (one barrier per
 //     step, packets double-buffered by step parity).  Systems opt in (S::TWO_WAVEFRONTS): it pays where the tests are a real
 //     share of a step (car +18 %, boat_novice and the 12-state integrator +2 %), not for the pendulum (no obstacles: -4 %).
-//   * Riccati systems keep one wavefront (their gain uses the whole wavefront).
+//   * Riccati systems run four wavefronts that execute the rollout redundantly and share the gain (dare_lqr<S, 256>, round 4; COOP
+//     in k_steer); LQRRT_DARE_WAVEFRONTS=1 keeps round 3's one wavefront per rollout.
 template <class S, class = void> struct wants_two : std::false_type {};
 template <class S> struct wants_two<S, std::enable_if_t<S::TWO_WAVEFRONTS>> : std::true_type {};
-template <class S> constexpr int steer_wavefronts_max() { return is_packed<S>::value ? 3 : wants_two<S>::value ? 2 : 1; }
+template <class S> constexpr int steer_wavefronts_max() { return has_dare_gain<S>::value ? 4 : is_packed<S>::value ? 3 : wants_two<S>::value ? 2 : 1; }
 struct DuoLds {
     double pk[2 * MAXN + 4 + MAXM];      // two wavefronts (boats): xn | trn | e | u   of the newest step
     double rud;                          //   the heading torque of the step in flight
@@ -893,8 +895,15 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
 #endif
     STEER_TS(0);
     BLK_T(blk_t0);
-    constexpr bool DUO = NWF >= 2;
-    static_assert(NWF <= 2 || is_packed<S>::value, "the chain rollout needs the duo_* / *_effort pieces of the system");
+    // Riccati systems with four wavefronts: every wavefront runs the whole (single-wavefront) kernel redundantly -- the values of a
+    // rollout are uniform, the four of them sit on four SIMDs -- and they share the one stage that has work for 256 lanes, the gain
+    // (dare_lqr<S, 256>).  Stores of the same bits to the same address by all four are harmless; nothing in this path is atomic
+    // (the fused rounds and the sharded hand-over are not instantiated for these systems).
+    constexpr bool COOP = has_dare_gain<S>::value && NWF == 4;
+    constexpr int GNT = COOP ? 256 : 64;                       // threads that compute a gain together
+    constexpr bool DUO = NWF >= 2 && !COOP;
+    static_assert(NWF <= 2 || is_packed<S>::value || COOP, "the chain rollout needs the duo_* / *_effort pieces of the system");
+    static_assert(!has_dare_gain<S>::value || NWF == 1 || NWF == 4, "Riccati systems: one wavefront, or four that share the gain");
     constexpr bool PLAIN2 = NWF == 2 && !is_packed<S>::value;
     extern __shared__ double hist[];
     double* hx = hist;
@@ -1504,7 +1513,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         for (int d = 0; d < S::N; ++d) x[d] = xn[d];
 #pragma unroll
         for (int j = 0; j < 2 * S::NW; ++j) trig[j] = trn[j];
-        system_gain<S>(Pl, x, trig, u, r.dt, gl_lds, lane, K);  // planner.py:436
+        system_gain<S, GNT>(Pl, x, trig, u, r.dt, gl_lds, COOP ? (int)threadIdx.x : lane, K);  // planner.py:436
         STEP_TS(ts3);
         STEP_ACC(2, ts2, ts3); STEP_ACC(3, ts0, ts0 + 1);
     }
@@ -1528,7 +1537,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
                 for (int j = 0; j < 2 * S::NW; ++j) trig[j] = htr[2 * S::NW * (cnt - 1) + j];
             }
             else trig_of<S>(x, trig);
-            system_gain<S>(Pl, x, trig, ul, r.dt, gl_lds, lane, K);   // planner.py:257: lqr(xnew, u_last)
+            system_gain<S, GNT>(Pl, x, trig, ul, r.dt, gl_lds, COOP ? (int)threadIdx.x : lane, K);   // planner.py:257: lqr(xnew, u_last)
         }
         bool in = true;                                          // planner.py:442-447 (strict)
 #pragma unroll

@@ -13,9 +13,12 @@ boat -- 6 states, 3 controls, the metric's dimension -- with the same lqr linear
 (--job bnlqr400; lqrrt_amd.systems.BoatNoviceLqr / oracle.systems_np.BoatNoviceLqr).
 
 Tolerances.  Topology (parents, nearest ids, edge lengths, counts) exact.  The Riccati equation at dt = 1 ms is
-ill-conditioned: SciPy's Schur method and the doubling iteration the oracle / device use agree to ~1e-7 relative on S
-and K (neither is the exact solution), so gains are compared at 2e-5 relative (worst case: samples whose cost-to-go is ~1e11, a nearly uncontrollable linearisation), node states at 1e-7 absolute
-(observed ~1e-10), and HIP against the C oracle -- the same algorithm in the same order -- bit for bit.
+ill-conditioned: SciPy's Schur method and the doubling iteration the oracle / device use agree to ~6e-6 relative on S
+(neither is the exact solution); HIP against the C oracle -- the same algorithm in the same order -- bit for bit.  The
+numerical tolerances below are 10x what is OBSERVED on the three fixtures (round 4; they were round numbers up to 100x
+looser), and test_riccati_decision_margin says how far the two solvers' difference is from changing a decision: it puts
+SciPy's own S (the fixtures' `S_samples`) and the doubling solver's S through every cost-to-go comparison of the reference's
+runs and reports the smallest ratio of cost gap to solver disagreement.
 """
 import os
 
@@ -24,10 +27,15 @@ import pytest
 
 import teacher
 
-K_RTOL = 2e-5
-X_ATOL = 1e-7
-# free-running node states: the two Riccati solvers' ~2e-7 relative difference in K is carried along 400 nodes of saturating
-# thruster dynamics on the boat (observed 3.6e-6, median 3e-8); teacher-forced (one edge at a time) it stays below X_ATOL
+# observed on the fixtures (C oracle and, bit for bit the same, the HIP path) -> tolerance = 10 x observed, rounded up:
+#   |K - K_scipy| / max|K|:   pendulum 1.7e-7,  boat 2.3e-7      (element-wise relative it is 1.8e-6 / 6.7e-5 on the small entries)
+#   |S - S_scipy| / max|S|:   pendulum 6.3e-6,  boat 2.3e-10     (dt = 1 ms vs dt = 0.1 s: the conditioning of the equation)
+#   teacher-forced end state: pendulum 1.5e-8,  boat 1.6e-7
+#   free-running node states: pendulum 1.9e-8 (600 nodes), boat 3.6e-6 (the 2e-7 gain difference carried along 400 nodes of
+#                             saturating thruster dynamics; median 3e-8) -- kept at the tighter values of round 3
+K_TOL = {"pendulum_lqr": 2e-6, "boat_novice_lqr": 2.5e-6}            # x max|K|, absolute
+S_TOL = {"pendulum_lqr": 6.5e-5, "boat_novice_lqr": 2.5e-9}          # x max|S|, absolute
+X_ATOL_TF = {"pendulum_lqr": 1.5e-7, "boat_novice_lqr": 1.6e-6}
 X_ATOL_RUN = {"pendulum_lqr": 1e-7, "boat_novice_lqr": 2e-5}
 
 # (system, fixture tag): the 4-state pendulum at 120 and 600 nodes (the longer run is where a solver that is only accurate to
@@ -73,7 +81,45 @@ def test_c_oracle_riccati_vs_scipy(golden_dir, name, tag):
     for x, S_ref in zip(g["xrand_all"][:60], g["S_samples"][:60]):
         S, _, it = o.lqr(x, np.zeros(o.m))
         assert it < 40
-        np.testing.assert_allclose(S, S_ref, rtol=K_RTOL, atol=K_RTOL * np.abs(S_ref).max())
+        np.testing.assert_allclose(S, S_ref, rtol=0, atol=S_TOL[name] * np.abs(S_ref).max())
+
+
+@pytest.mark.parametrize("name,tag,min_safety", [("pendulum_lqr", "120", 10.0), ("pendulum_lqr", "600", 1.2), ("boat_novice_lqr", "400", 1e5)])
+def test_riccati_decision_margin(golden_dir, name, tag, min_safety):
+    """How close does the difference between the two Riccati solvers come to changing a decision?  For every iteration of the
+    reference's run the cost-to-go of every eligible node of the reference's own tree prefix is formed twice, with SciPy's S about
+    the sample (the fixture's `S_samples`: what the reference compared) and with the doubling solver's S (what the C oracle and
+    the device compare).  Asserted: the arg-min is the same node in every iteration, and it is the reference's.  Reported and
+    bounded from below: the smallest ratio, over all decisions and all competing nodes with a different state, of the cost gap to
+    the winner over the two solvers' disagreement on those two costs -- the factor by which the solver difference would have to
+    grow to flip a decision.  Observed (profiles/r04_riccati_margin.txt): pendulum 120 nodes 21, 600 nodes 1.6 (one decision in
+    600 where a 2.8e-5 relative gap meets a 1.8e-5 disagreement: the dt = 1 ms equation is that ill-conditioned), boat 7e5."""
+    import coracle
+    from systems_np import SYSTEMS
+    g = _fx(golden_dir, name, tag)
+    s, rs = _native(name), SYSTEMS[name](0)
+    sch = teacher.Schedule(g, s.goal, s.goal_buffer)
+    o = coracle.make(s, 16, seed=1)
+    safety, min_gap = np.inf, np.inf
+    for t in range(sch.iters):
+        size = int(sch.size_before[t])
+        ign = sch.ignored_at(size)[:size].astype(bool)
+        x = sch.xrand[t]
+        d = np.array([rs.erf(x, xi) for xi in sch.state[:size]])
+        S_dbl, _, _ = o.lqr(x, np.zeros(o.m))
+        c_ref = np.einsum("ij,jk,ik->i", d, g["S_samples"][t], d)
+        c_dbl = np.einsum("ij,jk,ik->i", d, S_dbl, d)
+        idx = np.flatnonzero(~ign) if (~ign).any() else np.arange(size)
+        w = int(idx[np.argmin(c_ref[idx])])
+        assert w == int(sch.nearest[t]) == int(idx[np.argmin(c_dbl[idx])]), t
+        others = np.array([j for j in idx if j != w and not np.array_equal(d[j], d[w])], dtype=np.int64)   # (equal states tie under any S)
+        if len(others):
+            gap = c_ref[others] - c_ref[w]
+            dis = np.abs(c_dbl[others] - c_ref[others]) + abs(c_dbl[w] - c_ref[w])
+            safety = min(safety, float(np.min(gap / np.maximum(dis, 1e-300))))
+            min_gap = min(min_gap, float(np.min(gap) / max(c_ref[w], 1e-300)))
+    print("%s %s: %d decisions, smallest relative cost gap %.3e, smallest gap / solver disagreement %.3e" % (name, tag, sch.iters, min_gap, safety))
+    assert safety > min_safety
 
 
 @pytest.mark.parametrize("name,tag", CASES)
@@ -90,7 +136,7 @@ def test_c_oracle_vs_reference_run(golden_dir, name, tag):
     np.testing.assert_array_equal(near, g["nearest"])
     np.testing.assert_array_equal(ln, g["steer_len"].astype(np.int32))
     np.testing.assert_allclose(o.states(), g["state"], rtol=0, atol=X_ATOL_RUN[name])
-    np.testing.assert_allclose(o.gains(), g["K"], rtol=K_RTOL, atol=K_RTOL * np.abs(g["K"]).max())
+    np.testing.assert_allclose(o.gains(), g["K"], rtol=0, atol=K_TOL[name] * np.abs(g["K"]).max())
     for t in "abc":
         x, u = o.edge(int(g["edge_%s_id" % t]))
         np.testing.assert_allclose(x, g["edge_%s_x" % t], rtol=0, atol=X_ATOL_RUN[name])
@@ -108,7 +154,7 @@ def test_c_oracle_vs_reference_run(golden_dir, name, tag):
             k, xs, _, Kend = o.steer_from(sch.nearest[t], sch.xrand[t])
             assert k == sch.steer_len[t]
             if k:
-                assert np.abs(xs[-1] - sch.state[sch.new_node[t]]).max() < 5 * X_ATOL
+                assert np.abs(xs[-1] - sch.state[sch.new_node[t]]).max() < X_ATOL_TF[name]
 
 
 @pytest.mark.gpu
@@ -119,7 +165,7 @@ def test_hip_riccati_operator_vs_scipy(golden_dir, name, tag):
     s = _native(name)
     for x, S_ref in zip(g["xrand_all"][:40], g["S_samples"][:40]):
         S, K = s.lqr(x, np.zeros(s.ncontrols))
-        np.testing.assert_allclose(S, S_ref, rtol=K_RTOL, atol=K_RTOL * np.abs(S_ref).max())
+        np.testing.assert_allclose(S, S_ref, rtol=0, atol=S_TOL[name] * np.abs(S_ref).max())
         assert K.shape == (s.ncontrols, s.nstates)
 
 
@@ -143,7 +189,7 @@ def test_hip_vs_reference_run_and_c_oracle(golden_dir, name, tag, wave):
     np.testing.assert_array_equal(np.array(p.tree.pID, dtype=np.int32), g["pID"])
     np.testing.assert_array_equal(p._engine.edge_lengths(), g["edge_len"])
     np.testing.assert_allclose(p.tree.state, g["state"], rtol=0, atol=X_ATOL_RUN[name])
-    np.testing.assert_allclose(p._engine.gains(), g["K"], rtol=K_RTOL, atol=K_RTOL * np.abs(g["K"]).max())
+    np.testing.assert_allclose(p._engine.gains(), g["K"], rtol=0, atol=K_TOL[name] * np.abs(g["K"]).max())
     np.testing.assert_array_equal(np.array(p.node_seq, dtype=np.int32), g["node_seq"])
     np.testing.assert_allclose(np.array(p.x_seq), g["plan_x"], rtol=0, atol=X_ATOL_RUN[name])
     # against the sequential C oracle (same Riccati algorithm in the same order): bit for bit
@@ -170,4 +216,4 @@ def test_hip_teacher_forced(golden_dir, name, tag):
     r = replay_hip(s, sch, kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]), wave=64)
     print(r)
     assert r["nearest_miss"] == 0 and r["steer_len_mismatch"] == 0
-    assert r["end_state_compared"] == len(sch.state) - 1 and r["end_state_max_err"] < 5 * X_ATOL      # (boat: 1.6e-7 observed)
+    assert r["end_state_compared"] == len(sch.state) - 1 and r["end_state_max_err"] < X_ATOL_TF[name]
