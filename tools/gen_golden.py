@@ -153,7 +153,7 @@ def gen_ops(name):
 # --------------------------------------------------------------------------- trajectory level
 
 def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None, horizon=None, pruning=True, tries=10, guide=None,
-             finish_on_goal=False, teacher=False, stable_ties=True):
+             finish_on_goal=False, teacher=False, stable_ties=True, edges_only=False):
     """teacher=True additionally stores EVERY iteration's xrand and tie flag (`xrand_all`, `tie_mask`), which is what the
     teacher-forced parity tests replay decision by decision.  stable_ties=False runs the reference with numpy's own
     (unspecified) argsort tie order, i.e. with nothing patched at all."""
@@ -230,6 +230,24 @@ def run_traj(name, max_nodes, keep_xrand=512, tag=None, min_time=None, horizon=N
         out["edge_%s_x" % tagid] = np.array(tree.x_seq[ID], dtype=np.float64)
         out["edge_%s_u" % tagid] = np.array(tree.u_seq[ID], dtype=np.float64)
     path = os.path.join(OUT, "traj_%s_%s.npz" % (name, tag or str(max_nodes)))
+    if edges_only:
+        # EVERY edge interior of the run (tree.x_seq / u_seq, tree.py:121-132) and the plan's interpolators at 64 times
+        # (planner.py:451-464), in a file of their own next to the traj fixture of the SAME run (asserted)
+        old = np.load(path)
+        assert str(old["pid_hash"]) == str(out["pid_hash"]) and np.array_equal(old["state"], out["state"]), "not the committed run"
+        e = dict(pid_hash=out["pid_hash"], edge_len=edge_len,
+                 x_cat=np.concatenate([np.array(q, dtype=np.float64).reshape(-1, n) for q in tree.x_seq]),
+                 u_cat=np.concatenate([np.array(q, dtype=np.float64).reshape(-1, ns["ncontrols"]) for q in tree.u_seq]))
+        assert len(e["x_cat"]) == int(edge_len.sum())
+        if np.isfinite(planner.T) and planner.T > 0:
+            ts = np.concatenate((np.linspace(0.0, float(planner.T), 60), [-1.0, 1.25 * float(planner.T), 0.5 * planner.dt, float(planner.T) - 1e-9]))
+            e["interp_t"] = ts
+            e["interp_x"] = np.array([planner.get_state(t) for t in ts], dtype=np.float64)
+            e["interp_u"] = np.array([planner.get_effort(t) for t in ts], dtype=np.float64)
+        epath = os.path.join(OUT, "edges_%s_%s.npz" % (name, tag or str(max_nodes)))
+        np.savez_compressed(epath, **e)
+        print("wrote %s: %d edges, %d rows, plan T=%s, %d KB" % (epath, tree.size, len(e["x_cat"]), planner.T, os.path.getsize(epath) // 1024))
+        return
     np.savez_compressed(path, **out)
     print("wrote %s: iters=%d cand=%d nodes=%d hash=%s sum=%r goal=%s ties=%d wall=%.1fs" % (
         path, iters, n_candidates, tree.size, out["pid_hash"], float(out["state_sum"]),
@@ -509,6 +527,24 @@ def gen_riccati(name, max_nodes, tag=None):
         out["edge_%s_x" % tagid] = np.array(tree.x_seq[ID], dtype=np.float64)
         out["edge_%s_u" % tagid] = np.array(tree.u_seq[ID], dtype=np.float64)
     path = os.path.join(OUT, "traj_%s_%s.npz" % (name, tag or str(max_nodes)))
+    if edges_only:
+        # EVERY edge interior of the run (tree.x_seq / u_seq, tree.py:121-132) and the plan's interpolators at 64 times
+        # (planner.py:451-464), in a file of their own next to the traj fixture of the SAME run (asserted)
+        old = np.load(path)
+        assert str(old["pid_hash"]) == str(out["pid_hash"]) and np.array_equal(old["state"], out["state"]), "not the committed run"
+        e = dict(pid_hash=out["pid_hash"], edge_len=edge_len,
+                 x_cat=np.concatenate([np.array(q, dtype=np.float64).reshape(-1, n) for q in tree.x_seq]),
+                 u_cat=np.concatenate([np.array(q, dtype=np.float64).reshape(-1, ns["ncontrols"]) for q in tree.u_seq]))
+        assert len(e["x_cat"]) == int(edge_len.sum())
+        if np.isfinite(planner.T) and planner.T > 0:
+            ts = np.concatenate((np.linspace(0.0, float(planner.T), 60), [-1.0, 1.25 * float(planner.T), 0.5 * planner.dt, float(planner.T) - 1e-9]))
+            e["interp_t"] = ts
+            e["interp_x"] = np.array([planner.get_state(t) for t in ts], dtype=np.float64)
+            e["interp_u"] = np.array([planner.get_effort(t) for t in ts], dtype=np.float64)
+        epath = os.path.join(OUT, "edges_%s_%s.npz" % (name, tag or str(max_nodes)))
+        np.savez_compressed(epath, **e)
+        print("wrote %s: %d edges, %d rows, plan T=%s, %d KB" % (epath, tree.size, len(e["x_cat"]), planner.T, os.path.getsize(epath) // 1024))
+        return
     np.savez_compressed(path, **out)
     print("wrote %s: iters=%d cand=%d nodes=%d hash=%s goal=%s wall=%.1fs" % (
         path, len(nearest), out["n_candidates"], tree.size, out["pid_hash"], bool(planner.plan_reached_goal), wall))
@@ -527,6 +563,9 @@ def main():
         # every iteration's xrand next to nearest / steer_len: input of the teacher-forced parity tests
         "adv10k": lambda: run_traj("boat_advanced", 10000, keep_xrand=64, tag="10k", teacher=True),
         "adv3000": lambda: run_traj("boat_advanced", 3000, keep_xrand=64, teacher=True),
+        # every edge interior + the interpolators of runs whose traj fixture is committed (same run, asserted)
+        "edges_adv3000": lambda: run_traj("boat_advanced", 3000, keep_xrand=64, teacher=True, edges_only=True),
+        "edges_car2000": lambda: run_traj("car", 2000, keep_xrand=64, teacher=True, edges_only=True),
         "car500t": lambda: run_traj("car", 500, teacher=True),
         "car2000t": lambda: run_traj("car", 2000, keep_xrand=64, teacher=True),
         "pend150t": lambda: run_traj("pendulum", 150, teacher=True),
