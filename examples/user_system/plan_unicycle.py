@@ -16,8 +16,8 @@ if "LQRRT_LIB" not in os.environ and os.path.exists(_here):
 import lqrrt_amd as lqrrt
 
 
-def make_system():
-    rs = np.random.RandomState(0)
+def make_system(obstacle_seed=0):
+    rs = np.random.RandomState(obstacle_seed)
     centres = rs.uniform(8, 42, (24, 2))
     radius = 0.6                                                   # the vehicle is a disc: inflate the obstacles by its radius
     obs = np.hstack((centres, np.full((24, 1), 1.5 + radius)))

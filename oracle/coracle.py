@@ -45,6 +45,28 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class _UserModel(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("nw", C.c_int), ("wd", C.c_int * 2),
+                ("gain", C.c_void_p), ("step", C.c_void_p), ("feasible", C.c_void_p)]
+
+
+_user_libs = []
+
+
+def use_user_model(path):
+    """Registers the host build of an out-of-tree problem (tools/build_user_system.py --oracle) as the oracle's model 100
+    (LQRRT_MODEL_USER): the callbacks are the engine's own header, the sequential loop is oracle/lqrrt_oracle.c's."""
+    u = C.CDLL(path)
+    _user_libs.append(u)                                    # keep it loaded: the oracle calls into it
+    n, m, nw = C.c_int(), C.c_int(), C.c_int()
+    wd = (C.c_int * 2)()
+    u.lq_user_dims(C.byref(n), C.byref(m), C.byref(nw), wd)
+    um = _UserModel(n.value, m.value, nw.value, wd, C.cast(u.lq_user_gain, C.c_void_p), C.cast(u.lq_user_step, C.c_void_p),
+                    C.cast(u.lq_user_feasible, C.c_void_p))
+    lib().orc_register_user(C.byref(um))
+    return n.value, m.value
+
+
 def _f(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 

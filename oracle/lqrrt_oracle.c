@@ -28,7 +28,22 @@
 #define MAXN 12
 #define MAXM 6
 
-enum { BOAT_ADV = 1, BOAT_INT = 2, BOAT_NOV = 3, CAR = 4, PEND = 5, DINT = 6, ROS_BOAT = 7, PEND_LQR = 8, BOAT_NOV_LQR = 9 };
+enum { BOAT_ADV = 1, BOAT_INT = 2, BOAT_NOV = 3, CAR = 4, PEND = 5, DINT = 6, ROS_BOAT = 7, PEND_LQR = 8, BOAT_NOV_LQR = 9, USER = 100 };
+
+/* An out-of-tree problem (LQRRT_MODEL_USER): its three callbacks are the SAME header the engine was
+ * built with, compiled for the host by tools/build_user_system.py --oracle (oracle/user_model_shim.cpp) and registered here
+ * before orc_create(USER, ...).  The sequential loop around them is this file's, so a user's problem gets the bit-for-bit net
+ * every built-in system has. */
+typedef struct {
+    int n, m, nw, wd[2];
+    void (*gain)(const double* P, const double* x, const double* trig, const double* u, double* K);
+    void (*step)(const double* P, const double* x, const double* trig, double* u, double dt, double* xn);
+    int (*feasible)(const double* P, const double* vps, int V, const double* obs, int O, int stride, const double* x, const double* u,
+                    const double* trig);
+} orc_user_model;
+static orc_user_model g_user;
+static int g_user_set = 0;
+void orc_register_user(const orc_user_model* m) { g_user = *m; g_user_set = 1; }
 #define RICCATI(o) ((o)->model == PEND_LQR || (o)->model == BOAT_NOV_LQR)
 
 typedef struct {
@@ -260,6 +275,7 @@ static void gain(const orc* o, const double* x, const double* tr, const double* 
             return;
         case PEND: K[0] = P[14]; K[1] = P[15]; K[2] = P[16]; K[3] = P[17]; return;
         case DINT: for (int j = 0; j < 72; ++j) K[j] = P[1 + j]; return;
+        case USER: g_user.gain(P, x, tr, u, K); return;
     }
     K[0] = kp[0] * c;    K[1] = kp[0] * s;    K[2] = kp[0] * 0.0;  K[3] = kd[0];  K[4] = 0.0;   K[5] = 0.0;
     K[6] = kp[1] * (-s); K[7] = kp[1] * c;    K[8] = kp[1] * 0.0;  K[9] = 0.0;    K[10] = kd[1]; K[11] = 0.0;
@@ -413,6 +429,7 @@ static void step(const orc* o, const double* x, const double* tr, double* u, dou
             const double h = P[0];
             for (int i = 0; i < 6; ++i) { xn[i] = x[i] + h * x[6 + i]; xn[6 + i] = x[6 + i] + h * u[i]; }
         } break;
+        case USER: g_user.step(P, x, tr, u, dt, xn); break;
     }
 }
 
@@ -448,6 +465,7 @@ static int feasible(const orc* o, const double* x, const double* u, const double
                 if (x[0] >= b[0] && x[0] <= b[3] && x[1] >= b[1] && x[1] <= b[4] && x[2] >= b[2] && x[2] <= b[5]) return 0;
             }
             return 1;
+        case USER: return g_user.feasible(P, o->vps, o->V, o->obs, o->O, o->stride, x, u, tr);
     }
     return 1;
 }
@@ -468,6 +486,10 @@ orc* orc_create(int model, const double* params, int n_params, const double* vps
         case PEND_LQR:
         case PEND: o->n = 4; o->m = 1; o->nw = 2; o->wd[0] = 0; o->wd[1] = 1; break;
         case DINT: o->n = 12; o->m = 6; o->nw = 0; break;
+        case USER:
+            if (!g_user_set) { free(o); return 0; }
+            o->n = g_user.n; o->m = g_user.m; o->nw = g_user.nw; o->wd[0] = g_user.wd[0]; o->wd[1] = g_user.wd[1];
+            break;
         default: free(o); return 0;
     }
     memcpy(o->P, params, sizeof(double) * n_params);

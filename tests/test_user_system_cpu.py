@@ -55,3 +55,38 @@ def test_user_system_host_description():
     with pytest.raises(ValueError):
         import lqrrt_amd
         lqrrt_amd.Planner(lambda x, u, dt: x, s.lqr, lqrrt_amd.Constraints(4, 2, s.goal_buffer, s.is_feasible), horizon=2)
+
+
+USER_ORACLE = os.path.join(ROOT, "examples", "user_system", "liblqrrt_unicycle_oracle.so")
+
+
+def test_user_system_gets_a_sequential_oracle():
+    """The same header compiled for the host (tools/build_user_system.py --oracle) drives the sequential C oracle: the
+    out-of-tree problem plans on CPU, its edges re-simulate with its own dynamics callback and its states are feasible under its
+    own is_feasible (64 lanes emulated one after the other).  The GPU suite then asserts HIP == this oracle bit for bit
+    (tests/test_user_system_gpu.py), the net every built-in system has."""
+    assert os.path.exists(USER_ORACLE), "examples/user_system/liblqrrt_unicycle_oracle.so missing: __graft_entry__.build() makes it"
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import coracle, plan_unicycle
+assert coracle.use_user_model(%r) == (4, 2)
+s = plan_unicycle.make_system()
+o = coracle.make(s, 400, seed=1)
+o.extend(max_nodes=400)
+assert o.size == 401 and o.parents()[0] == -1
+st, pid = o.states(), o.parents()
+for i in range(1, o.size, 5):
+    xs, us = o.edge(i)
+    assert 1 <= len(xs) <= 20 and np.array_equal(xs[-1], st[i])
+    prev = np.vstack((st[pid[i]][None, :], xs[:-1]))
+    for a, u, b in zip(prev, us, xs):
+        assert np.array_equal(o.dynamics(a, u), b)
+        assert o.feasible(b, u)
+centres = s.obs
+d = np.sqrt(((st[:, None, :2] - centres[None, :, :2]) ** 2).sum(-1))
+assert np.all(d[1:] > centres[None, :, 2])                 # no node inside an (inflated) obstacle
+print("OK", o.iterations, o.hits)
+""" % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "examples", "user_system"), USER_ORACLE)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]

@@ -24,9 +24,25 @@ def build(header, out):
     return os.path.abspath(out)
 
 
+def build_oracle(header, out):
+    """The same header compiled for the host (g++, oracle/user_model_shim.cpp): the callbacks the sequential C oracle calls for
+    LQRRT_MODEL_USER (oracle/coracle.use_user_model), so that an out-of-tree problem is checked bit for bit like the built-in ones."""
+    header = os.path.abspath(header)
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-fPIC", "-shared",
+           "-DLQRRT_USER_SYSTEM=\"%s\"" % header, os.path.join(ROOT, "oracle", "user_model_shim.cpp"), "-o", os.path.abspath(out), "-lm"]
+    subprocess.check_call(cmd)
+    return os.path.abspath(out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("header")
-    ap.add_argument("-o", "--out", required=True)
+    ap.add_argument("-o", "--out", default=None, help="the engine with the problem compiled in (hipcc, ~1.5 min)")
+    ap.add_argument("--oracle", default=None, help="also / only: the host build of the same header for the sequential C oracle")
     a = ap.parse_args()
-    print(build(a.header, a.out))
+    if not a.out and not a.oracle:
+        ap.error("give -o and / or --oracle")
+    if a.out:
+        print(build(a.header, a.out))
+    if a.oracle:
+        print(build_oracle(a.header, a.oracle))

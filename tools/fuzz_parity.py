@@ -12,6 +12,12 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 
 NAMES = ["boat_advanced", "boat_intermediate", "boat_novice", "car", "double_integrator", "ros_boat", "pendulum"]
+# FUZZ_USER=<oracle build of the user header>: fuzz the out-of-tree example instead (examples/user_system/unicycle.hpp; the engine
+# with it compiled in comes through LQRRT_LIB, the oracle's callbacks through tools/build_user_system.py --oracle)
+USER_ORACLE = os.environ.get("FUZZ_USER")
+if USER_ORACLE:
+    NAMES = ["user"]
+    sys.path.insert(0, os.path.join(ROOT, "examples", "user_system"))
 
 
 def draw_case(rng, rng2, names=None, rng3=None):
@@ -20,7 +26,11 @@ def draw_case(rng, rng2, names=None, rng3=None):
     import lqrrt_amd
     names = names or NAMES
     name = names[rng.randint(len(names))]
-    if name == "double_integrator":
+    if name == "user":
+        import coracle, plan_unicycle
+        coracle.use_user_model(USER_ORACLE)
+        s = plan_unicycle.make_system(int(rng.randint(4)))
+    elif name == "double_integrator":
         s = lqrrt_amd.systems.DoubleIntegrator(n_boxes=int(rng.choice([50, 2000, 20000])), seed=int(rng.randint(5)))
     elif name == "ros_boat":
         s = lqrrt_amd.systems.RosBoat(str(rng.choice(["boat", "car", "escape"])), focus=[12.0, -3.0] if rng.rand() < 0.3 else None)
@@ -203,5 +213,5 @@ if __name__ == "__main__":
     bad = run(cases, seed, only, os.environ.get("FUZZ_WAVE"))
     for k, d in bad:
         print("MISMATCH case", k, d)
-    print("cases %d mismatches %d in %.1f s" % (cases, len(bad), time.time() - t0))
+    print("cases %d mismatches %d in %.1f s%s" % (cases, len(bad), time.time() - t0, " (user system)" if USER_ORACLE else ""))
     sys.exit(1 if bad else 0)
