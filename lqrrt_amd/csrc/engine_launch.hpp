@@ -188,6 +188,12 @@ static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
     *n_chunks = std::max(1, (count + c - 1) / c);
 }
 
+// When the two-level scan is the default (LQRRT_NN_WG4 overrides): decided by the A/B of round 4 (profiles/r04_ab_wg4.txt)
+static bool nn_wg4_default(int W, int count) {
+    (void)W; (void)count;
+    return false;
+}
+
 // NN over a node table for W samples at xs (device, [W][n]); writes id/cost and/or records.
 // the scan variants that can take an IgnPatch (the generic identity / dense-S ones; not the structured-S and per-sample-S forms)
 static bool scan_takes_patch(const lqrrt_engine* e) {
@@ -207,6 +213,14 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     int chunk, n_chunks;
     if (tri) { chunk = tri_chunk(); n_chunks = (nv.count + chunk - 1) / chunk; }   // in-wave pass: the reduction is fused into k_decide
     else pick_chunks(nv.count, W, &chunk, &n_chunks);
+    // two-level reduction (kernels.hpp k_nn_scan WPB = 4): four wavefronts per workgroup, one partial per four chunks
+    static const int wg4_env = getenv("LQRRT_NN_WG4") ? atoi(getenv("LQRRT_NN_WG4")) : -1;
+    const int sm_pre = Spers ? -1 : (!(Sd ? Sd : e->d_S) ? S_IDENT : (Sd ? S_DENSE : e->smode));
+    const bool wg4_has = !tri && !(patch && patch->n > 0) && !Spers &&
+                         (sm_pre == S_IDENT || sm_pre == S_DENSE || (sm_pre == S_BAND2 && e->model == LQRRT_MODEL_DOUBLE_INTEGRATOR));
+    const bool wg4 = wg4_has && n_chunks >= 8 && (wg4_env >= 0 ? wg4_env != 0 : nn_wg4_default(W, nv.count));
+    const int n_sub = n_chunks;
+    if (wg4) n_chunks = (n_sub + 3) / 4;
     if (n_chunks_out) *n_chunks_out = n_chunks;
     dim3 grid((W + 63) / 64, n_chunks);
     const double* S_use = Spers ? Spers : (Sd ? Sd : e->d_S);
@@ -219,6 +233,9 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     if (profile) prof_begin(e, st, &ev, 0);
 #define NN_LAUNCH(DENSE, TRI)                                                                            \
     DISPATCH(e, hipExtLaunchKernelGGL((k_nn_scan<S, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
+                                      e->d_pcost, e->d_pidx, ps_c, ps_t, pt))
+#define NN_LAUNCH4(DENSE)                                                                                \
+    DISPATCH(e, hipExtLaunchKernelGGL((k_nn_scan<S, DENSE, false, false, 4>), grid, dim3(256), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
                                       e->d_pcost, e->d_pidx, ps_c, ps_t, pt))
     // (the instantiation that looks at the patch is a launch of its own: the scan's inner loop lives at the SGPR limit, and the
     //  plain one must not pay for what two launches in three do not need)
@@ -235,16 +252,20 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
         if (!e->riccati) return fail(LQRRT_E_ARG, "per-sample S is only instantiated for Riccati systems");
         DISPATCH(e, if constexpr (has_dare_gain<S>::value) { if (tri) NN_ONE(S, S_PERSAMPLE, true); else NN_ONE(S, S_PERSAMPLE, false); });
     } else if (sm == S_BAND2 && e->model == LQRRT_MODEL_DOUBLE_INTEGRATOR) {
-        if (tri) NN_ONE(DoubleIntegratorT<6>, S_BAND2, true); else NN_ONE(DoubleIntegratorT<6>, S_BAND2, false);
+        if (tri) NN_ONE(DoubleIntegratorT<6>, S_BAND2, true);
+        else if (wg4) hipExtLaunchKernelGGL((k_nn_scan<DoubleIntegratorT<6>, S_BAND2, false, false, 4>), grid, dim3(256), 0, st, ev.a, ev.b, 0,
+                                            nv, xs, xtrig, W, S_use, chunk, e->d_pcost, e->d_pidx, ps_c, ps_t, pt);
+        else NN_ONE(DoubleIntegratorT<6>, S_BAND2, false);
     } else if (sm == S_DIAG && e->model == LQRRT_MODEL_ROS_BOAT) {
         if (tri) NN_ONE(RosBoat, S_DIAG, true); else NN_ONE(RosBoat, S_DIAG, false);
     } else if (S_use) {
-        if (tri) { NN_LAUNCH(S_DENSE, true); } else if (pt.n > 0) { NN_LAUNCH_PATCH(S_DENSE); } else { NN_LAUNCH(S_DENSE, false); }
+        if (tri) { NN_LAUNCH(S_DENSE, true); } else if (pt.n > 0) { NN_LAUNCH_PATCH(S_DENSE); } else if (wg4) { NN_LAUNCH4(S_DENSE); } else { NN_LAUNCH(S_DENSE, false); }
     } else {
-        if (tri) { NN_LAUNCH(S_IDENT, true); } else if (pt.n > 0) { NN_LAUNCH_PATCH(S_IDENT); } else { NN_LAUNCH(S_IDENT, false); }
+        if (tri) { NN_LAUNCH(S_IDENT, true); } else if (pt.n > 0) { NN_LAUNCH_PATCH(S_IDENT); } else if (wg4) { NN_LAUNCH4(S_IDENT); } else { NN_LAUNCH(S_IDENT, false); }
     }
 #undef NN_ONE
 #undef NN_LAUNCH
+#undef NN_LAUNCH4
 #undef NN_LAUNCH_PATCH
     if (profile) prof_end(e, st, &ev, 0, (double)W * (double)nv.count * (8.0 * e->n + 1.0));
     if (tri || defer_reduce) { HIPCHK(hipGetLastError()); return 0; }     // deferred: the steer launch reduces (SteerFuse)

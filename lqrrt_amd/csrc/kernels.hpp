@@ -208,12 +208,17 @@ __device__ __forceinline__ double quad_cost(const double* e, const double* Sd) {
 // chunk-major (ps_t = 1), the order k_decide wants.
 // xtrig: cos/sin of the samples' angular coordinates [W][2*NW] if the caller has them (the engine computes them once
 // per sample batch), else null and they are computed here.
-template <class S, int DENSE, bool TRI, bool PATCH = false>
-__global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __restrict__ xs, const double* __restrict__ xtrig,
+// WPB = 4 (round 4, two-level reduction; LQRRT_NN_WG4): four wavefronts per workgroup scan four consecutive chunks and reduce
+// their minima through LDS, so a sample gets ONE partial per four chunks: a quarter of the scattered 12-byte stores (each of
+// them a 64-byte transaction: 58 % of the scan's physical traffic, profiles/r03_nn_traffic.json) and a quarter of the partials
+// the steer prologue has to read back.  Chunks ascend in node id, the combination keeps the (cost, id) order.
+template <class S, int DENSE, bool TRI, bool PATCH = false, int WPB = 1>
+__global__ __launch_bounds__(64 * WPB) void k_nn_scan(NodeView nv, const double* __restrict__ xs, const double* __restrict__ xtrig,
                                                 int W, const double* __restrict__ Sd, int chunk,
                                                 double* __restrict__ pcost, int* __restrict__ pidx,
                                                 int ps_c, int ps_t, IgnPatch pt) {
-    const int lane = threadIdx.x;
+    static_assert(WPB == 1 || (!PATCH && !TRI), "the four-wavefront form exists for the plain tree scan");
+    const int lane = threadIdx.x & 63;
     // patch entry k lives in lane k (and k + 16, ...): one vector load each, issued with the launch's first loads -- the
     // argument block is not in any cache yet, and a lookup that went back to it per tile cost the launch ~2 us
     int pt_idx = -1;
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
     }
     const int t = bx * 64 + lane;
     const int ts = t < W ? t : W - 1;
-    const int i0 = nv.first + by * chunk;
+    const int i0 = nv.first + (by * WPB + (int)(threadIdx.x >> 6)) * chunk;
     int i1 = i0 + chunk;
     if (i1 > nv.first + nv.count) i1 = nv.first + nv.count;
     if constexpr (TRI) {
@@ -407,6 +412,20 @@ __global__ __launch_bounds__(64) void k_nn_scan(NodeView nv, const double* __res
     if (mode == 2) scan(std::integral_constant<int, 2>{});
     else if (mode == 1) scan(std::integral_constant<int, 1>{});
     else scan(std::integral_constant<int, 0>{});
+    if constexpr (WPB > 1) {
+        __shared__ double rc[WPB][64];
+        __shared__ int ri[WPB][64];
+        const int wv = threadIdx.x >> 6;
+        rc[wv][lane] = best; ri[wv][lane] = bidx;
+        __syncthreads();
+        if (wv != 0) return;
+#pragma unroll
+        for (int w = 1; w < WPB; ++w) {                          // ascending chunks: strict '<' keeps the lowest id among equal costs
+            const double oc = rc[w][lane];
+            const int oi = ri[w][lane];
+            if (oi >= 0 && (bidx < 0 || oc < best)) { best = oc; bidx = oi; }
+        }
+    }
     if (t < W) {
         const size_t o = (size_t)by * ps_c + (size_t)t * ps_t;
         pcost[o] = best; pidx[o] = bidx;
