@@ -14,7 +14,7 @@ import bench
 def worker(idx, seed, steps, barrier, out):
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        boat, eng = bench.build_problem(10000, 1024, 0, seed=seed)
+        boat, eng = bench.build_problem("cfg4", 10000, 1024, 0, seed=seed)
         eng.extend(1024, until_size=9500)
         eng.tree_mark()
         barrier.wait()
