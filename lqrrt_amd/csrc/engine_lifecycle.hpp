@@ -50,8 +50,11 @@ static int alloc_wave(lqrrt_engine* e) {
     e->tv.H = e->H;
     TRY(dalloc(&e->tv.xedge, (size_t)e->cap * e->H * e->n));
     TRY(dalloc(&e->tv.uedge, (size_t)e->cap * e->H * e->m));
-    TRY(dalloc(&e->d_rec, (size_t)e->maxW * e->L.R));
-    HIPCHK(hipMemset(e->d_rec, 0, (size_t)e->maxW * e->L.R * sizeof(double)));
+    // (+ 4 records: the in-wave scan fetches record slots four at a time, k_nn_scan<TRI> `fetch`, and reads up to three slots past
+    //  the last record of the wave -- never visited, but they have to be mapped: a wave of one sample on an engine built for
+    //  max_wave = 1 faulted once the allocator placed the buffer at the end of a mapping (round 4, tools/fuzz_parity.py 60 12 33))
+    TRY(dalloc(&e->d_rec, (size_t)(e->maxW + 4) * e->L.R));
+    HIPCHK(hipMemset(e->d_rec, 0, (size_t)(e->maxW + 4) * e->L.R * sizeof(double)));
     return 0;
 }
 
