@@ -129,7 +129,14 @@ static double shard_tail_fraction() {
 // [rank * per, ...) of the W samples with its block as the second destination (ShardOut); this gathers the blocks -- in
 // place: the rank's own block is its chunk of the receive buffer -- and unpacks the other ranks' samples into the local
 // records, prepared for the repair rounds (k_shard_unpack_prep).  Payload per rank: per * (header + 1) + tail doubles.
-static int allgather_nodes(lqrrt_engine* e, lqrrt_comm* c, int W, int per, int hd, int tb, hipStream_t st) {
+// Will the commit of a gathered wave of W samples run the fused rounds (engine_wave.hpp commit_impl, same predicate)?  Then the
+// unpack launch is not needed: round 0 takes every sample out of the blocks itself (kernels.hpp RoundArgs::gblk).
+static bool gathered_wave_fuses(const lqrrt_engine* e, int W) {
+    static const bool fold = [] { const char* v = getenv("LQRRT_SHARD_FOLD"); return !(v && atoi(v) == 0); }();
+    return fold && e->wave_matrix && !e->sync_mode && fused_rounds_enabled() && (int64_t)e->N + W <= (int64_t)e->cap && W <= 256;
+}
+
+static int allgather_nodes(lqrrt_engine* e, lqrrt_comm* c, int W, int per, int hd, int tb, hipStream_t st, bool may_fold = false) {
     const size_t blk = (size_t)per * hd + tb;
     if (c->kind == LQRRT_COMM_RCCL && !c->nccl) return fail(LQRRT_E_STATE, "the communicator was aborted after a rank failed");
     if (c->kind == LQRRT_COMM_RCCL && c->world > 1) {
@@ -137,6 +144,12 @@ static int allgather_nodes(lqrrt_engine* e, lqrrt_comm* c, int W, int per, int h
     } else if (c->kind == LQRRT_COMM_RCCL) {
         // world of one: still a real collective on the stream (what bench.py's forced-sharded mode times)
         NCCLCHK(rccl()->AllGather(e->d_blk, e->d_blk, blk * sizeof(double), 1, c->nccl, st));
+    }
+    e->gath_pending = false;
+    if (may_fold && gathered_wave_fuses(e, W)) {
+        e->gath_pending = true;
+        e->gath_stride = (long long)blk; e->gath_hd = hd; e->gath_per = per; e->gath_rank = c->rank;
+        return 0;
     }
     const double* xs = wave_samples(e);
     const double* xtr = wave_sample_trig(e);
@@ -152,7 +165,7 @@ static int allgather_nodes(lqrrt_engine* e, lqrrt_comm* c, int W, int per, int h
     return 0;
 }
 
-static int sample_sharded_wave(lqrrt_engine* e, lqrrt_comm* c, int W, hipStream_t st) {
+static int sample_sharded_wave(lqrrt_engine* e, lqrrt_comm* c, int W, hipStream_t st, bool may_fold = false) {
     const int G = c->world;
     const int per = (W + G - 1) / G;
     const int hd = e->L.off_xseq + 1;
@@ -183,7 +196,7 @@ static int sample_sharded_wave(lqrrt_engine* e, lqrrt_comm* c, int W, hipStream_
         }
     }
     e->wave_complete = false;
-    TRY(allgather_nodes(e, c, W, per, hd, tb, st));
+    TRY(allgather_nodes(e, c, W, per, hd, tb, st, may_fold));
     e->wave_prepared = true;
     return 0;
 }
@@ -252,7 +265,7 @@ extern "C" int lqrrt_engine_extend_sharded(lqrrt_engine* e, lqrrt_comm* c, int s
         lqrrt_extend_stats ws;
         int rc;
         if (scheme == LQRRT_SHARD_SAMPLES) {
-            rc = sample_sharded_wave(e, c, W, st);
+            rc = sample_sharded_wave(e, c, W, st, true);
             if (rc == 0) rc = commit_impl(e, W, cap_attempts, lim, pruning, &ws, stream, true);
         } else {
             rc = tree_sharded_wave(e, c, W, st);

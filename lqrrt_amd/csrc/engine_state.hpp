@@ -110,6 +110,10 @@ struct lqrrt_engine {
     bool spec_fusable = false;    // the last speculative launch prepared buffer 0 of the fused rounds
     // sample-/tree-sharded waves (lqrrt_engine_extend_sharded): the ranks' all-gather blocks, the tail cursor of this rank's
     bool wave_prepared = false;   // the records of the current wave came through lqrrt_allgather_nodes (k_shard_unpack_prep)
+    // ... or are still in the all-gather blocks: the first fused round takes them out itself (RoundArgs::gblk, round 4)
+    bool gath_pending = false;
+    long long gath_stride = 0;
+    int gath_hd = 0, gath_per = 0, gath_rank = 0;
     double* d_blk = nullptr;
     size_t blk_cap = 0;           // doubles
     int* d_blk_cursor = nullptr;

@@ -274,6 +274,9 @@ static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_
     const bool fused = mat && ((e->wave_complete && e->spec_fusable) || prepared) && !e->sync_mode && fused_rounds_enabled() &&
                        (int64_t)e->N + W <= (int64_t)e->cap && W <= 256;      // (the round prologue keeps 4 x 64 samples' flags in registers)
     e->spec_fusable = false;
+    const bool gathered = e->gath_pending;                 // the samples are still in the all-gather blocks: round 0 unpacks
+    e->gath_pending = false;
+    if (gathered && !fused) return fail(LQRRT_E_STATE, "a gathered wave without its unpack launch must run the fused rounds");
     if (mat && !e->wave_complete && !prepared) {
         if (e->d_S) { DISPATCH(e, hipLaunchKernelGGL((k_wave_rows<S, true>), dim3(W), dim3(64), 0, st, e->d_rec, e->L, xs, e->d_S, e->d_M, W)); }
         else { DISPATCH(e, hipLaunchKernelGGL((k_wave_rows<S, false>), dim3(W), dim3(64), 0, st, e->d_rec, e->L, xs, nullptr, e->d_M, W)); }
@@ -304,6 +307,12 @@ static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_
         qf.M = nullptr;
         auto enqueue = [&](int r) -> int {
             ra.round = r; ra.seq = ++e->seq;
+            if (gathered && r == 0) {
+                ra.gblk = e->d_blk; ra.gstride = e->gath_stride; ra.ghd = e->gath_hd; ra.gper = e->gath_per; ra.grank = e->gath_rank;
+                ra.gcursor = e->d_blk_cursor;
+            } else {
+                ra.gblk = nullptr; ra.gcursor = nullptr;
+            }
             return launch_steer(e, xs, nullptr, 0, W, nullptr, st, nullptr, &qf, &ra);
         };
         TRY(enqueue(0));

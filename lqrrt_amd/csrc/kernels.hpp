@@ -678,7 +678,16 @@ struct RoundArgs {
     int* host_ctrl;                      // pinned: as k_decide's ctrl
     int* host_summary;                   // pinned: len, flags, parent per sample (converged round only)
     FixedAngles fx;
+    // Round 0 of a GATHERED wave (sample-sharded, lqrrt_engine_extend_sharded; round 4): the ranks' all-gather blocks instead of
+    // the buffers a speculative launch of the whole wave would have prepared -- every workgroup takes its own sample out of the
+    // blocks (what k_shard_unpack_prep did in a launch of its own) and decides from the HEADERS: they were complete before this
+    // launch began, so no workgroup reads what another one writes.  gblk == null: an ordinary round.
+    const double* gblk; long long gstride; int ghd, gper, grank; int* gcursor;
 };
+// header of sample s of a gathered wave: the record up to the edges + one word, where its edge lies in its block's tail
+__device__ __forceinline__ const double* gathered_header(const RoundArgs& ra, int s) {
+    return ra.gblk + (size_t)(s / ra.gper) * ra.gstride + (size_t)(s % ra.gper) * ra.ghd;
+}
 // One 64-bit word per round parity counts the workgroups that are through (bits 0-15), those that re-steered (16-31) and those
 // that deferred (32-47): every workgroup adds its share with ONE atomic when it is done, and the value the last one gets back
 // is the round's result -- no second round trip for the counts, and no fences: a workgroup reads nothing that another
@@ -833,8 +842,9 @@ __device__ unsigned long long g_pro_acc[16];        // prologue of rolling workg
 // The last workgroup to add its share to the round's word closes the round: counts to the host and, in a converged round,
 // ranks and the committed prefix for the append.  One wavefront (the helpers wait at barrier S or are gone): no workgroup
 // barrier in here.  (A function, not a lambda: a closure that is not scalarised costs the kernel a stack frame.)
-__device__ __forceinline__ void close_round(const RoundArgs& ra, int lane, unsigned long long round_before, unsigned long long round_share) {
+__device__ __forceinline__ void close_round(const RoundArgs& ra, const RecLayout& L, int lane, unsigned long long round_before, unsigned long long round_share) {
     const int cur = ra.round & 1, nxt = cur ^ 1;
+    const bool g0 = ra.gblk != nullptr;
     unsigned long long* word_r = (unsigned long long*)(ra.ctl + RC_PACK) + cur;
     const unsigned long long before_me = ((unsigned long long)(unsigned)__shfl((int)(round_before >> 32), 0) << 32) |
                                          (unsigned)__shfl((int)round_before, 0);
@@ -851,13 +861,15 @@ __device__ __forceinline__ void close_round(const RoundArgs& ra, int lane, unsig
             for (int c0 = 0; c0 < ra.W; c0 += 64) {
                 const int tt = c0 + lane;
                 const bool in = tt < ra.W;
-                const int len = in ? lfn[2 * tt] : 0, flg = in ? lfn[2 * tt + 1] : 0;
+                const double* hh = (g0 && in) ? gathered_header(ra, tt) : nullptr;
+                const int len = in ? (g0 ? (int)hh[L.off_len] : lfn[2 * tt]) : 0, flg = in ? (g0 ? (int)hh[L.off_flags] : lfn[2 * tt + 1]) : 0;
                 const bool a = len > 0;
                 const unsigned long long A = __ballot(a);
                 const int mine = before + __popcll(A & ((1ull << lane) - 1ull));      // accepted before sample tt
                 if (in) {
                     ra.rank[tt] = mine;
-                    ra.host_summary[tt] = len; ra.host_summary[ra.W + tt] = flg; ra.host_summary[2 * ra.W + tt] = ra.par[cur][tt];
+                    ra.host_summary[tt] = len; ra.host_summary[ra.W + tt] = flg;
+                    ra.host_summary[2 * ra.W + tt] = g0 ? (int)hh[L.off_parent] : ra.par[cur][tt];
                     if (a && (flg & 1)) first_hit = min(first_hit, tt);
                     if (ra.room >= 0 && (long long)mine >= ra.room) t_room = min(t_room, tt);
                 }
@@ -880,6 +892,8 @@ __device__ __forceinline__ void close_round(const RoundArgs& ra, int lane, unsig
                 ra.host_ctrl[0] = first_hit < ra.W ? first_hit : ra.W - 1;
             }
         }
+        // (a gathered wave has no speculative launch of its own that clears the flags of the wave before it)
+        if (g0 && lane == 0) { ra.ctl[RC_CONV + cur] = 0; if (!converged) ra.ctl[RC_CONV + nxt] = 0; }
         if (lane == 0) *word_r = 0ull;                                                          // for round + 2
         // the summary (all lanes' stores, pinned host memory) before the word that announces it
         if (converged) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __threadfence_system(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -956,7 +970,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     if constexpr (CH) {
         if (threadIdx.x >= 128) {
             // ---------------- checking wavefront
-            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
+            if (ron && !ra.gblk && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
             for (int i = lane; i < MAXP; i += 64) Pl[i] = P.p[i];
             if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
             const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
@@ -987,7 +1001,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         }
         if (threadIdx.x >= 64) {
             // ---------------- heading wavefront: what step p + 1 needs and only depends on two components of x_p
-            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;
+            if (ron && !ra.gblk && ra.ctl[RC_CONV + (ra.round & 1)]) return;
             __syncthreads();                                                // S
             if (!duo.go) return;
             const double tt0 = duo.tt[0], tt1 = duo.tt[1];
@@ -1009,7 +1023,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     if constexpr (PLAIN2) {
         if (threadIdx.x >= 64) {
             // ---------------- checking wavefront of the plain two-wavefront rollout
-            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
+            if (ron && !ra.gblk && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
             for (int i = lane; i < MAXP; i += 64) Pl[i] = P.p[i];
             if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
             const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
@@ -1037,7 +1051,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     if constexpr (NWF == 2 && !PLAIN2) {
         if (threadIdx.x >= 64) {
             // ---------------- helper wavefront
-            if (ron && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
+            if (ron && !ra.gblk && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
             for (int i = lane; i < MAXP; i += 64) Pl[i] = P.p[i];
             if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
             const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
@@ -1125,7 +1139,8 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
 #pragma unroll
             for (int j = 0; j < S::M * S::N; ++j) K[j] = tv.K[(size_t)p * S::M * S::N + j];
         } else {
-            const double* pr = rec + (size_t)(~p) * L.R;
+            // (round 0 of a gathered wave: the in-wave parent's record is being unpacked by ITS workgroup right now -- read the header)
+            const double* pr = (ron && ra.gblk) ? gathered_header(ra, ~p) : rec + (size_t)(~p) * L.R;
 #pragma unroll
             for (int d = 0; d < S::N; ++d) x[d] = pr[L.off_xend + d];
 #pragma unroll
@@ -1186,12 +1201,60 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         pref = bi;
     } else if (ron) {
         const int cur = ra.round & 1, nxt = cur ^ 1;
+        const bool g0 = ra.gblk != nullptr;                       // round 0 of a gathered wave: decide from the all-gather blocks
+        // cost of the end state in header h for sample u (the arithmetic of the row epilogue / k_wave_rows); +inf: no node
+        auto hcost = [&](const double* h, int u) -> double {
+            if (!((int)h[L.off_len] > 0)) return INFINITY;
+            double xu[S::N], tu[2 * S::NW + 1], xe[S::N], te[2 * S::NW + 1], e[S::N];
+#pragma unroll
+            for (int d = 0; d < S::N; ++d) { xu[d] = xs[(size_t)u * S::N + d]; xe[d] = h[L.off_xend + d]; }
+            if (f.xtrig) {
+#pragma unroll
+                for (int j = 0; j < 2 * S::NW; ++j) tu[j] = f.xtrig[(size_t)u * (2 * S::NW) + j];
+            } else {
+                trig_of<S>(xu, tu);
+            }
+#pragma unroll
+            for (int j = 0; j < 2 * S::NW; ++j) te[j] = h[L.off_trig + j];
+            erf_cached<S>(xu, tu, xe, te, e);
+            return quad_cost<S, DENSE>(e, f.Sd);
+        };
         // batch A: everything the decision needs that only depends on t (issued before the flag is even tested)
-        const int conv_flag = ra.ctl[RC_CONV + cur];
+        const int conv_flag = g0 ? 0 : ra.ctl[RC_CONV + cur];
         int lf_len[4], lf_flg[4];
         unsigned char chg[4];
         double colv[4];
-        {
+        double csnap_t;
+        int psnap_t, par_t, stale_t;
+        if (g0) {
+            const double* ht = gathered_header(ra, t);
+            // this sample out of its block into the local record (a sample another rank speculated; the own ones are there)
+            if (t / ra.gper != ra.grank) {
+                for (int q = lane; q < L.off_xseq; q += 64) my[q] = ht[q];
+                const int len = (int)ht[L.off_len], off = (int)ht[L.off_xseq];
+                if (len > 0 && off >= 0) {
+                    const double* tl = ra.gblk + (size_t)(t / ra.gper) * ra.gstride + (size_t)ra.gper * ra.ghd + off;
+                    for (int q = lane; q < len * S::N; q += 64) my[L.off_xseq + q] = tl[q];
+                    for (int q = lane; q < len * S::M; q += 64) my[L.off_useq + q] = tl[len * S::N + q];
+                }
+            }
+            if (t == 0 && lane == 0 && ra.gcursor) ra.gcursor[0] = 0;     // for this rank's next speculative launch
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int tt = lane + 64 * i;
+                const bool in = tt < ra.W;
+                const double* h = gathered_header(ra, in ? tt : 0);
+                lf_len[i] = in ? (int)h[L.off_len] : 0;
+                lf_flg[i] = in ? (int)h[L.off_flags] : 0;
+                chg[i] = 0;
+                colv[i] = (tt < t) ? hcost(h, t) : INFINITY;
+            }
+            csnap_t = ht[L.off_cost];
+            psnap_t = (int)ht[L.off_parent];
+            par_t = psnap_t;
+            // an edge that did not fit its rank's tail: re-steered in this round, by its owner too (replicated rounds)
+            stale_t = ((int)ht[L.off_len] > 0 && (int)ht[L.off_xseq] < 0) ? 1 : 0;
+        } else {
             const int* lfc = ra.lf[cur];
             const double* Mc = ra.M[cur];
 #pragma unroll
@@ -1203,11 +1266,11 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
                 chg[i] = in ? ra.changed[cur][tt] : 0;
                 colv[i] = (tt < t) ? Mc[(size_t)tt * ra.W + t] : INFINITY;
             }
+            csnap_t = rec[(size_t)t * L.R + L.off_cost];
+            psnap_t = (int)rec[(size_t)t * L.R + L.off_parent];
+            par_t = ra.par[cur][t];
+            stale_t = ra.stale[cur][t];
         }
-        const double csnap_t = rec[(size_t)t * L.R + L.off_cost];
-        const int psnap_t = (int)rec[(size_t)t * L.R + L.off_parent];
-        const int par_t = ra.par[cur][t];
-        const int stale_t = ra.stale[cur][t];
         if (conv_flag) {
             // the previous round converged: this launch is the commit.  Sample t's record becomes tree node
             // base + rank[t] if it lies in the committed prefix (tree.py:77-96; what k_append does).
@@ -1268,13 +1331,15 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
                 // the in-wave parent's own decision, evaluated here instead of waited for: redone this round -> defer
                 const int sn = ~want;                              // (sn < t <= hz)
                 const double* Mc = ra.M[cur];
+                const double* hs = g0 ? gathered_header(ra, sn) : nullptr;
                 double cs[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) cs[i] = (lane + 64 * i < sn) ? Mc[(size_t)(lane + 64 * i) * ra.W + sn] : INFINITY;
-                const double csnap_s = rec[(size_t)sn * L.R + L.off_cost];
-                const int psnap_s = (int)rec[(size_t)sn * L.R + L.off_parent];
-                const int par_s = ra.par[cur][sn];
-                const int stale_s = ra.stale[cur][sn];
+                for (int i = 0; i < 4; ++i)
+                    cs[i] = (lane + 64 * i < sn) ? (g0 ? hcost(gathered_header(ra, lane + 64 * i), sn) : Mc[(size_t)(lane + 64 * i) * ra.W + sn]) : INFINITY;
+                const double csnap_s = g0 ? hs[L.off_cost] : rec[(size_t)sn * L.R + L.off_cost];
+                const int psnap_s = g0 ? (int)hs[L.off_parent] : (int)rec[(size_t)sn * L.R + L.off_parent];
+                const int par_s = g0 ? psnap_s : ra.par[cur][sn];
+                const int stale_s = g0 ? (((int)hs[L.off_len] > 0 && (int)hs[L.off_xseq] < 0) ? 1 : 0) : ra.stale[cur][sn];
                 double ws = INFINITY;
                 int ss = -1;
 #pragma unroll
@@ -1291,8 +1356,8 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         }
         const bool redo = need && !defer;
         if (lane == 0) {
-            ra.par[nxt][t] = redo ? want : ra.par[cur][t];
-            ra.stale[nxt][t] = redo ? 0 : ((need && defer) || mark_stale ? 1 : ra.stale[cur][t]);
+            ra.par[nxt][t] = redo ? want : par_t;
+            ra.stale[nxt][t] = redo ? 0 : ((need && defer) || mark_stale ? 1 : stale_t);
             ra.changed[nxt][t] = redo ? 1 : 0;
         }
         if (redo) round_share += RC_ONE_LIST;
@@ -1308,9 +1373,15 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             // (the look at what came back happens at the end of this function, which a workgroup that stands reaches at once)
         }
         if (!redo) {
-            // nothing to recompute: this sample's row and len/flags move on unchanged
-            for (int u = t + 1 + lane; u < ra.W; u += 64) ra.M[nxt][(size_t)t * ra.W + u] = ra.M[cur][(size_t)t * ra.W + u];
-            if (lane < 2) ra.lf[nxt][2 * t + lane] = ra.lf[cur][2 * t + lane];
+            // nothing to recompute: this sample's row and len/flags move on unchanged (gathered round 0: they are made here)
+            if (g0) {
+                const double* ht = gathered_header(ra, t);
+                for (int u = t + 1 + lane; u < ra.W; u += 64) ra.M[nxt][(size_t)t * ra.W + u] = hcost(ht, u);
+                if (lane < 2) ra.lf[nxt][2 * t + lane] = (int)ht[lane == 0 ? L.off_len : L.off_flags];
+            } else {
+                for (int u = t + 1 + lane; u < ra.W; u += 64) ra.M[nxt][(size_t)t * ra.W + u] = ra.M[cur][(size_t)t * ra.W + u];
+                if (lane < 2) ra.lf[nxt][2 * t + lane] = ra.lf[cur][2 * t + lane];
+            }
             pref = 0x7fffffff;                                  // (marker: skip the rollout, go to the ticket)
         } else {
             pref = want;
@@ -1636,7 +1707,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     }
 #endif
     }   // !round_skip
-    if (ron) close_round(ra, lane, round_before, round_share);
+    if (ron) close_round(ra, L, lane, round_before, round_share);
 }
 
 // Rows of the in-wave cost matrix straight from the records (sharded waves: records of other ranks arrive by
