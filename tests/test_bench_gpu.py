@@ -45,6 +45,8 @@ def test_bench_line_fields():
     assert 3.5 < ck["cycles_per_dependent_fp64_fma"] < 9.0 and 1.0 < ck["ns_per_independent_fp64_fma"] < 5.0
     # the cap in force (exact-mode controller: the fused rounds' 256), not the command line's upper bound
     assert 8 <= d["config"]["mean_wave"] <= d["config"]["wave_cap"] == 256 and d["config"]["wave_cap_cli"] == 1024
+    sp = d["seed_spread"]                                            # tree-to-tree spread on the line itself
+    assert set(sp["by_sample_seed"]) == {"1", "2", "3", "4"} and sp["min"] <= sp["mean"] <= sp["max"] and sp["min"] > 1e4
     rp = d["repeats"]
     assert rp["regions"] == 3 and rp["min"] <= rp["median"] <= rp["max"] and rp["min"] <= d["value"] <= rp["max"]
     assert rp["max"] < 1.5 * rp["min"]                              # back-to-back regions on one box agree
