@@ -154,12 +154,14 @@ static int allgather_nodes(lqrrt_engine* e, lqrrt_comm* c, int W, int per, int h
     const double* xs = wave_samples(e);
     const double* xtr = wave_sample_trig(e);
     double* M = e->wave_matrix ? e->d_M : nullptr;
-    if (e->d_S) {
+    const double* Su = e->riccati ? wave_sample_S(e) : e->d_S;
+    const long long sst = e->riccati ? (long long)e->n * e->n : 0;
+    if (Su) {
         DISPATCH(e, hipLaunchKernelGGL((k_shard_unpack_prep<S, true>), dim3(W), dim3(64), 0, st, e->d_rec, e->L, e->d_blk, (long long)blk, hd, per,
-                                       c->rank, W, xs, xtr, e->d_S, M, e->d_par_done, e->d_changed, e->d_stale, e->d_lf[0], e->d_rctl, e->d_blk_cursor));
+                                       c->rank, W, xs, xtr, Su, sst, M, e->d_par_done, e->d_changed, e->d_stale, e->d_lf[0], e->d_rctl, e->d_blk_cursor));
     } else {
         DISPATCH(e, hipLaunchKernelGGL((k_shard_unpack_prep<S, false>), dim3(W), dim3(64), 0, st, e->d_rec, e->L, e->d_blk, (long long)blk, hd, per,
-                                       c->rank, W, xs, xtr, (const double*)nullptr, M, e->d_par_done, e->d_changed, e->d_stale, e->d_lf[0], e->d_rctl, e->d_blk_cursor));
+                                       c->rank, W, xs, xtr, (const double*)nullptr, 0ll, M, e->d_par_done, e->d_changed, e->d_stale, e->d_lf[0], e->d_rctl, e->d_blk_cursor));
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -238,7 +240,6 @@ extern "C" int lqrrt_engine_extend_sharded(lqrrt_engine* e, lqrrt_comm* c, int s
     if (!e || !c) return fail(LQRRT_E_ARG, "null argument");
     if (wave < 1) return fail(LQRRT_E_ARG, "wave must be >= 1");
     if (scheme != LQRRT_SHARD_SAMPLES && scheme != LQRRT_SHARD_TREE) return fail(LQRRT_E_ARG, "unknown sharding scheme %d", scheme);
-    if (scheme == LQRRT_SHARD_SAMPLES && e->riccati) return fail(LQRRT_E_ARG, "sample-sharded waves are not instantiated for Riccati systems");
     TRY(use_device(e));
     hipStream_t st = (hipStream_t)stream;
     lqrrt_extend_stats acc;

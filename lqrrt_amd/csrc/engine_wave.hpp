@@ -61,7 +61,9 @@ static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, 
     const bool whole = (lo == 0 && hi == W);
     static const int matrix_max = getenv("LQRRT_MATRIX_MAX_W") ? std::min(atoi(getenv("LQRRT_MATRIX_MAX_W")), (int)lqrrt_engine::MATRIX_MAX_W)
                                                                 : (int)lqrrt_engine::MATRIX_MAX_W;
-    e->wave_matrix = W <= matrix_max && !e->sync_mode && !e->riccati;
+    // (Riccati systems keep the matrix -- costs under the S about each sample -- when the wave is speculated here as a whole or goes
+    //  through the native all-gather; slices handed to the Python-level sharded classes fall back to the scan of the records)
+    e->wave_matrix = W <= matrix_max && !e->sync_mode && (!e->riccati || whole || so != nullptr);
     if (cnt > 0) {
         // snapshot NN for the slice: records lo..hi-1 get (cost, parent); the reduce also initialises the
         // slice's wave bookkeeping (parent-in-use, changed, stale)
@@ -135,7 +137,7 @@ extern "C" int lqrrt_wave_steer_candidates(lqrrt_engine* e, int W, int parts, co
     hipLaunchKernelGGL(k_best_unpack, dim3((W * parts + 255) / 256), dim3(256), 0, st, best_dev, W, parts, e->d_pcost, e->d_pidx);
     static const int matrix_max = getenv("LQRRT_MATRIX_MAX_W") ? std::min(atoi(getenv("LQRRT_MATRIX_MAX_W")), (int)lqrrt_engine::MATRIX_MAX_W)
                                                                 : (int)lqrrt_engine::MATRIX_MAX_W;
-    e->wave_matrix = W <= matrix_max && !e->sync_mode && !e->riccati;
+    e->wave_matrix = W <= matrix_max && !e->sync_mode;
     const double* xtr = wave_sample_trig(e);
     SteerFuse f;
     memset(&f, 0, sizeof f);
@@ -171,7 +173,7 @@ static int pick_wave(const lqrrt_engine* e, int wave_cap) {
     // profiles/r03_wave_cap.txt).  LQRRT_EXACT_WAVE_MAX=1024 restores the old behaviour.
     static const int exact_max = getenv("LQRRT_EXACT_WAVE_MAX") ? atoi(getenv("LQRRT_EXACT_WAVE_MAX")) : 256;
     // (the sharded loops too: their gathered waves go through the same rounds; one collective per ~130 us wave either way)
-    if (!e->sync_mode && !e->riccati && exact_max >= 8) W = std::min(W, exact_max);
+    if (!e->sync_mode && exact_max >= 8) W = std::min(W, exact_max);
     if (W >= 64) W = (W / 64) * 64;
     return W;
 }
@@ -286,6 +288,7 @@ static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_
     memset(&rf, 0, sizeof rf);
     rf.M = mat ? e->d_M : nullptr; rf.W = W;
     rf.xtrig = wave_sample_trig(e);
+    if (e->riccati) { rf.Sd = wave_sample_S(e); rf.s_stride = (long long)e->n * e->n; }     // cost-to-go under the S about each sample
 
     const int guard = 4 * W + 8;
     int rounds = 0;

@@ -910,8 +910,8 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
                                               const int* __restrict__ list, int lo,
                                               const int* __restrict__ par, const int* __restrict__ list_count,
                                               SteerFuse f, RoundArgs ra) {
-    // fused rounds need the in-wave matrix, which waves of Riccati-gain systems never use (per-sample S): compiled out
-    const bool ron = has_dare_gain<S>::value ? false : ra.on != 0;
+    // (round 4: Riccati-gain systems run the fused rounds too -- their in-wave matrix holds the cost under the S about each sample)
+    const bool ron = ra.on != 0;
     // list mode with a device-side count: the launch is enqueued before the host knows how many samples
     // k_decide listed, so surplus workgroups simply leave (and a converged round costs one empty launch)
     if (list_count && (int)blockIdx.x + lo >= list_count[0]) return;
@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
 #pragma unroll
             for (int j = 0; j < 2 * S::NW; ++j) te[j] = h[L.off_trig + j];
             erf_cached<S>(xu, tu, xe, te, e);
-            return quad_cost<S, DENSE>(e, f.Sd);
+            return quad_cost<S, DENSE>(e, f.Sd + (size_t)u * f.s_stride);
         };
         // batch A: everything the decision needs that only depends on t (issued before the flag is even tested)
         const int conv_flag = g0 ? 0 : ra.ctl[RC_CONV + cur];
@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             // launch is still running; one that re-steers looks after its rollout, when the answer has long arrived: no
             // workgroup ends with an atomic round trip across the chip.
             unsigned long long* word_r = (unsigned long long*)(ra.ctl + RC_PACK) + cur;
-            if (lane == 0) round_before = __hip_atomic_fetch_add(word_r, round_share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) round_before = __hip_atomic_fetch_add(word_r, round_share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // (the look at what came back happens at the end of this function, which a workgroup that stands reaches at once)
         }
         if (!redo) {
@@ -1675,12 +1675,12 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             double c = INFINITY;
             if (cnt > 0) {
                 erf_cached<S>(xu, tu, x, trig, e);
-                c = quad_cost<S, DENSE>(e, f.Sd);
+                c = quad_cost<S, DENSE>(e, f.Sd + (size_t)u * f.s_stride);       // (the S about sample u for Riccati systems)
             }
             Mout[(size_t)t * Wm + u] = c;
         }
     }
-    if (f.sh_hdr) {
+    if (f.sh_hdr && threadIdx.x < 64) {                          // (one wavefront: the tail slot is taken with an atomic)
         // this rank's share of a sample-sharded wave: header and (compacted) edge into the all-gather block
         int off = -1;
         const int need = cnt * (S::N + S::M);
@@ -1707,7 +1707,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     }
 #endif
     }   // !round_skip
-    if (ron) close_round(ra, L, lane, round_before, round_share);
+    if (ron && threadIdx.x < 64) close_round(ra, L, lane, round_before, round_share);   // (the workgroup's first wavefront holds the ticket)
 }
 
 // Rows of the in-wave cost matrix straight from the records (sharded waves: records of other ranks arrive by
@@ -1748,7 +1748,7 @@ template <class S, int DENSE>
 __global__ __launch_bounds__(64) void k_shard_unpack_prep(double* __restrict__ rec, RecLayout L, const double* __restrict__ blk,
                                                           long long blk_stride, int hd, int per, int rank, int W,
                                                           const double* __restrict__ xs, const double* __restrict__ xtrig,
-                                                          const double* __restrict__ Sd, double* __restrict__ M,
+                                                          const double* __restrict__ Sd, long long s_stride, double* __restrict__ M,
                                                           int* __restrict__ par_done, unsigned char* __restrict__ changed,
                                                           unsigned char* __restrict__ stale, int* __restrict__ lf0,
                                                           int* __restrict__ round_ctl, int* __restrict__ tail_cursor) {
@@ -1809,7 +1809,7 @@ __global__ __launch_bounds__(64) void k_shard_unpack_prep(double* __restrict__ r
             double c = INFINITY;
             if (len > 0) {
                 erf_cached<S>(xu, tu, x, trig, e);
-                c = quad_cost<S, DENSE>(e, Sd);
+                c = quad_cost<S, DENSE>(e, Sd + (size_t)u * s_stride);
             }
             M[(size_t)t * W + u] = c;
         }

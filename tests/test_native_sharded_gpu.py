@@ -53,7 +53,9 @@ def _same_tree(a, b):
     ("boat_advanced", 2500, 256, 8, 5, "sample"), ("car", 1200, 256, 3, 2, "sample"),
     ("boat_advanced", 1500, 1024, 4, 1, "sample"),                     # waves beyond the fused rounds' 256
     ("boat_advanced", 1500, 256, 4, 3, "tree"), ("boat_intermediate", 900, 128, 8, 0, "tree"),
-    ("double_integrator", 1200, 512, 4, 2, "tree"), ("double_integrator", 1200, 256, 2, 1, "sample")])
+    ("double_integrator", 1200, 512, 4, 2, "tree"), ("double_integrator", 1200, 256, 2, 1, "sample"),
+    # round 4: Riccati systems (K per recorded step, S per sample) are sample-sharded too, through the fused rounds
+    ("boat_novice_lqr", 500, 64, 2, 1, "sample"), ("pendulum_lqr", 150, 64, 4, 0, "sample"), ("boat_novice_lqr", 400, 64, 3, 2, "tree")])
 def test_loopback_rank_matches_single_engine(name, nodes, wave, world, rank, scheme):
     from lqrrt_amd.parallel import NativeComm
     _, ref = _make(name, nodes + wave + 8, wave)
