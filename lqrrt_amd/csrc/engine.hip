@@ -26,8 +26,12 @@
 //   LQRRT_REFILL_AHEAD           1        refill_ahead             0: the sample pool's feasibility batch and filter only when the pool runs dry
 //   LQRRT_IGNORE_PATCH           1        speculate_impl           0: the ignore words a goal hit changed are uploaded, not passed as scan arguments
 //   LQRRT_HOSTPROF               unset    hostprof_on              host time per wave, printed when an engine is destroyed
+//   LQRRT_DARE_WAVEFRONTS        auto     steer_wavefronts         1|4: wavefronts per rollout of a Riccati system (auto: 4 for n >= 6, they share the gain)
+//   LQRRT_NN_WG4                 0        launch_nn                1: two-level reduction of the tree scan's partial minima (four wavefronts per workgroup)
+//   LQRRT_SHARD_FOLD             1        gathered_wave_fuses      0: a gathered wave is unpacked by a launch of its own instead of by its first round
 // (Python side: LQRRT_LIB -- load another build of this library, lqrrt_amd/_native.py; LQRRT_FORCE_SHARDED and
-//  LQRRT_BENCH_EVENTS_EVERY -- bench.py.)
+//  LQRRT_BENCH_EVENTS_EVERY -- bench.py; LQRRT_TORQUE_VMIN -- default of the boats' torque_vmin, lqrrt_amd/systems.py, the one
+//  lever here that is a PARAMETER of the problem: it changes the arithmetic of the heading torque below that speed)
 // Compile-time (measurement builds only): -DSTEER_TIMING (device timestamps and placement counters in k_steer,
 // tools/steer_phases_bench.py), -DLQRRT_NO_KERNARG_TOUCH (k_steer without the touch of its argument block), -DABL_* (ablations,
 // tools/ablate_steer.py), -DLQRRT_USER_SYSTEM='"header"' (an out-of-tree problem as LQRRT_MODEL_USER, tools/build_user_system.py).
