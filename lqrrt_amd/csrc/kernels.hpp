@@ -16,10 +16,11 @@
 //     (round 1 staged tiles in LDS and was bound by the LDS pipe).  Angle errors come from a per-node table when the
 //     sampler's angular coordinates are fixed.  Bound by fp64 issue, not by HBM: the node table is cache-resident.
 //   * steer: one problem per WORKGROUP of 1-4 wavefronts.  Every value of a rollout is wave-uniform; the lanes only split the
-//     hull x obstacle sweep.  The boats with the heading torque spread a step over up to four SIMDs (main / torque /
-//     checker / next heading, two barriers per step); other analytic-gain systems run the step tests on a second wavefront;
-//     Riccati systems keep one wavefront (dare.hpp uses all of it).  Edge history, geometry and constants in LDS; no
-//     scratch in any instantiation (tests/test_abi_cpu.py).
+//     hull x obstacle sweep.  The boats with the heading torque run the chain rollout (three wavefronts: chain / heading /
+//     checker, one barrier per step; the torque of a moving boat is one atan2, systems.hpp rudder_term); other analytic-gain
+//     systems run the step tests on a second wavefront; Riccati systems with six states run four wavefronts that share the gain
+//     (dare.hpp dare_lqr<S, 256>).  Edge history, geometry and constants in LDS; no scratch in any instantiation
+//     (tests/test_abi_cpu.py).
 //   * exact-mode repair rounds of waves <= 256 are fused into k_steer launches (RoundArgs): every workgroup decides for its
 //     own sample, re-steers if it must; the last one to finish closes the round and, on convergence, prepares the commit.
 //   * gfx9-specific assumptions (the build is refused for any other target below; this file is gfx950 code, not portable HIP):
