@@ -22,13 +22,14 @@
 //   LQRRT_SHARD_TAIL             0.4      shard_tail_fraction      share of the worst-case edge payload a sharded rank's block reserves
 //   LQRRT_RCCL                   unset    rccl                     path of the librccl.so to resolve (default: the one in the process)
 //   LQRRT_POISON                 unset    dalloc                   fill every device allocation with 0xff (reads of unwritten memory show)
-//   LQRRT_TRACE                  unset    trace_on                 per-round trace on stderr
+//   LQRRT_TRACE                  unset    trace_on                 per-round trace on stderr (2: + every fused round's per-sample state, tools/round_trace.py)
 //   LQRRT_REFILL_AHEAD           1        refill_ahead             0: the sample pool's feasibility batch and filter only when the pool runs dry
 //   LQRRT_IGNORE_PATCH           1        speculate_impl           0: the ignore words a goal hit changed are uploaded, not passed as scan arguments
 //   LQRRT_HOSTPROF               unset    hostprof_on              host time per wave, printed when an engine is destroyed
 //   LQRRT_DARE_WAVEFRONTS        auto     steer_wavefronts         1|4: wavefronts per rollout of a Riccati system (auto: 4 for n >= 6, they share the gain)
 //   LQRRT_NN_WG4                 0        launch_nn                1: two-level reduction of the tree scan's partial minima (four wavefronts per workgroup)
 //   LQRRT_SHARD_FOLD             1        gathered_wave_fuses      0: a gathered wave is unpacked by a launch of its own instead of by its first round
+//   LQRRT_SECOND_CHOICE          1        second_choice_enabled    0: a sample whose wanted in-wave parent is being redone waits idly instead of steering from its best standing candidate
 // (Python side: LQRRT_LIB -- load another build of this library, lqrrt_amd/_native.py; LQRRT_FORCE_SHARDED and
 //  LQRRT_BENCH_EVENTS_EVERY -- bench.py; LQRRT_TORQUE_VMIN -- default of the boats' torque_vmin, lqrrt_amd/systems.py, the one
 //  lever here that is a PARAMETER of the problem: it changes the arithmetic of the heading torque below that speed)

@@ -159,6 +159,11 @@ static bool trace_on() {
     static const bool on = getenv("LQRRT_TRACE") != nullptr;     // read once: getenv walks the environment
     return on;
 }
+// LQRRT_TRACE=2: every fused round also dumps its samples' state (blocking copies: a debugging aid, tools/round_trace.py)
+static bool trace_rounds_on() {
+    static const bool on = [] { const char* v = getenv("LQRRT_TRACE"); return v && atoi(v) >= 2; }();
+    return on;
+}
 
 // LQRRT_HOSTPROF=1: where the host's time goes per wave (printed when the engine is destroyed)
 struct HostProf { double wait = 0, book = 0, flush = 0, nn = 0, steer = 0, other = 0; long waves = 0; };

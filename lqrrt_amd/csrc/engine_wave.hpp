@@ -203,6 +203,12 @@ static bool fused_rounds_enabled() {
     static const bool on = [] { const char* v = getenv("LQRRT_FUSED_ROUNDS"); return !(v && atoi(v) == 0); }();
     return on;
 }
+// LQRRT_SECOND_CHOICE=0: a sample whose in-wave parent is being redone waits for it idly (rounds 2-3) instead of steering from its
+// best standing candidate in the meantime
+static bool second_choice_enabled() {
+    static const bool on = [] { const char* v = getenv("LQRRT_SECOND_CHOICE"); return !(v && atoi(v) == 0); }();
+    return on;
+}
 static int wait_word(lqrrt_engine* e, hipStream_t st, int* word, int seq);
 static int wait_summary(lqrrt_engine* e, hipStream_t st) { return wait_word(e, st, e->h_summary + 2, e->seq); }
 // word[0] = counts, word[1] = sequence number (one aligned 64-bit store on the device side)
@@ -296,6 +302,7 @@ static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_
         RoundArgs ra;
         memset(&ra, 0, sizeof ra);
         ra.on = 1; ra.W = W; ra.base = e->N;
+        ra.second_choice = second_choice_enabled() ? 1 : 0;
         ra.max_commit = max_commit;
         ra.room = node_limit >= 0 ? node_limit + 1 - (int64_t)e->N : -1;
         ra.M[0] = e->d_M; ra.M[1] = e->d_M2;
@@ -333,6 +340,20 @@ static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_
             const unsigned counts = (unsigned)__atomic_load_n(&word[0], __ATOMIC_RELAXED);
             const int n_list = (int)(counts >> 16), n_defer = (int)(counts & 0xffffu);
             if (trace_on()) fprintf(stderr, "[wave N=%d W=%d] fused round %d: list=%d defer=%d\n", e->N, W, r, n_list, n_defer);
+            if (trace_rounds_on()) {
+                // what round r left behind (buffers [(r + 1) & 1]; round r + 1, already queued, only reads them)
+                const int nx = (r + 1) & 1;
+                HIPCHK(hipStreamSynchronize(st));                  // (the counts arrive while re-steering workgroups still run)
+                std::vector<int> lf(2 * W), pr(W);
+                std::vector<unsigned char> ch(W), sl(W);
+                HIPCHK(hipMemcpy(lf.data(), ra.lf[nx], sizeof(int) * 2 * W, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(pr.data(), ra.par[nx], sizeof(int) * W, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(ch.data(), ra.changed[nx], W, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(sl.data(), ra.stale[nx], W, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[roundstate N=%d W=%d r=%d]", e->N, W, r);
+                for (int t = 0; t < W; ++t) fprintf(stderr, " %d:%d:%d:%d:%d", pr[t], lf[2 * t], lf[2 * t + 1] & 1, (int)ch[t], (int)sl[t]);
+                fprintf(stderr, "\n");
+            }
             if (n_list == 0 && n_defer == 0) break;
             if (n_list == 0) return fail(LQRRT_E_STATE, "exact-mode repair made no progress (deferred=%d)", n_defer);
             ws.fix_rounds++;
