@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         trig_of<S>(xt, ttrig);
     }
     bool parent_loaded = false;
-    auto load_parent = [&](int p) __attribute__((always_inline)) {                                // state, cos/sin and gain of tree node p >= 0 / record ~p
+    auto load_parent = [&](int p) {                                  // state, cos/sin and gain of tree node p >= 0 / record ~p
         if (p >= 0) {
 #pragma unroll
             for (int d = 0; d < S::N; ++d) x[d] = tv.state[(size_t)d * tv.cap + p];
@@ -1204,7 +1204,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         const int cur = ra.round & 1, nxt = cur ^ 1;
         const bool g0 = ra.gblk != nullptr;                       // round 0 of a gathered wave: decide from the all-gather blocks
         // cost of the end state in header h for sample u (the arithmetic of the row epilogue / k_wave_rows); +inf: no node
-        auto hcost = [&](const double* h, int u) __attribute__((always_inline)) -> double {
+        auto hcost = [&](const double* h, int u) -> double {
             if (!((int)h[L.off_len] > 0)) return INFINITY;
             double xu[S::N], tu[2 * S::NW + 1], xe[S::N], te[2 * S::NW + 1], e[S::N];
 #pragma unroll
@@ -1311,7 +1311,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             if (hz == ra.W - 1 && lf_len[i] > 0 && (lf_flg[i] & 1)) hz = lane + 64 * i;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) hz = min(hz, __shfl_xor(hz, off));
-        auto changed_of = [&](int idx) __attribute__((always_inline)) -> bool {                   // changed[cur][idx] from the lanes' prefetched bytes
+        auto changed_of = [&](int idx) -> bool {                   // changed[cur][idx] from the lanes' prefetched bytes
             int v = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const int w = __shfl((int)chg[i], idx & 63); if ((idx >> 6) == i) v = w; }
@@ -1328,8 +1328,9 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             need = (want != par_t) || (stale_t != 0);
             if (want < 0 && changed_of(~want)) need = true;
             if (need) { load_parent(want); parent_loaded = true; }    // (in flight together with the neighbour's column below)
-            // the decision of in-wave sample sn (< t <= hz), evaluated here instead of waited for: true = it is redone (or waits)
-            auto redone_now = [&](int sn) __attribute__((always_inline)) -> bool {
+            if (need && want < 0) {
+                // the in-wave parent's own decision, evaluated here instead of waited for: redone this round -> defer
+                const int sn = ~want;                              // (sn < t <= hz)
                 const double* Mc = ra.M[cur];
                 const double* hs = g0 ? gathered_header(ra, sn) : nullptr;
                 double cs[4];
@@ -1349,27 +1350,26 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
                 const int want_s = (ss >= 0 && ws < csnap_s) ? ~ss : psnap_s;
                 bool need_s = (want_s != par_s) || (stale_s != 0);
                 if (want_s < 0 && changed_of(~want_s)) need_s = true;
-                return need_s;
-            };
-            if (need && want < 0) {
-                defer = redone_now(~want);                         // its in-wave parent is redone this round -> wait for the new record
-                if (defer && ra.second_choice) {
-                    // ... but not idly (round 4): the sample steers from its best candidate that STANDS this round.  If the redone
-                    // parent comes back as the best choice, this rollout was for nothing (the workgroup would have idled); if it
-                    // does not -- its new end state lies elsewhere -- the sample is done a round earlier.  Same fixed point.
-                    const int sn = ~want;
+                defer = need_s;
+                if (defer && ra.second_choice && !g0) {
+                    // ... but the sample does not wait idly (round 4): it steers from its best candidate other than the parent
+                    // that is being redone.  If that parent comes back as the best choice, the rollout was for nothing (the
+                    // workgroup would have idled; the same if the second choice is itself redone this round, which is not
+                    // looked into); if it does not -- its new end state lies elsewhere -- the sample is done a round earlier.
+                    // Same fixed point: samples settle in index order whatever the later ones try in the meantime.
                     double wc2 = INFINITY;
                     int sm2 = -1;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (lane + 64 * i < t && lane + 64 * i != sn && colv[i] < wc2) { wc2 = colv[i]; sm2 = lane + 64 * i; }
+                    for (int i = 0; i < 4; ++i) {                           // (column t again: cheaper than keeping it in registers)
+                        const int c = lane + 64 * i;
+                        const double v = (c < t && c != sn) ? Mc[(size_t)c * ra.W + t] : INFINITY;
+                        if (v < wc2) { wc2 = v; sm2 = c; }
+                    }
                     lexmin_wave(wc2, sm2);
                     const int want2 = (sm2 >= 0 && wc2 < csnap_t) ? ~sm2 : psnap_t;
-                    bool stands = true;
-                    if (want2 < 0) stands = !changed_of(~want2) && !redone_now(~want2);
-                    if (stands && (want2 != par_t || stale_t != 0)) {
+                    if (want2 != par_t || stale_t != 0) {
                         want = want2; defer = false;
-                        load_parent(want);
+                        parent_loaded = false;                         // (loaded with everybody else's below)
                     }
                 }
             }
