@@ -1351,7 +1351,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
                 bool need_s = (want_s != par_s) || (stale_s != 0);
                 if (want_s < 0 && changed_of(~want_s)) need_s = true;
                 defer = need_s;
-                if (defer && ra.second_choice && !g0) {
+                if (defer && ra.second_choice) {
                     // ... but the sample does not wait idly (round 4): it steers from its best candidate other than the parent
                     // that is being redone.  If that parent comes back as the best choice, the rollout was for nothing (the
                     // workgroup would have idled; the same if the second choice is itself redone this round, which is not
@@ -1360,9 +1360,9 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
                     double wc2 = INFINITY;
                     int sm2 = -1;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {                           // (column t again: cheaper than keeping it in registers)
+                    for (int i = 0; i < 4; ++i) {                           // (column t again: cheaper than keeping it in registers;
                         const int c = lane + 64 * i;
-                        const double v = (c < t && c != sn) ? Mc[(size_t)c * ra.W + t] : INFINITY;
+                        const double v = (c < t && c != sn) ? (g0 ? colv[i] : Mc[(size_t)c * ra.W + t]) : INFINITY;   // (gathered round 0: computed, not stored)
                         if (v < wc2) { wc2 = v; sm2 = c; }
                     }
                     lexmin_wave(wc2, sm2);
