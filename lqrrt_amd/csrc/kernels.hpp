@@ -661,7 +661,9 @@ struct SteerFuse {
 // Fused repair rounds (small waves, exact mode).  One launch of k_steer with W workgroups is one round: every
 // wavefront first makes the decision k_decide makes for ITS sample (column minimum of the in-wave cost matrix against
 // the snapshot parent, then the redo / defer rules, evaluating its in-wave parent's decision a second time instead of
-// waiting for it), re-steers if it has to, and the last wavefront to finish publishes the round's counts.  State that one
+// waiting for it), re-steers if it has to -- a sample whose wanted parent is itself redone in this round steers from its
+// second choice meanwhile instead of idling (round 4: 42 -> 30 rounds per 1024 attempts of the headline workload; same fixed
+// point, LQRRT_SECOND_CHOICE=0 is the old schedule) -- and the last wavefront to finish publishes the round's counts.  State that one
 // workgroup reads while another may be rewriting it (matrix rows, len/flags, parent-in-use, stale, changed) is
 // double-buffered by round parity: round r reads [r & 1] and writes [1 - (r & 1)], unchanged samples copy theirs.  The
 // launch that follows a converged round finds the flag set and is the append (tree.py:77-96): one kernel boundary per
