@@ -38,7 +38,7 @@ print("TREE", eng.size, stats.attempts, stats.goal_hits, h.hexdigest())
 
 def _run(env_extra):
     env = dict(os.environ)
-    for k in ("LQRRT_REFILL_AHEAD", "LQRRT_IGNORE_PATCH", "LQRRT_FUSED_ROUNDS", "LQRRT_STEER_WAVEFRONTS"):
+    for k in ("LQRRT_REFILL_AHEAD", "LQRRT_IGNORE_PATCH", "LQRRT_FUSED_ROUNDS", "LQRRT_STEER_WAVEFRONTS", "LQRRT_SECOND_CHOICE"):
         env.pop(k, None)
     env.update(env_extra)
     out = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
@@ -52,5 +52,6 @@ def test_switches_do_not_change_the_tree():
     size, attempts, hits = (int(x) for x in base.split()[1:4])
     assert size > 7000 and attempts > 20000 and hits > 10            # the run is long enough to go through every mechanism
     for env in ({"LQRRT_REFILL_AHEAD": "0"}, {"LQRRT_IGNORE_PATCH": "0"}, {"LQRRT_FUSED_ROUNDS": "0"},
-                {"LQRRT_STEER_WAVEFRONTS": "2"}, {"LQRRT_REFILL_AHEAD": "0", "LQRRT_IGNORE_PATCH": "0", "LQRRT_STEER_WAVEFRONTS": "2"}):
+                {"LQRRT_STEER_WAVEFRONTS": "2"}, {"LQRRT_SECOND_CHOICE": "0"},
+                {"LQRRT_REFILL_AHEAD": "0", "LQRRT_IGNORE_PATCH": "0", "LQRRT_STEER_WAVEFRONTS": "2", "LQRRT_SECOND_CHOICE": "0"}):
         assert _run(env) == base, env
