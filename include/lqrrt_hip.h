@@ -175,6 +175,14 @@ int lqrrt_engine_set_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys, voi
 #define LQRRT_WAVE_SYNCHRONOUS  1
 int lqrrt_engine_set_wave_mode(lqrrt_engine* e, int mode);
 
+/* Restricts the engine's native loops (lqrrt_engine_extend, lqrrt_engine_extend_sharded) to a subset of the GPU's compute units:
+ * they then run on an engine-private stream created with this CU mask (n_words 32-bit words; bit k = the k-th CU as the driver
+ * numbers them, dealt round-robin to the XCDs: bit k is a CU of XCD k mod 8 on an MI355X).  The caller's stream is drained when such
+ * a call begins and the private stream when it returns, so the call stays ordered on the caller's stream.  n_words = 0 lifts the
+ * restriction.  No counterpart in the reference (planner.py has no notion of a device); speed only, results are unchanged.  Use: one
+ * planner on one XCD keeps its working set in that XCD's L2; several planners on disjoint masks share a GPU without contending. */
+int lqrrt_engine_set_cu_mask(lqrrt_engine* e, const uint32_t* mask, int n_words);
+
 /* Changing horizon_iters re-lays out the edge pools: call lqrrt_tree_reset afterwards. */
 int lqrrt_engine_set_resolution(lqrrt_engine* e, const lqrrt_resolution* r);
 

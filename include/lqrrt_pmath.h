@@ -123,38 +123,50 @@ LQ_HD void lq_sincos(double x, double* sn, double* cs) {
 LQ_HD double lq_sin(double x) { double s, c; lq_sincos(x, &s, &c); return s; }
 LQ_HD double lq_cos(double x) { double s, c; lq_sincos(x, &s, &c); return c; }
 
-/* four-quadrant arctangent, C99 sign conventions for zeros */
-LQ_HD double lq_atan2(double y, double x) {
-    const double ax = fabs(x), ay = fabs(y);
-    const int xneg = copysign(1.0, x) < 0.0;
-    /* the zero cases are patched in at the end by selects (straight-line code, see lq_sincos); the general
-     * path may then see 0/0, whose NaN is discarded */
-    const int swap = ay > ax;
-    const double mx = swap ? ay : ax, mn = swap ? ax : ay;
-    const double t = mn / mx;
-    const int big = t > LQ_TAN_PI_8;
-    const double z = big ? (t - 1.0) / (t + 1.0) : t;
-    const double w = z * z;
-    double p = -0x1.3a31a1d5ffde0p-6;
-    p = lq_fma(p, w, 0x1.4162b9ab69c5ap-5);
-    p = lq_fma(p, w, -0x1.a0999a234950fp-5);
-    p = lq_fma(p, w, 0x1.dfe6491089bd5p-5);
-    p = lq_fma(p, w, -0x1.10fa77ab514f0p-4);
-    p = lq_fma(p, w, 0x1.3b126305dc4dep-4);
-    p = lq_fma(p, w, -0x1.745d0b28a2eeep-4);
-    p = lq_fma(p, w, 0x1.c71c71853d607p-4);
-    p = lq_fma(p, w, -0x1.24924924361fep-3);
-    p = lq_fma(p, w, 0x1.999999999934cp-3);
-    p = lq_fma(p, w, -0x1.5555555555555p-2);
-    const double corr = z * w * p;                               /* atan z - z */
-    double a = big ? LQ_PI_4_HI + (z + (corr + LQ_PI_4_LO)) : z + corr;
-    a = swap ? LQ_PI_2_HI - (a - LQ_PI_2_LO) : a;
-    a = xneg ? LQ_PI_HI - (a - LQ_PI_LO) : a;
-    double res = copysign(a, y);
-    res = (ax == 0.0) ? copysign(LQ_PI_2_HI, y) : res;
-    res = (ay == 0.0) ? (xneg ? copysign(LQ_PI_HI, y) : y) : res;
-    return res;
+/* four-quadrant arctangent, C99 sign conventions for zeros.  One body, two spellings of its Horner steps: lq_atan2 uses lq_fma
+ * (on gfx950 the explicit three-address v_fma_f64 above, whose coefficients then live in VGPRs -- right for a rollout wavefront
+ * that has the register file to itself), lq_atan2_c leaves the step to the compiler's fma (coefficients as literals / SGPRs --
+ * right for the NN scan, whose speed is its occupancy: with the VGPR coefficients the scans that carry an atan2 lost a wavefront
+ * per SIMD, profiles/r05_nn_regression.txt).  fma is fma: both return the same bits (host: tests/test_pmath.py; device: every scan with an atan2 is compared bit for bit
+ * with the C oracle, which only has the first spelling). */
+#define LQ_ATAN2_IMPL(NAME, FMA) \
+LQ_HD double NAME(double y, double x) { \
+    const double ax = fabs(x), ay = fabs(y); \
+    const int xneg = copysign(1.0, x) < 0.0; \
+    /* the zero cases are patched in at the end by selects (straight-line code, see lq_sincos); the general \
+     * path may then see 0/0, whose NaN is discarded */ \
+    const int swap = ay > ax; \
+    const double mx = swap ? ay : ax, mn = swap ? ax : ay; \
+    const double t = mn / mx; \
+    const int big = t > LQ_TAN_PI_8; \
+    const double z = big ? (t - 1.0) / (t + 1.0) : t; \
+    const double w = z * z; \
+    double p = -0x1.3a31a1d5ffde0p-6; \
+    p = FMA(p, w, 0x1.4162b9ab69c5ap-5); \
+    p = FMA(p, w, -0x1.a0999a234950fp-5); \
+    p = FMA(p, w, 0x1.dfe6491089bd5p-5); \
+    p = FMA(p, w, -0x1.10fa77ab514f0p-4); \
+    p = FMA(p, w, 0x1.3b126305dc4dep-4); \
+    p = FMA(p, w, -0x1.745d0b28a2eeep-4); \
+    p = FMA(p, w, 0x1.c71c71853d607p-4); \
+    p = FMA(p, w, -0x1.24924924361fep-3); \
+    p = FMA(p, w, 0x1.999999999934cp-3); \
+    p = FMA(p, w, -0x1.5555555555555p-2); \
+    const double corr = z * w * p;                               /* atan z - z */ \
+    double a = big ? LQ_PI_4_HI + (z + (corr + LQ_PI_4_LO)) : z + corr; \
+    a = swap ? LQ_PI_2_HI - (a - LQ_PI_2_LO) : a; \
+    a = xneg ? LQ_PI_HI - (a - LQ_PI_LO) : a; \
+    double res = copysign(a, y); \
+    res = (ax == 0.0) ? copysign(LQ_PI_2_HI, y) : res; \
+    res = (ay == 0.0) ? (xneg ? copysign(LQ_PI_HI, y) : y) : res; \
+    return res; \
 }
+LQ_ATAN2_IMPL(lq_atan2, lq_fma)
+#if defined(__HIP_DEVICE_COMPILE__)
+LQ_ATAN2_IMPL(lq_atan2_c, __builtin_fma)
+#else
+LQ_ATAN2_IMPL(lq_atan2_c, fma)
+#endif
 
 /* ln 2 = LN2_HI + LN2_LO, LN2_HI with 32 significant bits so that k*LN2_HI is exact for |k| < 2^20 */
 #define LQ_LN2_HI    0x1.62e42fee00000p-1

@@ -65,6 +65,7 @@ SIGNATURES = {
     "lqrrt_engine_destroy": (_I, [_P]),
     "lqrrt_engine_set_geometry": (_I, [_P, C.POINTER(SystemDesc), _P]),
     "lqrrt_engine_set_wave_mode": (_I, [_P, _I]),
+    "lqrrt_engine_set_cu_mask": (_I, [_P, _P, _I]),
     "lqrrt_engine_set_resolution": (_I, [_P, C.POINTER(Resolution)]),
     "lqrrt_engine_set_sampler": (_I, [_P, C.POINTER(SamplerDesc)]),
     "lqrrt_engine_horizon_iters": (_I, [_P]),

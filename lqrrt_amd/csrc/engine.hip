@@ -29,6 +29,7 @@
 //   LQRRT_DARE_WAVEFRONTS        auto     steer_wavefronts         1|4: wavefronts per rollout of a Riccati system (auto: 4 for n >= 6, they share the gain)
 //   LQRRT_NN_WG4                 0        launch_nn                1: two-level reduction of the tree scan's partial minima (four wavefronts per workgroup)
 //   LQRRT_SHARD_FOLD             1        gathered_wave_fuses      0: a gathered wave is unpacked by a launch of its own instead of by its first round
+//   LQRRT_CU_XCDS                unset    apply_env_cu_mask        k[:first]: engines run their native loops on a stream restricted to k of the 8 XCDs
 //   LQRRT_SECOND_CHOICE          1        second_choice_enabled    0: a sample whose wanted in-wave parent is being redone waits idly instead of steering from its best standing candidate
 // (Python side: LQRRT_LIB -- load another build of this library, lqrrt_amd/_native.py; LQRRT_FORCE_SHARDED and
 //  LQRRT_BENCH_EVENTS_EVERY -- bench.py; LQRRT_TORQUE_VMIN -- default of the boats' torque_vmin, lqrrt_amd/systems.py, the one
@@ -43,6 +44,7 @@
 #include <hip/hip_ext.h>
 #include <dlfcn.h>
 #include <mutex>
+#include <atomic>
 #include <chrono>
 
 #include <algorithm>

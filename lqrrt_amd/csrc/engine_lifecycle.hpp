@@ -20,6 +20,7 @@ static void refill_drop(lqrrt_engine* e) {
 
 static void free_all(lqrrt_engine* e) {
     refill_drop(e);
+    if (e->cu_stream) { (void)hipStreamSynchronize(e->cu_stream); (void)hipStreamDestroy(e->cu_stream); e->cu_stream = nullptr; }
     if (e->rf_event) (void)hipEventDestroy(e->rf_event);
     if (e->rf_stream) (void)hipStreamDestroy(e->rf_stream);
     if (e->h_cand_pin) (void)hipHostFree(e->h_cand_pin);
@@ -30,7 +31,7 @@ static void free_all(lqrrt_engine* e) {
                     e->tv.xedge, e->tv.uedge, e->tv.ignore, e->d_rec, e->d_pcost, e->d_M,
                     e->d_pidx, e->d_par_done, e->d_par_want, e->d_list,
                     e->d_changed, e->d_stale, e->d_need, e->d_summary, e->d_pool, e->d_pool_trig, e->d_pool_S, e->d_QR, e->d_Sop, e->d_cand, e->d_flags,
-                    e->d_M2, e->d_lf[0], e->d_lf[1], e->d_par2, e->d_stale2, e->d_changed2, e->d_rctl, e->d_rank,
+                    e->d_M2, e->d_lf[0], e->d_lf[1], e->d_par2, e->d_stale2, e->d_changed2, e->d_head2, e->d_rctl, e->d_rank,
                     e->d_blk, e->d_blk_cursor};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -57,6 +58,8 @@ static int alloc_wave(lqrrt_engine* e) {
     HIPCHK(hipMemset(e->d_rec, 0, (size_t)(e->maxW + 4) * e->L.R * sizeof(double)));
     return 0;
 }
+
+static int apply_env_cu_mask(lqrrt_engine* e, int n_cus);
 
 extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int capacity, int max_wave,
                                    lqrrt_engine** out) {
@@ -117,6 +120,7 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     if (!rc) rc = dalloc(&e->d_par2, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_stale2, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_changed2, (size_t)e->maxW);
+    if (!rc) rc = dalloc(&e->d_head2, (size_t)lqrrt_engine::MATRIX_MAX_W * (n + 2 * nw + m * n));
     if (!rc) rc = dalloc(&e->d_rctl, (size_t)16);
     if (!rc) rc = dalloc(&e->d_rank, (size_t)e->maxW);
     if (!rc && hipMemset(e->d_rctl, 0, sizeof(int) * 16) != hipSuccess) rc = fail(LQRRT_E_HIP, "hipMemset failed");
@@ -142,8 +146,54 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     for (int i = 0; i < 624; ++i) e->mt_gen.key[i] = 0;
     e->mt_gen.pos = 624;
     e->mt_base = e->mt_gen;
+    rc = apply_env_cu_mask(e, prop.multiProcessorCount);
+    if (rc) { free_all(e); delete e; return rc; }
     *out = e;
     return 0;
+}
+
+// A stream whose dispatches only go to the CUs in `mask` (bit k of the mask: the driver deals the bits round-robin to the XCDs,
+// so with 8 XCDs bit k is CU k / 8 of XCD k % 8 -- tools/micro/cumask.hip reads HW_REG_XCC_ID under a mask to confirm it on the box).
+// n_words = 0 removes the restriction.  The native loops (lqrrt_engine_extend, lqrrt_engine_extend_sharded) then run on that stream:
+// the caller's stream is drained on entry and the private one on exit, so the call is ordered like any other call on the caller's
+// stream.  Operator calls and the step-by-step wave entry points stay on the caller's stream.
+extern "C" int lqrrt_engine_set_cu_mask(lqrrt_engine* e, const uint32_t* mask, int n_words) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    if (n_words < 0 || n_words > 32 || (n_words > 0 && !mask)) return fail(LQRRT_E_ARG, "bad CU mask");
+    TRY(use_device(e));
+    if (e->cu_stream) {
+        HIPCHK(hipStreamSynchronize(e->cu_stream));
+        HIPCHK(hipStreamDestroy(e->cu_stream));
+        e->cu_stream = nullptr;
+    }
+    e->cu_mask.clear();
+    if (n_words == 0) return 0;
+    bool any = false;
+    for (int i = 0; i < n_words; ++i) any = any || mask[i] != 0;
+    if (!any) return fail(LQRRT_E_ARG, "empty CU mask");
+    e->cu_mask.assign(mask, mask + n_words);
+    HIPCHK(hipExtStreamCreateWithCUMask(&e->cu_stream, (uint32_t)n_words, e->cu_mask.data()));
+    return 0;
+}
+
+// LQRRT_CU_XCDS=k[:first]: every engine created in this process gets a stream on k of the 8 XCDs (all their CUs), engine number i
+// on XCDs (first + i * k) mod 8 ... -- the A/B lever of profiles/r05_cu_mask.txt; unset = the caller's stream, the whole chip.
+static int apply_env_cu_mask(lqrrt_engine* e, int n_cus) {
+    const char* v = getenv("LQRRT_CU_XCDS");
+    if (!v || !*v) return 0;
+    const int k = atoi(v);
+    if (k < 1 || k >= 8) return 0;
+    const char* colon = strchr(v, ':');
+    static std::atomic<int> created{0};
+    const int first = (colon ? atoi(colon + 1) : 0) + created.fetch_add(1) * k;
+    std::vector<uint32_t> mask((size_t)(n_cus + 31) / 32, 0u);
+    for (int b = 0; b < n_cus; ++b) {
+        const int xcd = b & 7;
+        bool mine = false;
+        for (int j = 0; j < k; ++j) mine = mine || xcd == ((first + j) & 7);
+        if (mine) mask[(size_t)b >> 5] |= 1u << (b & 31);
+    }
+    return lqrrt_engine_set_cu_mask(e, mask.data(), (int)mask.size());
 }
 
 extern "C" int lqrrt_engine_destroy(lqrrt_engine* e) {

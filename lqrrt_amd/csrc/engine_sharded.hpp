@@ -241,6 +241,10 @@ extern "C" int lqrrt_engine_extend_sharded(lqrrt_engine* e, lqrrt_comm* c, int s
     if (wave < 1) return fail(LQRRT_E_ARG, "wave must be >= 1");
     if (scheme != LQRRT_SHARD_SAMPLES && scheme != LQRRT_SHARD_TREE) return fail(LQRRT_E_ARG, "unknown sharding scheme %d", scheme);
     TRY(use_device(e));
+    if (e->cu_stream) {                                   // engine-private stream on a subset of the CUs: as in lqrrt_engine_extend
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        stream = (void*)e->cu_stream;
+    }
     hipStream_t st = (hipStream_t)stream;
     lqrrt_extend_stats acc;
     memset(&acc, 0, sizeof acc);
@@ -287,6 +291,7 @@ extern "C" int lqrrt_engine_extend_sharded(lqrrt_engine* e, lqrrt_comm* c, int s
     acc.candidates = e->committed_row;
     acc.speculated = e->tot.speculated - spec0;
     if (out) *out = acc;
+    if (e->cu_stream) HIPCHK(hipStreamSynchronize(e->cu_stream));
     return 0;
 }
 

@@ -103,6 +103,7 @@ struct lqrrt_engine {
     int* d_lf[2] = {nullptr, nullptr};
     int* d_par2 = nullptr;
     unsigned char *d_stale2 = nullptr, *d_changed2 = nullptr;
+    double* d_head2 = nullptr;    // [MATRIX_MAX_W][n + 2 nw + m n]: second copy of the record heads (RoundArgs::head2)
     int* d_rctl = nullptr;        // [16]
     int* d_rank = nullptr;        // [maxW]
     int* h_round = nullptr;       // pinned + mapped [8 + 3*maxW]: hz, round words (2 parities), summary
@@ -166,6 +167,12 @@ struct lqrrt_engine {
     // adaptive wave size (exactness does not depend on W, only speed does)
     double ctl_w = 0.0;
     bool sync_mode = false;             // synchronous wave semantics (LQRRT_WAVE_SYNCHRONOUS) instead of exact
+
+    // Optional engine-private stream restricted to a subset of the CUs (lqrrt_engine_set_cu_mask / LQRRT_CU_XCDS): the native
+    // loops run on it instead of the caller's stream, so that one planner's working set stays in the L2 of the XCDs it runs on
+    // and several planners can own disjoint parts of the chip.
+    hipStream_t cu_stream = nullptr;
+    std::vector<uint32_t> cu_mask;
 
     // counters
     lqrrt_extend_stats tot{};

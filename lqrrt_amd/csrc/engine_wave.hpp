@@ -310,6 +310,7 @@ static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_
         ra.par[0] = e->d_par_done; ra.par[1] = e->d_par2;
         ra.stale[0] = e->d_stale; ra.stale[1] = e->d_stale2;
         ra.changed[0] = e->d_changed; ra.changed[1] = e->d_changed2;
+        ra.head2 = e->d_head2;
         ra.ctl = e->d_rctl; ra.rank = e->d_rank;
         ra.host_ctrl = e->h_round_dev; ra.host_summary = e->h_round_dev + 8;
         ra.fx = e->fix;
@@ -351,7 +352,7 @@ static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_
                 HIPCHK(hipMemcpy(ch.data(), ra.changed[nx], W, hipMemcpyDeviceToHost));
                 HIPCHK(hipMemcpy(sl.data(), ra.stale[nx], W, hipMemcpyDeviceToHost));
                 fprintf(stderr, "[roundstate N=%d W=%d r=%d]", e->N, W, r);
-                for (int t = 0; t < W; ++t) fprintf(stderr, " %d:%d:%d:%d:%d", pr[t], lf[2 * t], lf[2 * t + 1] & 1, (int)ch[t], (int)sl[t]);
+                for (int t = 0; t < W; ++t) fprintf(stderr, " %d:%d:%d:%d:%d", pr[t], lf[2 * t], lf[2 * t + 1] & 1, (int)(ch[t] & 1), (int)sl[t]);
                 fprintf(stderr, "\n");
             }
             if (n_list == 0 && n_defer == 0) break;
@@ -501,6 +502,13 @@ extern "C" int lqrrt_engine_extend(lqrrt_engine* e, int wave, int64_t max_attemp
     memset(&acc, 0, sizeof acc);
     acc.stop_reason = 0;
     const int64_t spec0 = e->tot.speculated;
+    // engine-private stream on a subset of the CUs (lqrrt_engine_set_cu_mask): what the caller queued is finished first, and the
+    // loop's last launches are finished before the call returns, so the call is ordered on the caller's stream as without it
+    if (e->cu_stream) {
+        TRY(use_device(e));
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        stream = (void*)e->cu_stream;
+    }
     while (true) {
         if (max_attempts >= 0 && acc.attempts >= max_attempts) { acc.stop_reason = LQRRT_STOP_ATTEMPTS; break; }
         if (node_limit >= 0 && (int64_t)e->N > node_limit) { acc.stop_reason = LQRRT_STOP_NODES; break; }
@@ -529,5 +537,6 @@ extern "C" int lqrrt_engine_extend(lqrrt_engine* e, int wave, int64_t max_attemp
     acc.candidates = e->committed_row;
     acc.speculated = e->tot.speculated - spec0;
     if (out) *out = acc;
+    if (e->cu_stream) HIPCHK(hipStreamSynchronize(e->cu_stream));
     return 0;
 }

@@ -246,7 +246,14 @@ __global__ __launch_bounds__(64 * WPB) void k_nn_scan(NodeView nv, const double*
     }
     const int t = bx * 64 + lane;
     const int ts = t < W ? t : W - 1;
-    const int i0 = nv.first + (by * WPB + (int)(threadIdx.x >> 6)) * chunk;
+    // The chunk index must be visibly wave-uniform: the node loop below is fed by the scalar unit only if `base` lives in an SGPR.
+    // Round 4 wrote `by * WPB + (threadIdx.x >> 6)` for every WPB; the compiler does not fold the shift for WPB == 1, the loop
+    // index became a vector value, every node fetch a vector load, and the kernels grew from 117 (tree scan) / 96 (in-wave scan) to
+    // 155 / 174 VGPRs, i.e. from 4 / 5 to 3 / 2 wavefronts per SIMD: W = 1024 x 10k nodes 13 -> 27 us (profiles/r05_nn_regression.txt;
+    // tests/test_abi_cpu.py pins the register counts of these instantiations now).
+    int wchunk = by;
+    if constexpr (WPB > 1) wchunk = by * WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i0 = nv.first + wchunk * chunk;
     int i1 = i0 + chunk;
     if (i1 > nv.first + nv.count) i1 = nv.first + nv.count;
     if constexpr (TRI) {
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(64 * WPB) void k_nn_scan(NodeView nv, const double*
             const long long i = base + (lane < cnt ? lane : 0);  // coalesced on the SoA tree
 #pragma unroll
             for (int k = 0; k < S::NW; ++k)
-                werr[k] = wrap_err(gtrig[2 * k], gtrig[2 * k + 1], nv.trig[i * nv.tn + (2 * k) * nv.td],
+                werr[k] = wrap_err_c(gtrig[2 * k], gtrig[2 * k + 1], nv.trig[i * nv.tn + (2 * k) * nv.td],
                                    nv.trig[i * nv.tn + (2 * k + 1) * nv.td]);
         }
         // Nodes are fetched four at a time: an aligned quad of node slots is one 32-byte scalar load per component on
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(64 * WPB) void k_nn_scan(NodeView nv, const double*
                 else if constexpr (MODE == 1)
                     e[S::wd(k)] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(werr[k]), jj),
                                                    __builtin_amdgcn_readlane(__double2loint(werr[k]), jj));
-                else e[S::wd(k)] = wrap_err(gtrig[2 * k], gtrig[2 * k + 1], nd[S::N + 2 * k], nd[S::N + 2 * k + 1]);
+                else e[S::wd(k)] = wrap_err_c(gtrig[2 * k], gtrig[2 * k + 1], nd[S::N + 2 * k], nd[S::N + 2 * k + 1]);
             }
             const double c = quad_cost<S, QC>(e, Suse);
             const int i = base + jj;
@@ -675,7 +682,14 @@ struct RoundArgs {
     int* lf[2];                          // {len, flags} per sample
     int* par[2];                         // parent in use per sample
     unsigned char* stale[2];
-    unsigned char* changed[2];
+    unsigned char* changed[2];           // bit 0: re-steered in the round that wrote it; bit 1: which copy of the record HEAD is current
+    // Second copy of every record's head (xend | trig | K, contiguous like in the record), [W][n + 2 NW + m n].  A sample that re-steers
+    // writes its new head into the copy that is NOT current and flips bit 1 of its `changed` byte for the next round, so that a
+    // workgroup which reads another sample's head during a launch (load_parent) always reads what the PREVIOUS launch left: since
+    // round 4's second-choice rule a sample may steer from a record whose owner is re-steering in the same launch, and an in-place
+    // head let it read a half-written state (same final tree -- the torn rollout is always redone -- but the counts of
+    // rounds and re-steers, which feed the wave-size controller and with it the all-gather sizes of a sharded world, depended on timing).
+    double* head2;
     int* ctl;                            // device: packed {ticket, n_list, n_defer} x 2 (64-bit each), -, -, converged[2], C, acc
     int* rank;                           // device [W]: accepted samples before t (written at convergence)
     int* host_ctrl;                      // pinned: as k_decide's ctrl
@@ -698,35 +712,6 @@ __device__ __forceinline__ const double* gathered_header(const RoundArgs& ra, in
 // value and, in a converged round, on buffers that nobody changed), the kernel boundary publishes the rest.
 enum { RC_PACK = 0, RC_CONV = 6, RC_C = 8, RC_ACC = 9 };
 constexpr unsigned long long RC_ONE_LIST = 1ull << 16, RC_ONE_DEFER = 1ull << 32;
-
-// wave-cooperative: first goal hit among the current records (or W - 1)
-__device__ __forceinline__ int round_horizon(const int* __restrict__ lf, int W, int lane) {
-    int hz = W - 1;
-    for (int t = lane; t < W; t += 64) {
-        if (lf[2 * t] > 0 && (lf[2 * t + 1] & 1)) { hz = t; break; }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) hz = min(hz, __shfl_xor(hz, off));
-    return hz;
-}
-
-// wave-cooperative: k_decide's phase 1 for sample t (t <= horizon): the parent it wants and whether it must be redone
-__device__ __forceinline__ void round_decide(const RoundArgs& ra, int cur, const double* __restrict__ rec, const RecLayout& L,
-                                             int t, int lane, int& want, bool& need) {
-    const double* M = ra.M[cur];
-    double wc = INFINITY;
-    int s = -1;
-    for (int c = lane; c < t; c += 64) {                      // ascending per lane, strict '<': lowest record on ties
-        const double v = M[(size_t)c * ra.W + t];
-        if (v < wc) { wc = v; s = c; }
-    }
-    lexmin_wave(wc, s);
-    const double csnap = rec[(size_t)t * L.R + L.off_cost];
-    const int psnap = (int)rec[(size_t)t * L.R + L.off_parent];
-    want = (s >= 0 && wc < csnap) ? ~s : psnap;
-    need = (want != ra.par[cur][t]) || (ra.stale[cur][t] != 0);
-    if (want < 0 && ra.changed[cur][~want]) need = true;
-}
 
 // Wavefronts per rollout.  A rollout is a serial recurrence that owns its SIMD, where an instruction costs ~6 cycles whatever it
 // is (tools/micro/issue.hip): a step is as long as the instruction count of its longest wavefront, so the work of a step is
@@ -1133,6 +1118,9 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         trig_of<S>(xt, ttrig);
     }
     bool parent_loaded = false;
+    constexpr int HD = S::N + 2 * S::NW + S::M * S::N;            // a record's head: xend | trig | K
+    int psel = 0;                                                  // fused rounds: which copy of an in-wave parent's head is current
+    int head_out = 0;                                              // ... and which copy this sample's new head goes to (RoundArgs::head2)
     auto load_parent = [&](int p) {                                  // state, cos/sin and gain of tree node p >= 0 / record ~p
         if (p >= 0) {
 #pragma unroll
@@ -1142,14 +1130,17 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
 #pragma unroll
             for (int j = 0; j < S::M * S::N; ++j) K[j] = tv.K[(size_t)p * S::M * S::N + j];
         } else {
-            // (round 0 of a gathered wave: the in-wave parent's record is being unpacked by ITS workgroup right now -- read the header)
-            const double* pr = (ron && ra.gblk) ? gathered_header(ra, ~p) : rec + (size_t)(~p) * L.R;
+            // (round 0 of a gathered wave: the in-wave parent's record is being unpacked by ITS workgroup right now -- read the header;
+            //  any other fused round: the copy of the head that the previous launch left current, see RoundArgs::head2)
+            const double* hp = (ron && ra.gblk) ? gathered_header(ra, ~p) + L.off_xend
+                             : (ron && psel)    ? ra.head2 + (size_t)(~p) * HD
+                                                : rec + (size_t)(~p) * L.R + L.off_xend;
 #pragma unroll
-            for (int d = 0; d < S::N; ++d) x[d] = pr[L.off_xend + d];
+            for (int d = 0; d < S::N; ++d) x[d] = hp[d];
 #pragma unroll
-            for (int j = 0; j < 2 * S::NW; ++j) trig[j] = pr[L.off_trig + j];
+            for (int j = 0; j < 2 * S::NW; ++j) trig[j] = hp[S::N + j];
 #pragma unroll
-            for (int j = 0; j < S::M * S::N; ++j) K[j] = pr[L.off_K + j];
+            for (int j = 0; j < S::M * S::N; ++j) K[j] = hp[S::N + 2 * S::NW + j];
         }
     };
     int pref;
@@ -1274,6 +1265,15 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             par_t = ra.par[cur][t];
             stale_t = ra.stale[cur][t];
         }
+        auto flags_of = [&](int idx) -> int {                      // the `changed` byte [cur][idx] from the lanes' prefetched bytes
+            int v = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int w = __shfl((int)chg[i], idx & 63); if ((idx >> 6) == i) v = w; }
+            return v;
+        };
+        auto changed_of = [&](int idx) -> bool { return (flags_of(idx) & 1) != 0; };
+        auto sel_of = [&](int idx) -> int { return (flags_of(idx) >> 1) & 1; };
+        const int sel_t = sel_of(t);                                // the current copy of this sample's own head
         if (conv_flag) {
             // the previous round converged: this launch is the commit.  Sample t's record becomes tree node
             // base + rank[t] if it lies in the committed prefix (tree.py:77-96; what k_append does).
@@ -1281,15 +1281,16 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             const int len = ra.lf[cur][2 * t];
             if (t < C && len > 0) {
                 const int id = ra.base + ra.rank[t];
-                if (lane < S::N) tv.state[(size_t)lane * tv.cap + id] = my[L.off_xend + lane];
-                if (lane < 2 * S::NW) tv.trig[(size_t)lane * tv.cap + id] = my[L.off_trig + lane];
+                const double* hd = sel_t ? ra.head2 + (size_t)t * HD : my + L.off_xend;
+                if (lane < S::N) tv.state[(size_t)lane * tv.cap + id] = hd[lane];
+                if (lane < 2 * S::NW) tv.trig[(size_t)lane * tv.cap + id] = hd[S::N + lane];
                 if constexpr (S::NW > 0) {
                     if (ra.fx.on && lane >= 32 && lane < 32 + S::NW) {
                         const int kk = lane - 32;
-                        tv.werr[(size_t)kk * tv.cap + id] = wrap_err(ra.fx.t[2 * kk], ra.fx.t[2 * kk + 1], my[L.off_trig + 2 * kk], my[L.off_trig + 2 * kk + 1]);
+                        tv.werr[(size_t)kk * tv.cap + id] = wrap_err(ra.fx.t[2 * kk], ra.fx.t[2 * kk + 1], hd[S::N + 2 * kk], hd[S::N + 2 * kk + 1]);
                     }
                 }
-                for (int q = lane; q < S::M * S::N; q += 64) tv.K[(size_t)id * S::M * S::N + q] = my[L.off_K + q];
+                for (int q = lane; q < S::M * S::N; q += 64) tv.K[(size_t)id * S::M * S::N + q] = hd[S::N + 2 * S::NW + q];
                 if (lane == 0) {
                     const int p = ra.par[cur][t];
                     tv.pID[id] = p >= 0 ? p : ra.base + ra.rank[~p];
@@ -1313,12 +1314,6 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             if (hz == ra.W - 1 && lf_len[i] > 0 && (lf_flg[i] & 1)) hz = lane + 64 * i;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) hz = min(hz, __shfl_xor(hz, off));
-        auto changed_of = [&](int idx) -> bool {                   // changed[cur][idx] from the lanes' prefetched bytes
-            int v = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { const int w = __shfl((int)chg[i], idx & 63); if ((idx >> 6) == i) v = w; }
-            return v != 0;
-        };
         if (t <= hz) {
             double wc = INFINITY;
             int sm = -1;
@@ -1329,7 +1324,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             want = (sm >= 0 && wc < csnap_t) ? ~sm : psnap_t;
             need = (want != par_t) || (stale_t != 0);
             if (want < 0 && changed_of(~want)) need = true;
-            if (need) { load_parent(want); parent_loaded = true; }    // (in flight together with the neighbour's column below)
+            if (need) { psel = want < 0 ? sel_of(~want) : 0; load_parent(want); parent_loaded = true; }    // (in flight together with the neighbour's column below)
             if (need && want < 0) {
                 // the in-wave parent's own decision, evaluated here instead of waited for: redone this round -> defer
                 const int sn = ~want;                              // (sn < t <= hz)
@@ -1371,6 +1366,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
                     const int want2 = (sm2 >= 0 && wc2 < csnap_t) ? ~sm2 : psnap_t;
                     if (want2 != par_t || stale_t != 0) {
                         want = want2; defer = false;
+                        psel = want2 < 0 ? sel_of(~want2) : 0;          // (the copy the previous launch left: sm2 may be re-steering right now)
                         parent_loaded = false;                         // (loaded with everybody else's below)
                     }
                 }
@@ -1379,10 +1375,12 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             mark_stale = true;        // beyond the horizon, but its in-wave parent just moved (see k_decide)
         }
         const bool redo = need && !defer;
+        // a new head goes to the copy that is not current (round 0 of a gathered wave: nobody reads the records, in place)
+        head_out = g0 ? 0 : (redo ? sel_t ^ 1 : sel_t);
         if (lane == 0) {
             ra.par[nxt][t] = redo ? want : par_t;
             ra.stale[nxt][t] = redo ? 0 : ((need && defer) || mark_stale ? 1 : stale_t);
-            ra.changed[nxt][t] = redo ? 1 : 0;
+            ra.changed[nxt][t] = (unsigned char)((redo ? 1 : 0) | (head_out << 1));
         }
         if (redo) round_share += RC_ONE_LIST;
         else if (need) round_share += RC_ONE_DEFER;
@@ -1669,7 +1667,8 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
 #pragma unroll
         for (int j = 0; j < S::M * S::N; ++j) node_l[S::N + 2 * S::NW + j] = K[j];
         __syncthreads();
-        for (int q = lane; q < S::N + 2 * S::NW + S::M * S::N; q += 64) my[L.off_xend + q] = node_l[q];
+        double* hd_out = (ron && head_out) ? ra.head2 + (size_t)t * HD : my + L.off_xend;
+        for (int q = lane; q < HD; q += 64) hd_out[q] = node_l[q];
     }
     if (lane == 0) {
         my[L.off_len] = (double)cnt;

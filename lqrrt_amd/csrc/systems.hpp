@@ -108,6 +108,10 @@ __device__ __forceinline__ double quad_bcast(double v) {
 __device__ __forceinline__ double wrap_err(double cg, double sg, double c, double s) {
     return lq_atan2(sg * c - cg * s, cg * c + sg * s);
 }
+// the same bits with the compiler's own fma in the atan2 (include/lqrrt_pmath.h lq_atan2_c): for the NN scans, which live on occupancy
+__device__ __forceinline__ double wrap_err_c(double cg, double sg, double c, double s) {
+    return lq_atan2_c(sg * c - cg * s, cg * c + sg * s);
+}
 
 // np.sum over the last axis of a C-contiguous (N,n) array: plain left-to-right loop for n < 8,
 // 8-lane unrolled pairwise block for n >= 8 (numpy/core/src/umath/loops_utils.h pairwise sum).

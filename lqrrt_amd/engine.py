@@ -53,6 +53,23 @@ class Engine(object):
         nat.check(nat.lib().lqrrt_engine_set_wave_mode(self.h, modes[mode]))
         self.wave_mode = mode
 
+    def set_cu_mask(self, xcds=None, mask=None, n_cus=256):
+        """Runs this engine's native loops on a stream restricted to some of the GPU's compute units (include/lqrrt_hip.h
+        lqrrt_engine_set_cu_mask).  `xcds`: iterable of XCD numbers 0..7 (all CUs of those XCDs), or `mask`: the raw words;
+        neither = the whole chip again.  Speed only."""
+        if mask is None and xcds is not None:
+            want = set(int(x) & 7 for x in xcds)
+            words = np.zeros((n_cus + 31) // 32, dtype=np.uint32)
+            for b in range(n_cus):
+                if (b & 7) in want:
+                    words[b >> 5] |= np.uint32(1 << (b & 31))
+            mask = words
+        if mask is None:
+            nat.check(nat.lib().lqrrt_engine_set_cu_mask(self.h, None, 0))
+            return
+        mask = np.ascontiguousarray(mask, dtype=np.uint32)
+        nat.check(nat.lib().lqrrt_engine_set_cu_mask(self.h, nat.ptr(mask), int(mask.size)))
+
     def sync_geometry(self):
         """Re-uploads parameters, hull points, obstacles and occupancy grid if the system object changed since
         this engine last saw it (system.revision; e.g. set_occupancy_grid between two plans)."""

@@ -179,6 +179,52 @@ def test_steer_kernels_use_no_scratch():
     two_level = [r for r in scan if r["name"].split("(")[0].rstrip(">").endswith(", 4")]
     assert two_level and all(r["scratch"] == 0 and r["lds"] == 4 * 64 * (8 + 4) for r in two_level)
     assert all(r["scratch"] == 0 and r["lds"] == 0 for r in scan if r not in two_level)
+    # Round 5: the scan's speed is its occupancy (profiles/r05_nn_regression.txt -- in round 4 an innocent
+    # `by * WPB + (threadIdx.x >> 6)` made the node loop's index a vector value: vector loads instead of s_load_dwordx8, 117 -> 155
+    # VGPRs, 4 -> 3 wavefronts per SIMD, 13 -> 27 us for the full-size launch, and nothing noticed).  Wavefronts per SIMD that the
+    # instantiations of the bench configurations must keep: <system, S form, in-wave, patch, WPB>.
+    def occ(sys_, dense, tri, patch, wpb):
+        key = "lq::k_nn_scan<lq::%s, %d, %s, %s, %d>" % (sys_, dense, "true" if tri else "false", "true" if patch else "false", wpb)
+        hit = [r for r in scan if r["name"].startswith("void " + key)]
+        assert len(hit) == 1, key
+        return hit[0]["occupancy"]
+    for sys_ in ("BoatAdvanced", "BoatIntermediate", "BoatNovice", "RosBoat", "BoatNoviceLqr"):
+        assert occ(sys_, 0, False, False, 1) >= 4 and occ(sys_, 0, False, True, 1) >= 4 and occ(sys_, 0, True, False, 1) >= 5, sys_
+        assert occ(sys_, 0, False, False, 4) >= 4, sys_
+    assert occ("Car", 0, False, False, 1) >= 4 and occ("Car", 0, True, False, 1) >= 4
+    assert occ("Pendulum", 0, False, False, 1) >= 6 and occ("Pendulum", 0, True, False, 1) >= 6
+    assert occ("DoubleIntegratorT<6>", 3, False, False, 1) >= 4 and occ("DoubleIntegratorT<6>", 3, True, False, 1) >= 7
+
+
+def test_scan_node_loop_is_fed_by_the_scalar_unit():
+    """The ISA of the headline tree scan: its node fetches are s_load_dwordx8 (four nodes of one state component), and vector
+    memory instructions appear only outside the node loop (samples in, partial minima out, the ignore words)."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not shutil.which(hipcc) and not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    d = tempfile.mkdtemp()
+    src = os.path.join(d, "scan_only.hip")
+    with open(src, "w") as f:
+        f.write('#include <hip/hip_runtime.h>\n#include "kernels.hpp"\nnamespace lq {\n'
+                'template __global__ void k_nn_scan<BoatAdvanced, 0, false, false, 1>(NodeView, const double*, const double*, int, '
+                'const double*, int, double*, int*, int, int, IgnPatch);\n'
+                'template __global__ void k_nn_scan<BoatAdvanced, 0, false, false, 4>(NodeView, const double*, const double*, int, '
+                'const double*, int, double*, int*, int, int, IgnPatch);\n}\n')
+    asm = os.path.join(d, "scan_only.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
+                           "-I", os.path.join(ROOT, "lqrrt_amd", "csrc"), "-I", os.path.join(ROOT, "include"), src, "-o", asm])
+    text = open(asm).read()
+    for wpb in (1, 4):
+        name = "_ZN2lq9k_nn_scanINS_12BoatAdvancedELi0ELb0ELb0ELi%dEEEvNS_8NodeViewEPKdS4_iS4_iPdPiiiNS_8IgnPatchE:" % wpb
+        body = text[text.index("\n" + name):]
+        body = body[:body.index("s_endpgm")]
+        n_s8 = body.count("s_load_dwordx8")
+        n_vec = body.count("global_load_") + body.count("flat_load_") + body.count("buffer_load_")
+        assert n_s8 >= 12, (wpb, n_s8)              # three modes x (6 state components + angle data) in two loop forms
+        assert n_vec <= 16, (wpb, n_vec)            # round 4's broken build: 99
 
 
 def test_planner_call_budget_follows_the_clock():

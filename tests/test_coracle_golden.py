@@ -73,7 +73,9 @@ def _boat_advanced_free_run(o, g, tries):
         d = np.flatnonzero(p[:n] != q[:n])
         return int(d[0]) if len(d) else n
     first = prefix(o)
-    assert first >= 150, "parents diverge from the reference at node %d" % first
+    # (the measured first divergence of the default torque form, one atan2 above 1 cm/s: node 152 on every fixture of this problem;
+    #  with the reference's sequence 201 = never / 211 / 211 -- tests/test_hip_parity.py FREE_RUN_FIRST_DIVERGENCE has the table)
+    assert first == 152, "parents leave the reference's at node %d" % first
     err = np.abs(o.states()[:first] - g["state"][:first]).max(axis=1)
     assert np.median(err) < 1e-12 and np.mean(err < 1e-9) > 0.8
     s = lqrrt_amd.systems.SYSTEMS["boat_advanced"](0)

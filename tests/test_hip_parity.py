@@ -105,14 +105,26 @@ TRAJ = [("boat_intermediate", "300", 256), ("boat_novice", "300", 256), ("car", 
         ("car", "guide", 64), ("boat_intermediate", "guide", 16)]
 
 
-@pytest.mark.parametrize("tag,wave,min_prefix", [("200", 64, 150), ("200", 1024, 150), ("3000", 1024, 150), ("10k", 1024, 150)])
-def test_boat_advanced_free_run_conditioning_smoke(golden_dir, tag, wave, min_prefix):
-    """NOT parity evidence -- a conditioning smoke test.  Chaotic problem: the free run agrees with the reference's run up to
-    the first ulp-triggered divergence and the test only asks that this is not earlier than node 150.  The parity statement
-    for this problem is teacher forcing (tests/test_teacher_gpu.py: every decision of the reference replayed from the
-    reference's own tree) plus bit-equality with the sequential C oracle (tests/test_hip_vs_coracle.py)."""
+# First node at which the free run's parent array leaves the reference's (len(pID) = never), measured for BOTH settings of the heading
+# torque on the three fixtures (round 5, VERDICT r04 item 4: the one-atan2 default was kept on an 8-seed A/B, +6.9 % mean,
+# profiles/r05_ab_torque_seeds.txt -- this table is what it costs in fidelity, on record).  The numbers are properties of the
+# arithmetic, not of the GPU: the sequential C oracle gives the same ones on the CPU (tests/test_coracle_golden.py), the first
+# differing DECISION is iteration 1264 (vmin = 0.01) / 1381 (inf: an edge one step shorter that leaves the parents alone for a while).
+FREE_RUN_FIRST_DIVERGENCE = {("200", 0.01): 152, ("3000", 0.01): 152, ("10k", 0.01): 152,
+                             ("200", np.inf): 201, ("3000", np.inf): 211, ("10k", np.inf): 211}
+
+
+@pytest.mark.parametrize("tag,wave,vmin", [("200", 64, 0.01), ("200", 1024, 0.01), ("3000", 1024, 0.01), ("10k", 1024, 0.01),
+                                           ("3000", 1024, np.inf), ("10k", 256, np.inf)])
+def test_boat_advanced_free_run_conditioning_smoke(golden_dir, tag, wave, vmin):
+    """NOT parity evidence -- a conditioning record.  Chaotic problem: the free run agrees with the reference's run up to
+    the first ulp-triggered divergence; the test pins WHERE that is for the default torque form (one atan2 above 1 cm/s) and for
+    the reference's sequence (torque_vmin = inf), so that a change of rounding anywhere in the rollout shows up here as a moved
+    number.  The parity statement for this problem is teacher forcing (tests/test_teacher_gpu.py: every decision of the reference
+    replayed from the reference's own tree) plus bit-equality with the sequential C oracle (tests/test_hip_vs_coracle.py)."""
     g = _load(golden_dir, "traj_boat_advanced_%s.npz" % tag)
     s = _system("boat_advanced")
+    s.torque_vmin = vmin
     p = _planner(s, int(g["max_nodes"]), wave_size=wave)
     np.random.seed(1)
     assert p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10) is False
@@ -120,7 +132,7 @@ def test_boat_advanced_free_run_conditioning_smoke(golden_dir, tag, wave, min_pr
     assert len(pid) == len(g["pID"])
     diff = np.flatnonzero(pid != g["pID"])
     first = int(diff[0]) if len(diff) else len(pid)
-    assert first >= min_prefix, "parents diverge from the reference at node %d" % first
+    assert first == FREE_RUN_FIRST_DIVERGENCE[(tag, vmin)], "parents leave the reference's at node %d" % first
     err = np.abs(p.tree.state[:first] - g["state"][:first]).max(axis=1)
     assert np.median(err) < 1e-12
     assert np.mean(err < ATOL) > 0.8

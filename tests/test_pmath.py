@@ -14,6 +14,7 @@ SRC = """
 #include "lqrrt_pmath.h"
 void v_sincos(const double* x, int n, double* s, double* c){ for(int i=0;i<n;i++) lq_sincos(x[i], &s[i], &c[i]); }
 void v_atan2(const double* y, const double* x, int n, double* a){ for(int i=0;i<n;i++) a[i]=lq_atan2(y[i],x[i]); }
+void v_atan2_c(const double* y, const double* x, int n, double* a){ for(int i=0;i<n;i++) a[i]=lq_atan2_c(y[i],x[i]); }
 void v_tanh(const double* x, int n, double* t){ for(int i=0;i<n;i++) t[i]=lq_tanh(x[i]); }
 """
 
@@ -61,6 +62,9 @@ def test_atan2_accuracy_and_zeros(pm):
     P = C.c_void_p
     pm.v_atan2(ys.ctypes.data_as(P), xs.ctypes.data_as(P), len(ys), a.ctypes.data_as(P))
     assert max(_ulps(g, mp.atan2(mp.mpf(float(y)), mp.mpf(float(x)))) for g, y, x in zip(a, ys, xs)) <= 2.0
+    ac = np.zeros_like(ys)                        # the compiler-fma spelling the NN scans use: the same bits
+    pm.v_atan2_c(ys.ctypes.data_as(P), xs.ctypes.data_as(P), len(ys), ac.ctypes.data_as(P))
+    np.testing.assert_array_equal(a.view(np.uint64), ac.view(np.uint64))
     sy = np.array([0.0, -0.0, 0.0, -0.0, 1.0, -1.0, 3.0, 0.0])
     sx = np.array([1.0, 1.0, -1.0, -1.0, 0.0, 0.0, -0.0, -0.0])
     sa = np.zeros_like(sy)
