@@ -193,10 +193,13 @@ static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
     *n_chunks = std::max(1, (count + c - 1) / c);
 }
 
-// When the two-level scan is the default (LQRRT_NN_WG4 overrides): decided by the A/B of round 4 (profiles/r04_ab_wg4.txt)
+// When the two-level scan is the default (LQRRT_NN_WG4 overrides).  Round 4 measured it on a scan whose node loop had lost its scalar
+// loads (profiles/r05_nn_regression.txt) and found +2 %; on the repaired loop (profiles/r05_ab_wg4.txt, same box, interleaved):
+// config 5 (50k nodes x 12 states) scan 61.4 -> 54.3 us per launch, 1.42 -> 1.51e6 attempts/s (+6.3 %); the headline's 10k-node
+// tree +1 % (noise), its synchronous mode -0.5 %.  So: on for large tables only.
 static bool nn_wg4_default(int W, int count) {
-    (void)W; (void)count;
-    return false;
+    (void)W;
+    return count >= 32768;
 }
 
 // NN over a node table for W samples at xs (device, [W][n]); writes id/cost and/or records.

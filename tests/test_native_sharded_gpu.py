@@ -16,11 +16,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _make(name, cap, wave, seed=1, sync=False, **sys_kw):
+def _make(name, cap, wave, seed=1, sync=False, device=0, **sys_kw):
     import lqrrt_amd
     from lqrrt_amd.engine import Engine
     s = lqrrt_amd.systems.DoubleIntegrator(**sys_kw) if name == "double_integrator" else lqrrt_amd.systems.SYSTEMS[name](0)
-    eng = Engine(s, capacity=cap, max_wave=wave)
+    eng = Engine(s, capacity=cap, max_wave=wave, device=device)
     kw = s.plan_kwargs
     eng.set_resolution(kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer))
     space = np.array(s.sample_space, dtype=np.float64)
@@ -192,6 +192,80 @@ def test_two_processes_through_the_collective_entry_point(tail):
         assert rc == 0 and "OK" in o, o[-1500:] + e[-2500:]
     stats = [o.split("STATS")[1].split("OK")[0].strip() for _, o, _ in outs]
     assert stats[0] == stats[1], stats                # same waves / rounds / re-steers on both ranks
+
+
+_TWO_DEVICE_CHILD = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import torch
+import test_native_sharded_gpu as t
+from lqrrt_amd.parallel import NativeComm
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+dev = rank if os.environ["LQRRT_TEST_PATH"] == "rccl" else 0
+torch.cuda.set_device(dev)
+uid = bytes.fromhex(os.environ["LQRRT_TEST_UID"])
+comm = NativeComm(rank, world, device=dev, uid=uid)
+out = []
+for name, nodes, wave, scheme in (("car", 1200, 256, "sample"), ("double_integrator", 2500, 256, "tree"), ("boat_advanced", 1500, 256, "sample")):
+    _, ref = t._make(name, nodes + wave + 8, wave, device=dev)
+    rs = ref.extend(wave, node_limit=nodes)
+    _, eng = t._make(name, nodes + wave + 8, wave, device=dev)
+    st = eng.extend_sharded(comm, scheme, wave, node_limit=nodes)
+    assert (st.attempts, st.accepted, st.goal_hits) == (rs.attempts, rs.accepted, rs.goal_hits), (name, scheme)
+    t._same_tree(eng, ref)
+    out.append((st.waves, st.fix_rounds, st.resteers, st.attempts))
+comm.close()
+print("RANK", rank, "DEVICE", dev, "STATS", out, "OK")
+"""
+
+
+def test_two_ranks_on_two_devices_through_real_rccl():
+    """What an 8-GPU box would run, in its smallest form: two ranks in two processes on devices 0 and 1, the
+    REAL communicator (ncclCommInitRank / ncclAllGather of the librccl PyTorch ships, resolved by the engine itself), sample-sharded
+    car-1200 and boat-1500, tree-sharded double-integrator-2500 -- each rank's parents / states / gains / edges / ignore set / best plan
+    equal to the single engine on its device, and waves / fix_rounds / resteers equal on both ranks (the wave-size controller, hence the
+    all-gather sizes, must be replicated).  On a box with ONE device the same child runs both ranks on device 0 through the
+    shared-memory double of librccl (tests/stub_rccl): never a skip; the path taken is printed."""
+    import subprocess, sys
+    import ctypes as C
+    import torch
+    from lqrrt_amd.parallel import NativeComm
+    two = torch.cuda.device_count() >= 2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LQRRT_TEST_PATH="rccl" if two else "stub")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if two:
+        env.pop("LQRRT_RCCL", None)
+        uid = NativeComm.unique_id()                              # ncclGetUniqueId of the real library, made here, carried by the environment
+    else:
+        stub = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub_rccl", "libstub_rccl.so")
+        if not os.path.exists(stub):
+            pytest.fail("tests/stub_rccl/libstub_rccl.so is missing: __graft_entry__.build() compiles it")
+        lib = C.CDLL(stub)
+        buf = (C.c_char * 128)()
+        assert lib.ncclGetUniqueId(buf) == 0
+        uid = bytes(buf)
+        env["LQRRT_RCCL"] = stub
+    env["LQRRT_TEST_UID"] = bytes(uid).hex()
+    print("two-rank parity path: %s" % ("real RCCL, devices 0 and 1" if two else "one device: shared-memory double of librccl"))
+    code = _TWO_DEVICE_CHILD % dict(root=root, tests=os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank hung")
+        outs.append((p.returncode, o, e))
+    for rc, o, e in outs:
+        assert rc == 0 and "OK" in o, o[-1500:] + e[-2500:]
+        print(o.strip().splitlines()[-1])
+    stats = [o.split("STATS")[1].split("OK")[0].strip() for _, o, _ in outs]
+    assert stats[0] == stats[1], stats
 
 
 def test_legacy_repair_path_for_waves_beyond_256():

@@ -55,3 +55,61 @@ def test_switches_do_not_change_the_tree():
                 {"LQRRT_STEER_WAVEFRONTS": "2"}, {"LQRRT_SECOND_CHOICE": "0"},
                 {"LQRRT_REFILL_AHEAD": "0", "LQRRT_IGNORE_PATCH": "0", "LQRRT_STEER_WAVEFRONTS": "2", "LQRRT_SECOND_CHOICE": "0"}):
         assert _run(env) == base, env
+
+
+def _grow(system_name, nodes, seed=1, xcds=None, wave=1024):
+    import numpy as np
+    import lqrrt_amd
+    from lqrrt_amd.engine import Engine
+    s = lqrrt_amd.systems.SYSTEMS[system_name](0)
+    eng = Engine(s, capacity=nodes + 1024 + 64, max_wave=1024)
+    kw = s.plan_kwargs
+    eng.set_resolution(kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer))
+    space = np.array(s.sample_space, dtype=np.float64)
+    eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), np.array(s.goal_bias, dtype=np.float64), 10)
+    st = np.random.RandomState(seed).get_state()
+    eng.set_mt19937(st[1], st[2])
+    if xcds is not None:
+        eng.set_cu_mask(xcds=xcds)
+    eng.tree_reset(s.x0)
+    stats = eng.extend(wave, node_limit=nodes)
+    h = hashlib.sha256()
+    for a in (eng.states(), eng.gains(), eng.parents()):
+        h.update(np.ascontiguousarray(a).tobytes())
+    out = (eng.size, stats.attempts, stats.waves, stats.fix_rounds, stats.resteers, stats.goal_hits, h.hexdigest())
+    eng.close()
+    return out
+
+
+def test_round_counts_do_not_depend_on_timing():
+    """with the second-choice rule a sample may steer from a record whose owner re-steers in the same launch.
+    Round 4 read that record in place -- a torn read whose rollout was always redone (same tree) but which made the COUNT of repair
+    rounds and re-steers depend on timing, and the wave-size controller (hence the all-gather sizes of a sharded world) with it.
+    Round 5 double-buffers the record heads (RoundArgs::head2).  Here: the same 4,000-node growth alone and three times with two
+    other planners hammering the same GPU from other threads -- waves, rounds, re-steers and the tree must be identical."""
+    import threading
+    alone = _grow("boat_advanced", 4000)
+    assert alone[3] > 300 and alone[4] > 2000                      # enough rounds and re-steers for a race to show
+    stop = threading.Event()
+
+    def noise(seed):
+        while not stop.is_set():
+            _grow("boat_advanced", 1500, seed=seed)
+    threads = [threading.Thread(target=noise, args=(k,)) for k in (7, 8)]
+    for th in threads:
+        th.start()
+    try:
+        for _ in range(3):
+            assert _grow("boat_advanced", 4000) == alone
+    finally:
+        stop.set()
+        for th in threads:
+            th.join()
+
+
+def test_cu_mask_changes_nothing_but_placement():
+    """lqrrt_engine_set_cu_mask: the native loop on a stream restricted to one / two XCDs grows the same tree with the same counts."""
+    base = _grow("boat_advanced", 2500)
+    assert _grow("boat_advanced", 2500, xcds=[0]) == base
+    assert _grow("boat_advanced", 2500, xcds=[2, 5]) == base
+    assert _grow("car", 1200, wave=256, xcds=[7]) == _grow("car", 1200, wave=256)

@@ -550,6 +550,69 @@ def gen_riccati(name, max_nodes, tag=None):
         path, len(nearest), out["n_candidates"], tree.size, out["pid_hash"], bool(planner.plan_reached_goal), wall))
 
 
+def gen_chain(name="car", plans=3, max_nodes=400, frac=0.75):
+    """The ROS node's tree chain, made deterministic (lqrrt_node.py:444-484; planner.py:172,311-334,451-464): `plans` chained
+    update_plan calls on ONE reference Planner, fake clock, each ended by the node limit, plan k+1 seeded at
+    get_state(frac * T_k) of plan k (the node seeds at get_ref(next_runtime)), the obstacle table swapped after the first plan
+    (the node writes module globals of the plugin file between plans, :260-263).  Fixture: every tree (parents, states, gains,
+    edge lengths), every seed, every plan (node_seq, x_seq, u_seq, T), iterations and sampler rows per plan, the swapped table."""
+    rl.TIES_STABLE = True
+    ns = rl.load_demo(name, OBS_SEED)
+    planner = rl.make_planner(name, ns, max_nodes)
+    n = ns["nstates"]
+    obs_a = np.array(ns["obs"], dtype=np.float64)
+    obs_b = np.copy(obs_a)
+    obs_b[:, 0] = np.round(obs_a[:, 0] + 2.5, 2)                 # the same field shifted: the old plan now grazes obstacles
+    obs_b[::2, 1] = np.round(obs_a[::2, 1] - 1.75, 2)
+    out = dict(plans=np.int64(plans), max_nodes=np.int64(max_nodes), frac=np.float64(frac), obs_a=obs_a, obs_b=obs_b,
+               plan_seeds=np.array([PLAN_SEED + 100 + k for k in range(plans)], dtype=np.int64))
+    x0 = np.array(rl.x0_of(name, ns), dtype=np.float64)
+    steer = planner._steer
+    count = [0]
+
+    def steer_spy(ID, xtar, force_arrive=False):
+        count[0] += 1
+        return steer(ID, xtar, force_arrive)
+    planner._steer = steer_spy
+    for k in range(plans):
+        if k == 1:
+            ns["obs"] = obs_b                                    # the plugin's global table rebound, as the node rewrites module globals
+                                                                 # (NOT in place: demo_car.py's table is an int64 array and would truncate)
+        count[0] = 0
+        np.random.seed(int(out["plan_seeds"][k]))
+        ret = planner.update_plan(x0, ns["sample_space"], goal_bias=ns["goal_bias"], xrand_gen=10)
+        probe = np.random.sample()
+        rs = np.random.RandomState(int(out["plan_seeds"][k]))
+        stream = rs.random_sample((count[0] * 12 + 64) * (n + 1))
+        pos = int(np.flatnonzero(stream == probe)[0])
+        assert pos % (n + 1) == 0
+        tree = planner.tree
+        pre = "p%d_" % k
+        out[pre + "x0"] = np.copy(x0)
+        out[pre + "returned"] = np.bool_(ret)
+        out[pre + "reached_goal"] = np.bool_(planner.plan_reached_goal)
+        out[pre + "iterations"] = np.int64(count[0])
+        out[pre + "n_candidates"] = np.int64(pos // (n + 1))
+        out[pre + "pID"] = np.array(tree.pID, dtype=np.int32)
+        out[pre + "state"] = np.array(tree.state, dtype=np.float64)
+        out[pre + "K"] = np.array([lk[1] for lk in tree.lqr], dtype=np.float64)
+        out[pre + "edge_len"] = np.array([len(q) for q in tree.x_seq], dtype=np.int32)
+        out[pre + "node_seq"] = np.array(planner.node_seq, dtype=np.int32)
+        out[pre + "plan_x"] = np.array(planner.x_seq, dtype=np.float64)
+        out[pre + "plan_u"] = np.array(planner.u_seq, dtype=np.float64)
+        out[pre + "plan_T"] = np.float64(planner.T)
+        ts = np.array([0.0, 0.25 * planner.T, frac * planner.T, planner.T, 1.5 * planner.T])
+        out[pre + "interp_t"] = ts
+        out[pre + "interp_x"] = np.array([planner.get_state(t) for t in ts], dtype=np.float64)
+        out[pre + "interp_u"] = np.array([planner.get_effort(t) for t in ts], dtype=np.float64)
+        print("plan %d: seed state %s -> %d nodes, %d iterations, goal=%s, T=%.2f, hash=%s" % (
+            k, np.round(x0, 3), tree.size, count[0], bool(planner.plan_reached_goal), planner.T, pid_hash(tree.pID)))
+        x0 = np.array(planner.get_state(frac * planner.T), dtype=np.float64)
+    path = os.path.join(OUT, "chain_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("wrote %s (%d KB)" % (path, os.path.getsize(path) // 1024))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--long", action="store_true", help="also run boat_advanced to 10k nodes (~20 min)")
@@ -586,6 +649,8 @@ def main():
         "plqr600": lambda: gen_pendulum_lqr(600),
         # the same pipeline at the metric's dimension: demo_boat_novice dynamics, 6 states / 3 controls, Riccati lqr about (x, 0)
         "bnlqr400": lambda: gen_riccati("boat_novice_lqr", 400),
+        # three chained plans on the car with a map swap in between (lqrrt_node.py:444-484), every tree / seed / plan
+        "chain_car": lambda: gen_chain("car"),
     }
     if args.job:
         jobs[args.job]()

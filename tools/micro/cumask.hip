@@ -24,6 +24,7 @@ __global__ void k_touch(double* p, int n) {
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int ncu = prop.multiProcessorCount;
