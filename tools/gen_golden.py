@@ -474,11 +474,11 @@ def gen_config5(max_nodes=600, n_boxes=3000, tag=None):
         path, len(nearest), out["n_candidates"], tree.size, out["pid_hash"], bool(planner.plan_reached_goal), int(np.sum(ties)), wall))
 
 
-def gen_pendulum_lqr(max_nodes=120, tag=None):
-    return gen_riccati("pendulum_lqr", max_nodes, tag)
+def gen_pendulum_lqr(max_nodes=120, tag=None, eps=None):
+    return gen_riccati("pendulum_lqr", max_nodes, tag, eps=eps)
 
 
-def gen_riccati(name, max_nodes, tag=None):
+def gen_riccati(name, max_nodes, tag=None, eps=None):
     """
     The north-star steer pipeline on the reference itself: the REFERENCE's Planner with the callbacks of
     oracle/systems_np.PendulumLqr / BoatNoviceLqr, whose lqr linearises the demo's dynamics by central differences and calls
@@ -487,7 +487,7 @@ def gen_riccati(name, max_nodes, tag=None):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     from systems_np import SYSTEMS
     lq = rl.import_reference()
-    s = SYSTEMS[name](OBS_SEED)
+    s = SYSTEMS[name](OBS_SEED) if eps is None else SYSTEMS[name](OBS_SEED, eps=eps)     # eps: step of the central differences
     cons = lq.Constraints(nstates=s.nstates, ncontrols=s.ncontrols, goal_buffer=s.goal_buffer, is_feasible=s.is_feasible)
     planner = lq.Planner(s.dynamics, s.lqr, cons, error_tol=s.error_tol, erf=s.erf, min_time=60, max_time=61, max_nodes=max_nodes,
                          goal0=s.goal, printing=False, sys_time=lambda: 0.0, **s.plan_kwargs)
@@ -527,24 +527,6 @@ def gen_riccati(name, max_nodes, tag=None):
         out["edge_%s_x" % tagid] = np.array(tree.x_seq[ID], dtype=np.float64)
         out["edge_%s_u" % tagid] = np.array(tree.u_seq[ID], dtype=np.float64)
     path = os.path.join(OUT, "traj_%s_%s.npz" % (name, tag or str(max_nodes)))
-    if edges_only:
-        # EVERY edge interior of the run (tree.x_seq / u_seq, tree.py:121-132) and the plan's interpolators at 64 times
-        # (planner.py:451-464), in a file of their own next to the traj fixture of the SAME run (asserted)
-        old = np.load(path)
-        assert str(old["pid_hash"]) == str(out["pid_hash"]) and np.array_equal(old["state"], out["state"]), "not the committed run"
-        e = dict(pid_hash=out["pid_hash"], edge_len=edge_len,
-                 x_cat=np.concatenate([np.array(q, dtype=np.float64).reshape(-1, n) for q in tree.x_seq]),
-                 u_cat=np.concatenate([np.array(q, dtype=np.float64).reshape(-1, ns["ncontrols"]) for q in tree.u_seq]))
-        assert len(e["x_cat"]) == int(edge_len.sum())
-        if np.isfinite(planner.T) and planner.T > 0:
-            ts = np.concatenate((np.linspace(0.0, float(planner.T), 60), [-1.0, 1.25 * float(planner.T), 0.5 * planner.dt, float(planner.T) - 1e-9]))
-            e["interp_t"] = ts
-            e["interp_x"] = np.array([planner.get_state(t) for t in ts], dtype=np.float64)
-            e["interp_u"] = np.array([planner.get_effort(t) for t in ts], dtype=np.float64)
-        epath = os.path.join(OUT, "edges_%s_%s.npz" % (name, tag or str(max_nodes)))
-        np.savez_compressed(epath, **e)
-        print("wrote %s: %d edges, %d rows, plan T=%s, %d KB" % (epath, tree.size, len(e["x_cat"]), planner.T, os.path.getsize(epath) // 1024))
-        return
     np.savez_compressed(path, **out)
     print("wrote %s: iters=%d cand=%d nodes=%d hash=%s goal=%s wall=%.1fs" % (
         path, len(nearest), out["n_candidates"], tree.size, out["pid_hash"], bool(planner.plan_reached_goal), wall))
@@ -647,6 +629,9 @@ def main():
         # finite-difference linearise -> DARE -> K rollout on the reference's Planner (scipy.linalg.solve_discrete_are)
         "plqr120": lambda: gen_pendulum_lqr(120),
         "plqr600": lambda: gen_pendulum_lqr(600),
+        # the same run with a linearisation step of 1e-4 instead of 1e-6: the finite differences of a dt = 1 ms model then carry
+        # 1e-12 instead of 1e-10 of rounding noise, which the ill-conditioned Riccati equation amplifies (tests/test_pendulum_lqr.py)
+        "plqr600e4": lambda: gen_pendulum_lqr(600, tag="600_eps1e-4", eps=1e-4),
         # the same pipeline at the metric's dimension: demo_boat_novice dynamics, 6 states / 3 controls, Riccati lqr about (x, 0)
         "bnlqr400": lambda: gen_riccati("boat_novice_lqr", 400),
         # three chained plans on the car with a map swap in between (lqrrt_node.py:444-484), every tree / seed / plan
