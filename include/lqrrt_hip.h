@@ -398,6 +398,19 @@ int lqrrt_engine_extend_sharded(lqrrt_engine* e, lqrrt_comm* c, int scheme, int 
                                 int64_t node_limit, int until_size, int pruning, int stop_on_goal,
                                 lqrrt_extend_stats* out, void* stream);
 
+/* Several INDEPENDENT engines (trees) advanced together, natively: the loop of lqrrt_engine_extend for each of the n engines, in
+ * lock step, with two kernel launches per step whose grids span all of them (the scans of the engines that begin a wave; every
+ * engine's steer launch -- speculative launch, fused repair round or append).  No counterpart in the reference, which plans one
+ * tree per Planner on one core (planner.py:233-290); the ROS node keeps three Planners and uses one at a time (lqrrt_node.py).  Every
+ * engine's result is exactly what lqrrt_engine_extend gives it alone (same stop rules per engine: max_attempts, node_limit,
+ * until_size, stop_on_goal); only the wall clock is shared -- a single planner cannot fill the chip (its launches are dependent
+ * and small), n planners can.  Calls with 4 or more engines are cut into groups, each advanced by a host thread and a stream of
+ * its own.  out: n stats blocks (or NULL).  Restrictions: 1 <= n <= 128 distinct engines of one model, one
+ * horizon and one device, exact wave mode, analytic-gain systems, waves of up to 256 samples.  After an error every engine of the
+ * call must be reset (lqrrt_tree_reset) before it is used again. */
+int lqrrt_engine_extend_multi(lqrrt_engine** engines, int n, int wave, int64_t max_attempts, int64_t node_limit, int until_size,
+                              int pruning, int stop_on_goal, lqrrt_extend_stats* out, void* stream);
+
 /* Goal bookkeeping (planner.py:260-283): number of goal hits so far and the node id of
  * the best (shortest, first on ties) plan end, its length in steps; -1 if none. */
 int lqrrt_plan_best(lqrrt_engine* e, int32_t* end_node, int64_t* steps, int64_t* hits);

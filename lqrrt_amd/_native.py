@@ -105,6 +105,7 @@ SIGNATURES = {
     "lqrrt_wave_steer_candidates": (_I, [_P, _I, _I, _P, _P]),
     "lqrrt_wave_commit": (_I, [_P, _I, _I64, _I64, _I, C.POINTER(ExtendStats), _P]),
     "lqrrt_engine_extend": (_I, [_P, _I, _I64, _I64, _I, _I, _I, C.POINTER(ExtendStats), _P]),
+    "lqrrt_engine_extend_multi": (_I, [_P, _I, _I, _I64, _I64, _I, _I, _I, _P, _P]),
     "lqrrt_comm_unique_id": (_I, [_P]),
     "lqrrt_comm_create": (_I, [_P, _I, _I, _I, C.POINTER(_P)]),
     "lqrrt_comm_create_loopback": (_I, [_I, _I, C.POINTER(_P)]),

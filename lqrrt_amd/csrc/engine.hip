@@ -45,6 +45,7 @@
 #include <dlfcn.h>
 #include <mutex>
 #include <atomic>
+#include <thread>
 #include <chrono>
 
 #include <algorithm>
@@ -98,6 +99,7 @@ static int fail(int code, const char* fmt, ...) {
 #include "engine_sampler.hpp"     // sample stream
 #include "engine_wave.hpp"        // ABI: wave_speculate / wave_commit / engine_extend
 #include "engine_sharded.hpp"     // ABI: comm_*, allgather_nodes, engine_extend_sharded
+#include "engine_multi.hpp"       // ABI: engine_extend_multi (several engines in lock step, two launches per tick)
 
 // --------------------------------------------------------------------------------------------
 // Shader clock and issue rate, measured (bench.py reports them next to every latency-bound figure; tools/micro/clock.hip is
@@ -155,30 +157,4 @@ extern "C" int lqrrt_clock_probe(int device, double* shader_mhz, double* ns_depe
     return 0;
 }
 
-#ifdef STEER_TIMING
-// debug build only (tools/ablate_steer.py): phase timestamps of block 0 of the last steer launch, 100 MHz ticks
-extern "C" int lqrrt_debug_steer_ts(unsigned long long* out8) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lq::g_steer_ts), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    return 0;
-}
-extern "C" int lqrrt_debug_loop_hist(unsigned long long* out32) {
-    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(lq::g_loop_hist), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
-    return 0;
-}
-extern "C" int lqrrt_debug_pro_acc(unsigned long long* out16) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(lq::g_pro_acc), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    return 0;
-}
-extern "C" int lqrrt_debug_blk_acc(unsigned long long* out8) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lq::g_blk_acc), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    return 0;
-}
-extern "C" int lqrrt_debug_place_acc(unsigned long long* out16) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(lq::g_place_acc), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    return 0;
-}
-extern "C" int lqrrt_debug_step_acc(unsigned long long* out8) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lq::g_step_acc), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    return 0;
-}
-#endif
+#include "measure_abi.hpp"       // -DSTEER_TIMING builds only: read-back of the device timestamps (tools/steer_phases_bench.py)

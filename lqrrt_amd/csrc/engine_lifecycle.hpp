@@ -21,6 +21,8 @@ static void refill_drop(lqrrt_engine* e) {
 static void free_all(lqrrt_engine* e) {
     refill_drop(e);
     if (e->cu_stream) { (void)hipStreamSynchronize(e->cu_stream); (void)hipStreamDestroy(e->cu_stream); e->cu_stream = nullptr; }
+    if (e->d_proto) { (void)hipFree(e->d_proto); e->d_proto = nullptr; }
+    if (e->multi_stream) { (void)hipStreamSynchronize(e->multi_stream); (void)hipStreamDestroy(e->multi_stream); e->multi_stream = nullptr; }
     if (e->rf_event) (void)hipEventDestroy(e->rf_event);
     if (e->rf_stream) (void)hipStreamDestroy(e->rf_stream);
     if (e->h_cand_pin) (void)hipHostFree(e->h_cand_pin);

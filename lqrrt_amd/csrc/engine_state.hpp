@@ -174,6 +174,11 @@ struct lqrrt_engine {
     hipStream_t cu_stream = nullptr;
     std::vector<uint32_t> cu_mask;
 
+    // lqrrt_engine_extend_multi: this engine's prototype (kernels.hpp EngineProto) in device memory, and what was uploaded last
+    EngineProto* d_proto = nullptr;
+    std::vector<char> proto_cache;
+    hipStream_t multi_stream = nullptr;   // the stream of the group this engine leads when a multi call runs on several host threads
+
     // counters
     lqrrt_extend_stats tot{};
 

@@ -236,6 +236,108 @@ extern "C" int lqrrt_wave_suggest(lqrrt_engine* e, int wave_cap) {
     return pick_wave(e, wave_cap);
 }
 
+// What follows a converged wave on the host: the committed prefix (first goal hit, node limit, max_commit), the append launch of
+// the legacy path, the host mirrors and the goal bookkeeping (planner.py:260-283), the sample cursor, the counters and the
+// wave-size controller.  Shared by lqrrt_wave_commit and the multi-engine loop (engine_multi.hpp).
+static int commit_finish(lqrrt_engine* e, int W, bool fused, int64_t max_commit, int64_t node_limit, int pruning,
+                         lqrrt_extend_stats& ws, int rounds, hipStream_t st) {
+    const double hb0 = hostprof_on() ? now_us() : 0.0;
+    // commit prefix: stop after the first goal hit, the node limit, or max_commit attempts
+    const int* sum = fused ? e->h_round + 8 : e->h_summary + 4;
+    const int* len = sum;
+    const int* flg = sum + W;
+    const int* par = sum + 2 * W;
+    int C = 0, acc = 0;
+    bool hit = false;
+    std::vector<int> sync_hits;
+    const int64_t room = node_limit + 1 - (int64_t)e->N;   // nodes that may still be added (size > max_nodes stops)
+    for (int t = 0; t < W; ++t) {
+        if ((int64_t)C >= max_commit) break;
+        if (node_limit >= 0 && (int64_t)acc >= room) break;
+        e->h_rank[t] = acc;
+        C = t + 1;
+        if (len[t] > 0) {
+            ++acc;
+            if (flg[t] & 1) {
+                hit = true;
+                if (!e->sync_mode) break;        // exact mode: the ignore set changes here, the wave ends
+                sync_hits.push_back(acc - 1);   // synchronous mode: remember the node (offset from base), go on
+            }
+        }
+    }
+    for (int t = C; t < W; ++t) e->h_rank[t] = acc;
+    if (e->N + acc > e->cap) return fail(LQRRT_E_CAPACITY, "tree capacity exceeded");
+    const int base = e->N;
+    if (acc > 0 && !fused) {
+        // ranks are read by the kernel straight from pinned host memory (written before the launch)
+        DISPATCH(e, hipLaunchKernelGGL((k_append<S>), dim3(C), dim3(64), 0, st, e->tv, e->d_rec, e->L, C, base, e->h_rank_dev, e->d_par_done, e->fix));
+        HIPCHK(hipGetLastError());
+    }
+    if (e->res.adaptive) {
+        // replay planner.py:418-425 over the committed attempts, in order: horizon_iters doubles whenever
+        // the step counter reaches it and halves when a rollout is stopped by error growth
+        const int hmax = e->res.H;
+        auto clipi = [&](double v) { return (int)std::min((double)hmax, std::max((double)e->hspan_min, v)); };
+        for (int t = 0; t < C; ++t) {
+            const int steps = flg[t] >> 8;
+            const bool grew = (flg[t] & 2) != 0;
+            const int upto = grew ? steps - 1 : steps;
+            for (int i = 1; i <= upto; ++i)
+                if (i == e->h_iters) e->h_iters = clipi(2.0 * e->h_iters);
+            if (grew) e->h_iters = clipi(e->h_iters / 2.0);
+        }
+    }
+    // host mirrors + goal bookkeeping (planner.py:260-283)
+    for (int t = 0; t < C; ++t) {
+        if (len[t] <= 0) continue;
+        const int id = base + e->h_rank[t];
+        const int p = par[t] >= 0 ? par[t] : base + e->h_rank[~par[t]];
+        e->h_pid.push_back(p);
+        e->h_elen.push_back(len[t]);
+        (void)id;
+    }
+    e->N += acc;
+    if (hit) {
+        if (!e->sync_mode) sync_hits.assign(1, acc - 1);      // exact mode: the goal hit is the last committed node
+        for (int off : sync_hits) {                          // in commit order
+            const int id = base + off;
+            int64_t steps = 0;
+            if (pruning && !e->ign_dirty) { e->ign_patch.clear(); e->ign_patch_valid = true; }   // device copy == host copy so far
+            for (int v = id; v != -1; v = e->h_pid[v]) {
+                steps += e->h_elen[v];
+                // ignores = union of succeeded paths, planner.py:270 (only consulted when pruning, :239)
+                if (pruning) {
+                    const unsigned long long bit = 1ull << (v & 63);
+                    if (!(e->h_ign[v >> 6] & bit)) {
+                        e->h_ign[v >> 6] |= bit;
+                        e->ign_dirty = true;
+                        if (e->ign_patch_valid && std::find(e->ign_patch.begin(), e->ign_patch.end(), v >> 6) == e->ign_patch.end()) {
+                            if (e->ign_patch.size() < 16) e->ign_patch.push_back(v >> 6);
+                            else e->ign_patch_valid = false;                   // too many words: the next scan waits for an upload
+                        }
+                    }
+                }
+            }
+            e->goal_hits++;
+            ws.goal_hits++;
+            if (e->best_end < 0 || steps < e->best_steps) { e->best_end = id; e->best_steps = steps; }  // planner.py:276 (T < self.T)
+        }
+    }
+    if (trace_on()) fprintf(stderr, "[wave N=%d W=%d] commit C=%d acc=%d hit=%d rounds=%d\n", base, W, C, acc, (int)hit, rounds);
+    // advance the stream
+    const int64_t last = e->cursor + C - 1;
+    if (C > 0) e->committed_row = e->pool_rows_end[(size_t)(last - e->pool_base)];
+    e->cursor += C;
+    ws.attempts = C; ws.accepted = acc; ws.tree_size = e->N;
+    ws.candidates = e->committed_row;
+    e->tot.attempts += C; e->tot.accepted += acc; e->tot.waves += 1; e->tot.fix_rounds += ws.fix_rounds;
+    e->tot.resteers += ws.resteers; e->tot.goal_hits += ws.goal_hits; e->tot.tree_size = e->N;
+    e->tot.candidates = e->committed_row;
+    if (!e->sync_mode) tune_wave(e, W, ws, e->maxW);
+    if (hostprof_on()) g_hp.book += now_us() - hb0;
+    return 0;
+}
+
 static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_limit, int pruning, lqrrt_extend_stats* out,
                        void* stream, bool prepared);
 
@@ -396,100 +498,7 @@ static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_
         if (++rounds > guard) return fail(LQRRT_E_STATE, "exact-mode repair did not converge");
     }
 
-    const double hb0 = hostprof_on() ? now_us() : 0.0;
-    // commit prefix: stop after the first goal hit, the node limit, or max_commit attempts
-    const int* sum = fused ? e->h_round + 8 : e->h_summary + 4;
-    const int* len = sum;
-    const int* flg = sum + W;
-    const int* par = sum + 2 * W;
-    int C = 0, acc = 0;
-    bool hit = false;
-    std::vector<int> sync_hits;
-    const int64_t room = node_limit + 1 - (int64_t)e->N;   // nodes that may still be added (size > max_nodes stops)
-    for (int t = 0; t < W; ++t) {
-        if ((int64_t)C >= max_commit) break;
-        if (node_limit >= 0 && (int64_t)acc >= room) break;
-        e->h_rank[t] = acc;
-        C = t + 1;
-        if (len[t] > 0) {
-            ++acc;
-            if (flg[t] & 1) {
-                hit = true;
-                if (!e->sync_mode) break;        // exact mode: the ignore set changes here, the wave ends
-                sync_hits.push_back(acc - 1);   // synchronous mode: remember the node (offset from base), go on
-            }
-        }
-    }
-    for (int t = C; t < W; ++t) e->h_rank[t] = acc;
-    if (e->N + acc > e->cap) return fail(LQRRT_E_CAPACITY, "tree capacity exceeded");
-    const int base = e->N;
-    if (acc > 0 && !fused) {
-        // ranks are read by the kernel straight from pinned host memory (written before the launch)
-        DISPATCH(e, hipLaunchKernelGGL((k_append<S>), dim3(C), dim3(64), 0, st, e->tv, e->d_rec, e->L, C, base, e->h_rank_dev, e->d_par_done, e->fix));
-        HIPCHK(hipGetLastError());
-    }
-    if (e->res.adaptive) {
-        // replay planner.py:418-425 over the committed attempts, in order: horizon_iters doubles whenever
-        // the step counter reaches it and halves when a rollout is stopped by error growth
-        const int hmax = e->res.H;
-        auto clipi = [&](double v) { return (int)std::min((double)hmax, std::max((double)e->hspan_min, v)); };
-        for (int t = 0; t < C; ++t) {
-            const int steps = flg[t] >> 8;
-            const bool grew = (flg[t] & 2) != 0;
-            const int upto = grew ? steps - 1 : steps;
-            for (int i = 1; i <= upto; ++i)
-                if (i == e->h_iters) e->h_iters = clipi(2.0 * e->h_iters);
-            if (grew) e->h_iters = clipi(e->h_iters / 2.0);
-        }
-    }
-    // host mirrors + goal bookkeeping (planner.py:260-283)
-    for (int t = 0; t < C; ++t) {
-        if (len[t] <= 0) continue;
-        const int id = base + e->h_rank[t];
-        const int p = par[t] >= 0 ? par[t] : base + e->h_rank[~par[t]];
-        e->h_pid.push_back(p);
-        e->h_elen.push_back(len[t]);
-        (void)id;
-    }
-    e->N += acc;
-    if (hit) {
-        if (!e->sync_mode) sync_hits.assign(1, acc - 1);      // exact mode: the goal hit is the last committed node
-        for (int off : sync_hits) {                          // in commit order
-            const int id = base + off;
-            int64_t steps = 0;
-            if (pruning && !e->ign_dirty) { e->ign_patch.clear(); e->ign_patch_valid = true; }   // device copy == host copy so far
-            for (int v = id; v != -1; v = e->h_pid[v]) {
-                steps += e->h_elen[v];
-                // ignores = union of succeeded paths, planner.py:270 (only consulted when pruning, :239)
-                if (pruning) {
-                    const unsigned long long bit = 1ull << (v & 63);
-                    if (!(e->h_ign[v >> 6] & bit)) {
-                        e->h_ign[v >> 6] |= bit;
-                        e->ign_dirty = true;
-                        if (e->ign_patch_valid && std::find(e->ign_patch.begin(), e->ign_patch.end(), v >> 6) == e->ign_patch.end()) {
-                            if (e->ign_patch.size() < 16) e->ign_patch.push_back(v >> 6);
-                            else e->ign_patch_valid = false;                   // too many words: the next scan waits for an upload
-                        }
-                    }
-                }
-            }
-            e->goal_hits++;
-            ws.goal_hits++;
-            if (e->best_end < 0 || steps < e->best_steps) { e->best_end = id; e->best_steps = steps; }  // planner.py:276 (T < self.T)
-        }
-    }
-    if (trace_on()) fprintf(stderr, "[wave N=%d W=%d] commit C=%d acc=%d hit=%d rounds=%d\n", base, W, C, acc, (int)hit, rounds);
-    // advance the stream
-    const int64_t last = e->cursor + C - 1;
-    if (C > 0) e->committed_row = e->pool_rows_end[(size_t)(last - e->pool_base)];
-    e->cursor += C;
-    ws.attempts = C; ws.accepted = acc; ws.tree_size = e->N;
-    ws.candidates = e->committed_row;
-    e->tot.attempts += C; e->tot.accepted += acc; e->tot.waves += 1; e->tot.fix_rounds += ws.fix_rounds;
-    e->tot.resteers += ws.resteers; e->tot.goal_hits += ws.goal_hits; e->tot.tree_size = e->N;
-    e->tot.candidates = e->committed_row;
-    if (!e->sync_mode) tune_wave(e, W, ws, e->maxW);
-    if (hostprof_on()) g_hp.book += now_us() - hb0;
+    TRY(commit_finish(e, W, fused, max_commit, node_limit, pruning, ws, rounds, st));
     if (out) *out = ws;
     return 0;
 }

@@ -29,6 +29,7 @@
 //     separately in vscnt), which the publication of a round's summary to pinned host memory relies on.
 #pragma once
 #include <type_traits>
+#include "measure.hpp"
 #include "systems.hpp"
 #include "dare.hpp"
 
@@ -213,11 +214,14 @@ __device__ __forceinline__ double quad_cost(const double* e, const double* Sd) {
 // their minima through LDS, so a sample gets ONE partial per four chunks: a quarter of the scattered 12-byte stores (each of
 // them a 64-byte transaction: 58 % of the scan's physical traffic, profiles/r03_nn_traffic.json) and a quarter of the partials
 // the steer prologue has to read back.  Chunks ascend in node id, the combination keeps the (cost, id) order.
-template <class S, int DENSE, bool TRI, bool PATCH = false, int WPB = 1>
-__global__ __launch_bounds__(64 * WPB) void k_nn_scan(NodeView nv, const double* __restrict__ xs, const double* __restrict__ xtrig,
-                                                int W, const double* __restrict__ Sd, int chunk,
-                                                double* __restrict__ pcost, int* __restrict__ pidx,
-                                                int ps_c, int ps_t, IgnPatch pt) {
+// The body of a scan launch for workgroup `b` of a gx x gy grid (linear id, x fastest): k_nn_scan (one engine's launch) and
+// k_nn_scan_multi (one launch whose grid spans several engines, lqrrt_engine_extend_multi) both run it.  pt_n: entries of `pt` to apply.
+template <class S, int DENSE, bool TRI, bool PATCH, int WPB>
+__device__ __forceinline__ void nn_scan_body(const NodeView& nv, const double* __restrict__ xs, const double* __restrict__ xtrig,
+                                             const int W, const double* __restrict__ Sd, const int chunk,
+                                             double* __restrict__ pcost, int* __restrict__ pidx,
+                                             const int ps_c, const int ps_t, const IgnPatch& pt, const int pt_n,
+                                             const int b, const int gx, const int gy) {
     static_assert(WPB == 1 || (!PATCH && !TRI), "the four-wavefront form exists for the plain tree scan");
     const int lane = threadIdx.x & 63;
     // patch entry k lives in lane k (and k + 16, ...): one vector load each, issued with the launch's first loads -- the
@@ -225,23 +229,23 @@ __global__ __launch_bounds__(64 * WPB) void k_nn_scan(NodeView nv, const double*
     int pt_idx = -1;
     unsigned long long pt_val = 0;
     if constexpr (PATCH) {
-        if (pt.n > 0) {
+        if (pt_n > 0) {
             pt_idx = pt.idx[lane & 15]; pt_val = pt.val[lane & 15];
-            if (blockIdx.x == 0 && blockIdx.y == 0 && lane < pt.n && nv.ignore) const_cast<unsigned long long*>(nv.ignore)[pt_idx] = pt_val;
+            if (b == 0 && lane < pt_n && nv.ignore) const_cast<unsigned long long*>(nv.ignore)[pt_idx] = pt_val;
         }
     }
     // XCD-aware tile mapping: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each
     // with its own L2.  Re-index so that XCD k owns a contiguous band of node chunks (for every sample
     // group): each L2 then holds 1/8 of the node table instead of all of it.  Speed only; any mapping is
-    // correct because every (group, chunk) pair is still visited exactly once.
-    int bx = blockIdx.x, by = blockIdx.y;
+    // correct because every (group, chunk) pair is still visited exactly once.  (A launch that spans several engines starts every
+    // engine's range at a multiple of 8 workgroups, so b & 7 is the XCD there too.)
+    int bx = b % gx, by = b / gx;
     {
-        const int nb = gridDim.x * gridDim.y;
+        const int nb = gx * gy;
         if ((nb & 7) == 0) {
-            const int b = blockIdx.y * gridDim.x + blockIdx.x;
             const int v = (b & 7) * (nb >> 3) + (b >> 3);
-            bx = v % gridDim.x;
-            by = v / gridDim.x;
+            bx = v % gx;
+            by = v / gx;
         }
     }
     const int t = bx * 64 + lane;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(64 * WPB) void k_nn_scan(NodeView nv, const double*
     bool patched = false;
     if constexpr (PATCH) {
         const int w0 = i0 >> 6, w1 = (i1 - 1) >> 6;
-        if (pt.n > 0) patched = __any(lane < pt.n && pt_idx >= w0 && pt_idx <= w1) != 0;
+        if (pt_n > 0) patched = __any(lane < pt_n && pt_idx >= w0 && pt_idx <= w1) != 0;
     }
     double xg[S::N], gtrig[2 * S::NW + 1];
 #pragma unroll
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(64 * WPB) void k_nn_scan(NodeView nv, const double*
                         const int ik = __builtin_amdgcn_readlane(pt_idx, k);
                         const unsigned long long vk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(pt_val >> 32), k) << 32) |
                                                       (unsigned)__builtin_amdgcn_readlane((int)pt_val, k);
-                        w = (k < pt.n && ik == wi) ? vk : w;
+                        w = (k < pt_n && ik == wi) ? vk : w;
                     }
                 }
                 el = ((w >> (i & 63)) & 1ull) == 0;
@@ -438,6 +442,15 @@ __global__ __launch_bounds__(64 * WPB) void k_nn_scan(NodeView nv, const double*
         const size_t o = (size_t)by * ps_c + (size_t)t * ps_t;
         pcost[o] = best; pidx[o] = bidx;
     }
+}
+
+template <class S, int DENSE, bool TRI, bool PATCH = false, int WPB = 1>
+__global__ __launch_bounds__(64 * WPB) void k_nn_scan(NodeView nv, const double* __restrict__ xs, const double* __restrict__ xtrig,
+                                                int W, const double* __restrict__ Sd, int chunk,
+                                                double* __restrict__ pcost, int* __restrict__ pidx,
+                                                int ps_c, int ps_t, IgnPatch pt) {
+    nn_scan_body<S, DENSE, TRI, PATCH, WPB>(nv, xs, xtrig, W, Sd, chunk, pcost, pidx, ps_c, ps_t, pt, pt.n,
+                                            (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y);
 }
 
 // cos/sin of the angular coordinates of a batch of samples, [B][2*NW]: computed once per sample batch so that
@@ -701,6 +714,9 @@ struct RoundArgs {
     // launch began, so no workgroup reads what another one writes.  gblk == null: an ordinary round.
     const double* gblk; long long gstride; int ghd, gper, grank; int* gcursor;
 };
+// (What changes from launch to launch in RoundArgs -- on, round, W, base, seq, max_commit, room -- reaches steer_body / close_round as
+//  scalars `rd_*`: the one-engine kernel passes its arguments' fields, the multi-engine kernel its per-engine slot, while the rest of
+//  RoundArgs stays where it is; a local COPY of RoundArgs would live in scratch, its two-element arrays are indexed by the round's parity.)
 // header of sample s of a gathered wave: the record up to the edges + one word, where its edge lies in its block's tail
 __device__ __forceinline__ const double* gathered_header(const RoundArgs& ra, int s) {
     return ra.gblk + (size_t)(s / ra.gper) * ra.gstride + (size_t)(s % ra.gper) * ra.ghd;
@@ -807,36 +823,17 @@ __device__ __forceinline__ bool rollout_check(const double* Pl, const Geo& g, co
     return stop;
 }
 
-#ifdef STEER_TIMING
-__device__ unsigned long long g_steer_ts[8];
-#define STEER_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_steer_ts[i] = wall_clock64(); } while (0)
-__device__ unsigned long long g_step_acc[8];        // per-phase ticks of the rollout loop of block 0, + step count
-__device__ unsigned long long g_loop_hist[32];
-__device__ unsigned long long g_blk_acc[8];
-__device__ unsigned long long g_place_acc[16];      // full-horizon rollouts by placement class: [class*2 + {sum loop ticks, count}], class = (two of the
-                                                    // workgroup's wavefronts on one SIMD ? 1 : 0) + (another rollout on the same CU ? 2 : 0) + (steps with a near obstacle ? 4 : 0)
-__device__ int g_cu_live[4096];
-__device__ unsigned long long g_pro_acc[16];        // prologue of rolling workgroups: [mode*5 + {to pref, parent loads, to S barrier, count}]         // full-horizon rollouts: sum kernel time, sum loop time, count, max kernel, max loop
-#define BLK_T(v) const unsigned long long v = wall_clock64()
-#define STEP_TS(v) const unsigned long long v = wall_clock64()
-#define STEP_ACC(i, a, b) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_step_acc[i] += (b) - (a); } while (0)
-#else
-#define STEER_TS(i) do {} while (0)
-#define BLK_T(v) const unsigned long long v = 0
-#define STEP_TS(v) do {} while (0)
-#define STEP_ACC(i, a, b) do {} while (0)
-#endif
 
 // The last workgroup to add its share to the round's word closes the round: counts to the host and, in a converged round,
 // ranks and the committed prefix for the append.  One wavefront (the helpers wait at barrier S or are gone): no workgroup
 // barrier in here.  (A function, not a lambda: a closure that is not scalarised costs the kernel a stack frame.)
-__device__ __forceinline__ void close_round(const RoundArgs& ra, const RecLayout& L, int lane, unsigned long long round_before, unsigned long long round_share) {
-    const int cur = ra.round & 1, nxt = cur ^ 1;
+__device__ __forceinline__ void close_round(const RoundArgs& ra, const int rd_on, const int rd_round, const int rd_W, const int rd_base, const int rd_seq, const long long rd_max_commit, const long long rd_room, const RecLayout& L, int lane, unsigned long long round_before, unsigned long long round_share) {
+    const int cur = rd_round & 1, nxt = cur ^ 1;
     const bool g0 = ra.gblk != nullptr;
     unsigned long long* word_r = (unsigned long long*)(ra.ctl + RC_PACK) + cur;
     const unsigned long long before_me = ((unsigned long long)(unsigned)__shfl((int)(round_before >> 32), 0) << 32) |
                                          (unsigned)__shfl((int)round_before, 0);
-    if ((int)(before_me & 0xffffu) == ra.W - 1) {
+    if ((int)(before_me & 0xffffu) == rd_W - 1) {
         const unsigned long long all = before_me + round_share;
         const int n_list = (int)((all >> 16) & 0xffffu), n_defer = (int)((all >> 32) & 0xffffu);
         const bool converged = n_list == 0 && n_defer == 0;
@@ -845,10 +842,10 @@ __device__ __forceinline__ void close_round(const RoundArgs& ra, const RecLayout
             // final records: accepted-before counts, committed prefix C.  (Nobody re-steers: this round's buffers
             // will be copies of the previous round's, which the kernel boundary has already published.)
             const int* lfn = ra.lf[cur];
-            int before = 0, first_hit = ra.W, t_room = ra.W;
-            for (int c0 = 0; c0 < ra.W; c0 += 64) {
+            int before = 0, first_hit = rd_W, t_room = rd_W;
+            for (int c0 = 0; c0 < rd_W; c0 += 64) {
                 const int tt = c0 + lane;
-                const bool in = tt < ra.W;
+                const bool in = tt < rd_W;
                 const double* hh = (g0 && in) ? gathered_header(ra, tt) : nullptr;
                 const int len = in ? (g0 ? (int)hh[L.off_len] : lfn[2 * tt]) : 0, flg = in ? (g0 ? (int)hh[L.off_flags] : lfn[2 * tt + 1]) : 0;
                 const bool a = len > 0;
@@ -856,10 +853,10 @@ __device__ __forceinline__ void close_round(const RoundArgs& ra, const RecLayout
                 const int mine = before + __popcll(A & ((1ull << lane) - 1ull));      // accepted before sample tt
                 if (in) {
                     ra.rank[tt] = mine;
-                    ra.host_summary[tt] = len; ra.host_summary[ra.W + tt] = flg;
-                    ra.host_summary[2 * ra.W + tt] = g0 ? (int)hh[L.off_parent] : ra.par[cur][tt];
+                    ra.host_summary[tt] = len; ra.host_summary[rd_W + tt] = flg;
+                    ra.host_summary[2 * rd_W + tt] = g0 ? (int)hh[L.off_parent] : ra.par[cur][tt];
                     if (a && (flg & 1)) first_hit = min(first_hit, tt);
-                    if (ra.room >= 0 && (long long)mine >= ra.room) t_room = min(t_room, tt);
+                    if (rd_room >= 0 && (long long)mine >= rd_room) t_room = min(t_room, tt);
                 }
                 before += __popcll(A);
             }
@@ -868,8 +865,8 @@ __device__ __forceinline__ void close_round(const RoundArgs& ra, const RecLayout
                 first_hit = min(first_hit, __shfl_xor(first_hit, off));
                 t_room = min(t_room, __shfl_xor(t_room, off));
             }
-            long long Cl = ra.W;
-            if (ra.max_commit < Cl) Cl = ra.max_commit;
+            long long Cl = rd_W;
+            if (rd_max_commit < Cl) Cl = rd_max_commit;
             if (t_room < Cl) Cl = t_room;
             if (first_hit + 1 < Cl) Cl = first_hit + 1;
             const int C = (int)(Cl < 0 ? 0 : Cl);
@@ -877,7 +874,7 @@ __device__ __forceinline__ void close_round(const RoundArgs& ra, const RecLayout
             if (lane == 0) {
                 ra.ctl[RC_C] = C;
                 ra.ctl[RC_CONV + nxt] = 1;
-                ra.host_ctrl[0] = first_hit < ra.W ? first_hit : ra.W - 1;
+                ra.host_ctrl[0] = first_hit < rd_W ? first_hit : rd_W - 1;
             }
         }
         // (a gathered wave has no speculative launch of its own that clears the flags of the wave before it)
@@ -886,25 +883,27 @@ __device__ __forceinline__ void close_round(const RoundArgs& ra, const RecLayout
         // the summary (all lanes' stores, pinned host memory) before the word that announces it
         if (converged) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __threadfence_system(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         if (lane == 0) {
-            const unsigned long long word = ((unsigned long long)(unsigned)ra.seq << 32) | (unsigned)((n_list << 16) | (n_defer & 0xffff));
+            const unsigned long long word = ((unsigned long long)(unsigned)rd_seq << 32) | (unsigned)((n_list << 16) | (n_defer & 0xffff));
             __hip_atomic_store((unsigned long long*)(ra.host_ctrl + 2 + 2 * cur), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
 
-template <class S, int DENSE, int NWF>
-__global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, TreeView tv, double* __restrict__ rec,
-                                              RecLayout L, const double* __restrict__ xs,
-                                              const int* __restrict__ list, int lo,
-                                              const int* __restrict__ par, const int* __restrict__ list_count,
-                                              SteerFuse f, RoundArgs ra) {
+// The body of a steer launch for workgroup `bid` of its launch: k_steer (one engine's launch, arguments in the kernel-argument
+// segment) and k_steer_multi (one launch whose grid spans several engines, arguments in a device-resident table) both run it.
+template <class S, int DENSE, int NWF, bool KERNARG_TOUCH>
+__device__ __forceinline__ void steer_body(const Params& P, const Geo& g, const Res& r, const TreeView& tv, double* __restrict__ rec,
+                                           const RecLayout& L, const double* __restrict__ xs,
+                                           const int* __restrict__ list, const int lo,
+                                           const int* __restrict__ par, const int* __restrict__ list_count,
+                                           const SteerFuse& f, const RoundArgs& ra, const int rd_on, const int rd_round, const int rd_W, const int rd_base, const int rd_seq, const long long rd_max_commit, const long long rd_room, const int bid) {
     // (round 4: Riccati-gain systems run the fused rounds too -- their in-wave matrix holds the cost under the S about each sample)
-    const bool ron = ra.on != 0;
+    const bool ron = rd_on != 0;
     // list mode with a device-side count: the launch is enqueued before the host knows how many samples
     // k_decide listed, so surplus workgroups simply leave (and a converged round costs one empty launch)
-    if (list_count && (int)blockIdx.x + lo >= list_count[0]) return;
+    if (list_count && bid + lo >= list_count[0]) return;
 #ifndef LQRRT_NO_KERNARG_TOUCH
-    {
+    if constexpr (KERNARG_TOUCH) {
         // The argument block is ~2 KB (31 cache lines) that no cache holds when a launch starts, and most of it is read
         // lazily, at the point of use, by scalar loads on the critical path (~1 us each on a miss).  One vector load per line
         // up front brings the whole block into this XCD's L2 while the first real loads are in flight anyway.
@@ -937,11 +936,6 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     __shared__ DuoLds duo;
     double* htr = hist + (size_t)r.H * (S::N + S::M) + geo_lds_doubles(g);   // DUO: cos/sin of every recorded state
     constexpr int PKN = S::N + 2 * S::NW;                                    // plain two-wavefront packet: offset of e
-#ifdef STEER_TIMING
-    __shared__ int hw_l[4];
-    __shared__ int cu_prev_l;
-    if ((threadIdx.x & 63) == 0) hw_l[threadIdx.x >> 6] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
-#endif
     // Chain rollout (three wavefronts, every system with the heading-torque pieces; round 4).  With the torque of a moving boat
     // down to one atan2 the dependency chain of a step, x_k -> torque -> x_k+1, is ~230 instructions INCLUDING erf, u = K e and
     // the whole finish step: shorter than any split of it over two wavefronts plus the two barriers that split needs.  So one
@@ -958,7 +952,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     if constexpr (CH) {
         if (threadIdx.x >= 128) {
             // ---------------- checking wavefront
-            if (ron && !ra.gblk && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
+            if (ron && !ra.gblk && ra.ctl[RC_CONV + (rd_round & 1)]) return;           // this launch is the append: nothing to roll out
             for (int i = lane; i < MAXP; i += 64) Pl[i] = P.p[i];
             if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
             const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
@@ -989,7 +983,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         }
         if (threadIdx.x >= 64) {
             // ---------------- heading wavefront: what step p + 1 needs and only depends on two components of x_p
-            if (ron && !ra.gblk && ra.ctl[RC_CONV + (ra.round & 1)]) return;
+            if (ron && !ra.gblk && ra.ctl[RC_CONV + (rd_round & 1)]) return;
             __syncthreads();                                                // S
             if (!duo.go) return;
             const double tt0 = duo.tt[0], tt1 = duo.tt[1];
@@ -1011,7 +1005,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     if constexpr (PLAIN2) {
         if (threadIdx.x >= 64) {
             // ---------------- checking wavefront of the plain two-wavefront rollout
-            if (ron && !ra.gblk && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
+            if (ron && !ra.gblk && ra.ctl[RC_CONV + (rd_round & 1)]) return;           // this launch is the append: nothing to roll out
             for (int i = lane; i < MAXP; i += 64) Pl[i] = P.p[i];
             if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
             const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
@@ -1039,7 +1033,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
     if constexpr (NWF == 2 && !PLAIN2) {
         if (threadIdx.x >= 64) {
             // ---------------- helper wavefront
-            if (ron && !ra.gblk && ra.ctl[RC_CONV + (ra.round & 1)]) return;           // this launch is the append: nothing to roll out
+            if (ron && !ra.gblk && ra.ctl[RC_CONV + (rd_round & 1)]) return;           // this launch is the append: nothing to roll out
             for (int i = lane; i < MAXP; i += 64) Pl[i] = P.p[i];
             if (lane < MAXN) { tol_l[lane] = r.tol[lane]; glo_l[lane] = r.goal_lo[lane]; ghi_l[lane] = r.goal_hi[lane]; }
             const GeoL gl = stage_geo(g, hist + (size_t)r.H * (S::N + S::M), lane, 64);
@@ -1105,7 +1099,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             }
         }
     }
-    const int t = list ? list[blockIdx.x + (list_count ? lo : 0)] : lo + (int)blockIdx.x;
+    const int t = list ? list[bid + (list_count ? lo : 0)] : lo + bid;
     double* my = rec + (size_t)t * L.R;
 
     double x[S::N], K[S::M * S::N], trig[2 * S::NW + 1], xt[S::N], ttrig[2 * S::NW + 1];
@@ -1150,8 +1144,8 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         // nearest node of this sample from the scan's partial minima (see k_nn_reduce for the rules)
         double b = INFINITY;
         int bi = -1;
-        const double* pc = f.pcost + (size_t)blockIdx.x * f.n_chunks;
-        const int* pi = f.pidx + (size_t)blockIdx.x * f.n_chunks;
+        const double* pc = f.pcost + (size_t)bid * f.n_chunks;
+        const int* pi = f.pidx + (size_t)bid * f.n_chunks;
         // (eight loads per lane in flight: the partials were written by other workgroups a moment ago, every access is a
         // ~1 us round trip, and the conditional update below keeps the compiler from overlapping the iterations itself)
         for (int c0 = lane; c0 < f.n_chunks; c0 += 512) {
@@ -1187,14 +1181,14 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             my[L.off_cost] = fallback ? INFINITY : b;
             my[L.off_parent] = (double)bi;
             f.par_out[t] = bi; f.changed[t] = 0; f.stale[t] = 0;
-            if (f.round_ctl && blockIdx.x == 0) {
+            if (f.round_ctl && bid == 0) {
 #pragma unroll
                 for (int q = 0; q < 10; ++q) f.round_ctl[q] = 0;
             }
         }
         pref = bi;
     } else if (ron) {
-        const int cur = ra.round & 1, nxt = cur ^ 1;
+        const int cur = rd_round & 1, nxt = cur ^ 1;
         const bool g0 = ra.gblk != nullptr;                       // round 0 of a gathered wave: decide from the all-gather blocks
         // cost of the end state in header h for sample u (the arithmetic of the row epilogue / k_wave_rows); +inf: no node
         auto hcost = [&](const double* h, int u) -> double {
@@ -1236,7 +1230,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int tt = lane + 64 * i;
-                const bool in = tt < ra.W;
+                const bool in = tt < rd_W;
                 const double* h = gathered_header(ra, in ? tt : 0);
                 lf_len[i] = in ? (int)h[L.off_len] : 0;
                 lf_flg[i] = in ? (int)h[L.off_flags] : 0;
@@ -1254,11 +1248,11 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int tt = lane + 64 * i;
-                const bool in = tt < ra.W;
+                const bool in = tt < rd_W;
                 lf_len[i] = in ? lfc[2 * tt] : 0;
                 lf_flg[i] = in ? lfc[2 * tt + 1] : 0;
                 chg[i] = in ? ra.changed[cur][tt] : 0;
-                colv[i] = (tt < t) ? Mc[(size_t)tt * ra.W + t] : INFINITY;
+                colv[i] = (tt < t) ? Mc[(size_t)tt * rd_W + t] : INFINITY;
             }
             csnap_t = rec[(size_t)t * L.R + L.off_cost];
             psnap_t = (int)rec[(size_t)t * L.R + L.off_parent];
@@ -1280,7 +1274,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             const int C = ra.ctl[RC_C];
             const int len = ra.lf[cur][2 * t];
             if (t < C && len > 0) {
-                const int id = ra.base + ra.rank[t];
+                const int id = rd_base + ra.rank[t];
                 const double* hd = sel_t ? ra.head2 + (size_t)t * HD : my + L.off_xend;
                 if (lane < S::N) tv.state[(size_t)lane * tv.cap + id] = hd[lane];
                 if (lane < 2 * S::NW) tv.trig[(size_t)lane * tv.cap + id] = hd[S::N + lane];
@@ -1293,7 +1287,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
                 for (int q = lane; q < S::M * S::N; q += 64) tv.K[(size_t)id * S::M * S::N + q] = hd[S::N + 2 * S::NW + q];
                 if (lane == 0) {
                     const int p = ra.par[cur][t];
-                    tv.pID[id] = p >= 0 ? p : ra.base + ra.rank[~p];
+                    tv.pID[id] = p >= 0 ? p : rd_base + ra.rank[~p];
                     tv.elen[id] = len;
                 }
                 double* xe = tv.xedge + (size_t)id * tv.H * S::N;
@@ -1308,10 +1302,10 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         // depends on t; what depends on the wanted parent) instead of eight dependent steps.  W <= 256 here (in-wave matrix).
         int want = par_t;
         bool need = false, defer = false, mark_stale = false;
-        int hz = ra.W - 1;
+        int hz = rd_W - 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i)                                // first goal hit among the current records (or W - 1)
-            if (hz == ra.W - 1 && lf_len[i] > 0 && (lf_flg[i] & 1)) hz = lane + 64 * i;
+            if (hz == rd_W - 1 && lf_len[i] > 0 && (lf_flg[i] & 1)) hz = lane + 64 * i;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) hz = min(hz, __shfl_xor(hz, off));
         if (t <= hz) {
@@ -1333,7 +1327,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
                 double cs[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    cs[i] = (lane + 64 * i < sn) ? (g0 ? hcost(gathered_header(ra, lane + 64 * i), sn) : Mc[(size_t)(lane + 64 * i) * ra.W + sn]) : INFINITY;
+                    cs[i] = (lane + 64 * i < sn) ? (g0 ? hcost(gathered_header(ra, lane + 64 * i), sn) : Mc[(size_t)(lane + 64 * i) * rd_W + sn]) : INFINITY;
                 const double csnap_s = g0 ? hs[L.off_cost] : rec[(size_t)sn * L.R + L.off_cost];
                 const int psnap_s = g0 ? (int)hs[L.off_parent] : (int)rec[(size_t)sn * L.R + L.off_parent];
                 const int par_s = g0 ? psnap_s : ra.par[cur][sn];
@@ -1359,7 +1353,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {                           // (column t again: cheaper than keeping it in registers;
                         const int c = lane + 64 * i;
-                        const double v = (c < t && c != sn) ? (g0 ? colv[i] : Mc[(size_t)c * ra.W + t]) : INFINITY;   // (gathered round 0: computed, not stored)
+                        const double v = (c < t && c != sn) ? (g0 ? colv[i] : Mc[(size_t)c * rd_W + t]) : INFINITY;   // (gathered round 0: computed, not stored)
                         if (v < wc2) { wc2 = v; sm2 = c; }
                     }
                     lexmin_wave(wc2, sm2);
@@ -1398,10 +1392,10 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             // nothing to recompute: this sample's row and len/flags move on unchanged (gathered round 0: they are made here)
             if (g0) {
                 const double* ht = gathered_header(ra, t);
-                for (int u = t + 1 + lane; u < ra.W; u += 64) ra.M[nxt][(size_t)t * ra.W + u] = hcost(ht, u);
+                for (int u = t + 1 + lane; u < rd_W; u += 64) ra.M[nxt][(size_t)t * rd_W + u] = hcost(ht, u);
                 if (lane < 2) ra.lf[nxt][2 * t + lane] = (int)ht[lane == 0 ? L.off_len : L.off_flags];
             } else {
-                for (int u = t + 1 + lane; u < ra.W; u += 64) ra.M[nxt][(size_t)t * ra.W + u] = ra.M[cur][(size_t)t * ra.W + u];
+                for (int u = t + 1 + lane; u < rd_W; u += 64) ra.M[nxt][(size_t)t * rd_W + u] = ra.M[cur][(size_t)t * rd_W + u];
                 if (lane < 2) ra.lf[nxt][2 * t + lane] = ra.lf[cur][2 * t + lane];
             }
             pref = 0x7fffffff;                                  // (marker: skip the rollout, go to the ticket)
@@ -1432,13 +1426,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         duo.tt[0] = ttrig[0]; duo.tt[1] = ttrig[1];
         __syncthreads();                                             // S
         BLK_T(blk_t1);
-#ifdef STEER_TIMING
-        if (threadIdx.x == 0) {
-            const int mode = f.n_chunks > 0 ? 0 : (ron ? 1 : 2);
-            atomicAdd(&g_pro_acc[mode * 5 + 0], blk_tp - blk_t0); atomicAdd(&g_pro_acc[mode * 5 + 1], blk_tq - blk_tp);
-            atomicAdd(&g_pro_acc[mode * 5 + 2], blk_t1 - blk_tq); atomicAdd(&g_pro_acc[mode * 5 + 3], 1ull);
-        }
-#endif
+        STEER_T_PROLOGUE(f.n_chunks > 0 ? 0 : (ron ? 1 : 2), blk_t0, blk_tp, blk_tq, blk_t1);
         // model constants in registers for the whole rollout: every index below is a compile-time constant, so the copy is
         // scalarised and only what the step uses stays live (loads from LDS inside the loop could not be hoisted across the barrier)
         double Pc[S::NP];
@@ -1470,15 +1458,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         }
         cnt = duo.cnt; steps = duo.steps; grew = duo.grew != 0;
         truncated = true;                                            // x / trig / K ran ahead: the node comes from the history
-#ifdef STEER_TIMING
-        if (threadIdx.x == 0 && steps >= 20) {
-            const unsigned long long t2 = wall_clock64();
-            atomicAdd(&g_blk_acc[1], t2 - blk_t1); atomicMax(&g_blk_acc[4], t2 - blk_t1);
-            atomicAdd(&g_blk_acc[5], blk_t1 - blk_t0); atomicMax(&g_blk_acc[6], blk_t1 - blk_t0);
-            atomicAdd(&g_blk_acc[2], 1ull);
-            atomicAdd(&g_loop_hist[min(31, (int)((t2 - blk_t1) / 200))], 1ull);      // 2 us buckets
-        }
-#endif
+        STEER_T_LOOP(steps, blk_t0, blk_t1);
     } else if constexpr (PLAIN2) {
         // main wavefront of the plain two-wavefront rollout: the steps; the other wavefront checks them one step behind
         duo.go = 1; duo.stop = 0; duo.cnt = 0; duo.steps = 0; duo.grew = 0; duo.truncated = 0;
@@ -1676,12 +1656,12 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         //        bits 8.. = number of completed steps (for the horizon_iters replay on the host)
         const int fw = flags | (grew ? 2 : 0) | (steps << 8);
         my[L.off_flags] = (double)fw;
-        int* lfo = ron ? ra.lf[(ra.round & 1) ^ 1] : f.lf0;
+        int* lfo = ron ? ra.lf[(rd_round & 1) ^ 1] : f.lf0;
         if (lfo) { lfo[2 * t] = cnt; lfo[2 * t + 1] = fw; }
     }
     STEER_TS(4);
-    double* Mout = ron ? ra.M[(ra.round & 1) ^ 1] : f.M;
-    const int Wm = ron ? ra.W : f.W;
+    double* Mout = ron ? ra.M[(rd_round & 1) ^ 1] : f.M;
+    const int Wm = ron ? rd_W : f.W;
     if (Mout) {
         // row t of the in-wave cost matrix: cost of this record's end state for every later sample u (the
         // arithmetic of k_nn_scan<TRI>: erf about the sample, quad_cost); +inf when the record adds no node
@@ -1712,7 +1692,7 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
             off = __builtin_amdgcn_readfirstlane(off);
             if (off + need > f.sh_tb) off = -2;                  // tail full (rare: the budget is ~2x the typical yield)
         }
-        double* h = f.sh_hdr + (size_t)blockIdx.x * f.sh_hd;
+        double* h = f.sh_hdr + (size_t)bid * f.sh_hd;
         __threadfence();                                         // the record fields read back below were written by other lanes
         for (int q = lane; q < L.off_xseq; q += 64) h[q] = my[q];
         if (lane == 0) h[L.off_xseq] = (double)off;
@@ -1723,14 +1703,19 @@ __global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, Tree
         }
     }
     STEER_TS(5);
-#ifdef STEER_TIMING
-    if (threadIdx.x == 0 && steps >= 20) {
-        const unsigned long long t3 = wall_clock64();
-        atomicAdd(&g_blk_acc[0], t3 - blk_t0); atomicMax(&g_blk_acc[3], t3 - blk_t0);
-    }
-#endif
+    STEER_T_KERNEL(steps, blk_t0);
     }   // !round_skip
-    if (ron && threadIdx.x < 64) close_round(ra, L, lane, round_before, round_share);   // (the workgroup's first wavefront holds the ticket)
+    if (ron && threadIdx.x < 64) close_round(ra, rd_on, rd_round, rd_W, rd_base, rd_seq, rd_max_commit, rd_room, L, lane, round_before, round_share);   // (the workgroup's first wavefront holds the ticket)
+}
+
+template <class S, int DENSE, int NWF>
+__global__ __launch_bounds__(64 * NWF) void k_steer(Params P, Geo g, Res r, TreeView tv, double* __restrict__ rec,
+                                              RecLayout L, const double* __restrict__ xs,
+                                              const int* __restrict__ list, int lo,
+                                              const int* __restrict__ par, const int* __restrict__ list_count,
+                                              SteerFuse f, RoundArgs ra) {
+    steer_body<S, DENSE, NWF, true>(P, g, r, tv, rec, L, xs, list, lo, par, list_count, f, ra, ra.on, ra.round, ra.W, ra.base, ra.seq, ra.max_commit, ra.room,
+                              (int)blockIdx.x);
 }
 
 // Rows of the in-wave cost matrix straight from the records (sharded waves: records of other ranks arrive by
@@ -2089,6 +2074,74 @@ __global__ __launch_bounds__(64) void k_append(TreeView tv, const double* __rest
     double* ue = tv.uedge + (size_t)id * tv.H * S::M;
     for (int q = lane; q < len * S::N; q += 64) xe[q] = my[L.off_xseq + q];
     for (int q = lane; q < len * S::M; q += 64) ue[q] = my[L.off_useq + q];
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Launches whose grid spans SEVERAL engines (lqrrt_engine_extend_multi, round 5).  One planner is a chain of dependent launches
+// that leaves ~98 % of the chip idle; n independent planners advance in lock step, one launch of each kind per "tick": the scans
+// of the engines that begin a wave in ONE k_nn_scan_multi launch, and every engine's steer launch of that tick -- a speculative
+// launch, a fused repair round or its append -- in ONE k_steer_multi launch.  A workgroup finds its engine from the prefix
+// table of workgroup counts in the kernel arguments, takes what does not change between launches (buffers, model constants,
+// geometry, resolution) from that engine's device-resident EngineProto and what does (tree size, wave size, sample window,
+// round number ...) from the arguments, and runs the same body as the one-engine kernels: the trees are bit-identical to those
+// the engines grow one by one (tests/test_multi_gpu.py).
+constexpr int MULTI_MAX = 32;            // engines per launch
+constexpr int MULTI_PATCHES = 4;         // goal hits per tick whose ignore words ride in the arguments (the others are uploaded)
+struct EngineProto { Params P; Geo g; Res r; TreeView tv; double* rec; RecLayout L; SteerFuse f; RoundArgs ra; };
+struct ProtoTable { const EngineProto* p[MULTI_MAX]; };
+struct ScanDyn { const double* xs; const double* xtrig; int W, N, chunk, n_chunks, gx, patch; };
+struct ScanMultiArgs { int n, pad; int block0[MULTI_MAX + 2]; ScanDyn d[MULTI_MAX]; IgnPatch patch[MULTI_PATCHES]; };
+struct SteerDyn { const double* xs; const double* xtrig; long long max_commit, room; int mode, count, n_chunks, N, W, round, base, seq; };
+struct SteerMultiArgs { int n, pad; int block0[MULTI_MAX + 2]; SteerDyn d[MULTI_MAX]; };
+enum { MULTI_IDLE = 0, MULTI_SPECULATE = 1, MULTI_ROUND = 2 };
+
+// engine of workgroup `blk`: block0 is ascending, block0[n] the grid size; a handful of scalar compares
+__device__ __forceinline__ int multi_engine_of(const int* block0, int n, int blk) {
+    int e = 0;
+    for (int i = 1; i < n; ++i) e = (blk >= block0[i]) ? i : e;
+    return e;
+}
+
+template <class S, int DENSE>
+__global__ __launch_bounds__(64) void k_nn_scan_multi(ProtoTable pt, ScanMultiArgs a) {
+    const int e = multi_engine_of(a.block0, a.n, (int)blockIdx.x);
+    const ScanDyn& d = a.d[e];
+    const int b = (int)blockIdx.x - a.block0[e];
+    if (b >= d.gx * d.n_chunks) return;                         // (every engine's range is padded to a multiple of 8 workgroups)
+    const EngineProto& p = *pt.p[e];
+    NodeView nv = p.f.nv;
+    nv.count = d.N;
+    const int slot = d.patch;
+    nn_scan_body<S, DENSE, false, true, 1>(nv, d.xs, d.xtrig, d.W, p.f.Sd, d.chunk, const_cast<double*>(p.f.pcost), const_cast<int*>(p.f.pidx), 1, d.n_chunks,
+                                           a.patch[slot < 0 ? 0 : slot], slot < 0 ? 0 : a.patch[slot].n, b, d.gx, d.n_chunks);
+}
+
+template <class S, int DENSE, int NWF>
+__global__ __launch_bounds__(64 * NWF) void k_steer_multi(ProtoTable pt, SteerMultiArgs a) {
+    const int e = multi_engine_of(a.block0, a.n, (int)blockIdx.x);
+    const SteerDyn& d = a.d[e];
+    const int bid = (int)blockIdx.x - a.block0[e];
+    if (bid >= d.count) return;
+    const EngineProto& p = *pt.p[e];
+    {
+        // as k_steer touches its argument block: the prototype's ~2.5 KB are read lazily by scalar loads on the critical path
+        const volatile int* ka = (const volatile int*)&p;
+        constexpr int LINES = (int)(sizeof(EngineProto) / 64);
+        if ((int)(threadIdx.x & 63) < LINES) (void)ka[(threadIdx.x & 63) * 16];
+    }
+    SteerFuse f = p.f;
+    f.W = d.W; f.xtrig = d.xtrig;
+    const int* par = nullptr;
+    int rd_on = 0;
+    if (d.mode == MULTI_SPECULATE) {
+        f.n_chunks = d.n_chunks; f.nv.count = d.N;
+        par = f.par_out;
+    } else {
+        f.n_chunks = 0; f.M = nullptr;
+        rd_on = 1;
+    }
+    steer_body<S, DENSE, NWF, false>(p.P, p.g, p.r, p.tv, p.rec, p.L, d.xs, nullptr, 0, par, nullptr, f, p.ra, rd_on, d.round, d.W, d.base, d.seq, d.max_commit, d.room, bid);
 }
 
 }  // namespace lq

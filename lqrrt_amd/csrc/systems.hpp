@@ -218,9 +218,7 @@ __device__ __forceinline__ bool grid_hits(const Geo& g, const GeoL& gl, double p
 
 __device__ __forceinline__ bool hull_hits(const GeoL& g, double px, double py, double c, double s,
                                           bool extra2p, int lane) {
-#ifdef ABL_NOFEAS
-    return false;
-#endif
+    ABL_IF_NOFEAS(return false;)
     bool hit = false;
     const double ms = -s;
     for (int o0 = 0; o0 < g.O; o0 += 64) {
@@ -296,9 +294,7 @@ struct BoatCommon {
         return gainv * wrap_err(cg, sg, c, s);
     }
     __device__ __forceinline__ static double rudder_term(double gainv, double vmin2, const double* x, double c, double s) {
-#ifdef ABL_NORUDDER
-        return 0.0;
-#endif
+        ABL_IF_NORUDDER(return 0.0;)
         if (torque_direct(vmin2, x)) return gainv * lq_atan2(x[4], x[3]);
         return rudder_ref(gainv, x, c, s);
     }
@@ -321,12 +317,8 @@ struct BoatCommon {
         const bool odd = (lane & 1) != 0;
         const double c = trig[0], s = trig[1];
         const double ya = ttrig[1] * c - ttrig[0] * s, xa = ttrig[0] * c + ttrig[1] * s;     // wrap_err(target, x)
-#ifdef ABL_NORUDDER
-        e2 = lq_atan2(ya, xa); rud = 0.0; lq_sincos(x[2] + x[5] * dt, &trn[1], &trn[0]); return;
-#endif
-#ifdef ABL_NOTRIG
-        e2 = ya; rud = yb * 1e-3; trn[1] = s; trn[0] = c; return;
-#endif
+        ABL_IF_NORUDDER(e2 = lq_atan2(ya, xa); rud = 0.0; lq_sincos(x[2] + x[5] * dt, &trn[1], &trn[0]); return;)
+        ABL_IF_NOTRIG(e2 = ya; rud = yb * 1e-3; trn[1] = s; trn[0] = c; return;)
         const double hn = x[2] + x[5] * dt;                      // euler(): xn[2] = x[2] + xdot[2]*dt, xdot[2] = x[5]
         if (__builtin_amdgcn_readfirstlane((int)direct)) {
             const double a = lq_atan2(odd ? x[4] : ya, odd ? x[3] : xa);

@@ -401,6 +401,20 @@ class Engine(object):
                                                 self._stream()))
         return st
 
+    @staticmethod
+    def extend_multi(engines, wave, max_attempts=-1, node_limit=-1, until_size=0, pruning=True, stop_on_goal=False):
+        """lqrrt_engine_extend_multi: n independent engines (trees) advanced in lock step by one native loop, two launches per
+        step whatever n is.  Every tree is what its engine grows alone with `extend`; returns the n stats blocks."""
+        engines = list(engines)
+        n = len(engines)
+        if n < 1:
+            raise ValueError("no engines")
+        handles = (C.c_void_p * n)(*[e.h for e in engines])
+        stats = (nat.ExtendStats * n)()
+        nat.check(nat.lib().lqrrt_engine_extend_multi(handles, n, int(wave), int(max_attempts), int(node_limit), int(until_size),
+                                                       1 if pruning else 0, 1 if stop_on_goal else 0, stats, engines[0]._stream()))
+        return [stats[i] for i in range(n)]
+
     def extend_sharded(self, comm, scheme, wave, max_attempts=-1, node_limit=-1, until_size=0, pruning=True, stop_on_goal=False):
         """lqrrt_engine_extend_sharded: the native loop with one RCCL all-gather per wave (comm: parallel.NativeComm)."""
         st = nat.ExtendStats()

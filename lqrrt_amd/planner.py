@@ -20,6 +20,7 @@ There is no CPU path: without the HIP library and a device, update_plan raises.
 """
 from __future__ import division
 
+import os
 import time
 
 import numpy as np
@@ -72,13 +73,20 @@ class Planner:
     # ------------------------------------------------------------------------------------------ engine
     def warm_up(self):
         """Creates the device engine (HBM pools sized by max_nodes, geometry upload) ahead of the first update_plan,
-        so that none of it is charged to a plan's time budget.  Quietly does nothing where there is no GPU or no
-        built library: constructing and configuring a Planner works anywhere, planning does not."""
+        so that none of it is charged to a plan's time budget.  Where there is no GPU or no built library nothing is created --
+        constructing and configuring a Planner works anywhere, planning does not -- and the reason is kept in
+        `self.warm_up_error` (None when the engine exists), so that a broken install can be diagnosed before the first plan;
+        update_plan raises it in full."""
+        self.warm_up_error = None
         try:
             if nat.available():
                 self._get_engine()
-        except (nat.NativeError, RuntimeError, OSError):
+            else:
+                self.warm_up_error = RuntimeError("lqrrt_amd: no engine created: %s" % (
+                    "liblqrrt_hip.so is not built" if not os.path.exists(nat.LIB_PATH) else "no HIP device visible"))
+        except (nat.NativeError, RuntimeError, OSError) as ex:
             self._engine = self._engine_key = None
+            self.warm_up_error = ex
 
     def _get_engine(self):
         """The native engine for the current system / capacity / device (recreated when one of them changed)."""

@@ -173,7 +173,13 @@ def test_steer_kernels_use_no_scratch():
     assert any("UserSystem" in r["name"] for r in steer)
     scan = [r for r in rows if "k_nn_scan<" in r["name"]]
     assert len(steer) >= 14 and len(scan) >= 20
-    assert all(r["scratch"] == 0 for r in steer), [(r["name"][:60], r["scratch"]) for r in steer if r["scratch"]]
+    # No spilling: ScratchSize 0 -- or, where the register allocator left a small frame RESERVED (these kernels live at the SGPR
+    # limit; an emergency slot of a few dozen bytes comes and goes with unrelated edits), not one instruction that touches it.
+    framed = [r for r in steer if r["scratch"] != 0]
+    assert all(r["scratch"] <= 64 for r in framed), [(r["name"][:60], r["scratch"]) for r in framed]
+    if framed:
+        touched = kr.private_memory_instructions([r["mangled"] for r in framed], ["-DLQRRT_USER_SYSTEM=\"%s\"" % user])
+        assert all(v == 0 for v in touched.values()), touched
     # the scan is fed by the scalar unit: no LDS at all -- except the opt-in two-level form (template argument WPB = 4,
     # LQRRT_NN_WG4), whose four wavefronts combine their minima through 3 KB of it
     two_level = [r for r in scan if r["name"].split("(")[0].rstrip(">").endswith(", 4")]
@@ -243,3 +249,4 @@ def test_planner_call_budget_follows_the_clock():
                           printing=False, wave_size=256, wave_mode="synchronous", **boat.plan_kwargs)
     assert q._attempt_budget(4e5, 1e-3) == 256 and q._attempt_budget(4e5, 2e-3) == 256 and q._attempt_budget(4e5, 1.0) == 1024
     assert p.tree is None and p._engine is None                         # no GPU here: nothing was created, nothing raised
+    assert isinstance(p.warm_up_error, Exception)                       # ... and the reason is on record (diagnosable before the first plan)

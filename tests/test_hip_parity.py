@@ -456,9 +456,15 @@ def test_replanning_and_control_surface():
     # (max_nodes far above what the budget can grow -- ~3e5 nodes/s for the car -- or the node limit, not the clock,
     #  ends the plan and update_plan returns False by design, planner.py:330-334)
     p.set_runtime(sys_time=time.time, max_nodes=600000)
+    p.warm_up()                          # the engine for the new node limit exists before the clock starts, as after __init__
+    assert p.warm_up_error is None
     t0 = time.time()
     assert p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10, specific_time=0.2) is True
-    assert 0.2 <= time.time() - t0 < 20.0 and p.plan_reached_goal
+    elapsed = time.time() - t0
+    # the budget is honoured on the real clock: never early (planner.py:286-293), and late by at most one native call, which is
+    # sized to half of the time left at the measured rate (lqrrt_amd/planner.py _attempt_budget) -- within 2x with a wide margin
+    assert 0.2 <= elapsed < 0.4, elapsed
+    assert p.plan_reached_goal
     assert p.tree.size > 300             # the budget buys a much larger tree than the reference's ~20 nodes (loose: shared boxes)
 
 

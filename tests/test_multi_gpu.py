@@ -1,0 +1,162 @@
+"""GPU: lqrrt_engine_extend_multi -- n independent engines advanced in lock step by one native loop, two launches per step whose
+grids span the engines (include/lqrrt_hip.h; csrc/engine_multi.hpp; kernels.hpp k_nn_scan_multi / k_steer_multi).
+
+The claim to check is simple: an engine's tree in a multi call is EXACTLY the tree it grows alone with lqrrt_engine_extend --
+parents, states, gains, every edge row, ignore set, best plan -- and so are its counts (waves, repair rounds, re-steers, attempts,
+candidate rows): the per-engine protocol is the one of the fused repair rounds, only the launches are shared.  Checked for four
+sample seeds of the headline problem, for the car, for engines that stop at different times, and against the sequential C oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def _make(name, cap, wave, seed):
+    import lqrrt_amd
+    from lqrrt_amd.engine import Engine
+    s = lqrrt_amd.systems.SYSTEMS[name](0)
+    eng = Engine(s, capacity=cap, max_wave=wave)
+    kw = s.plan_kwargs
+    eng.set_resolution(kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer))
+    space = np.array(s.sample_space, dtype=np.float64)
+    eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), np.array(s.goal_bias, dtype=np.float64), 10)
+    st = np.random.RandomState(seed).get_state()
+    eng.set_mt19937(st[1], st[2])
+    eng.tree_reset(s.x0)
+    return s, eng
+
+
+def _same(a, b):
+    assert a.size == b.size
+    np.testing.assert_array_equal(a.parents(), b.parents())
+    np.testing.assert_array_equal(a.states(), b.states())
+    np.testing.assert_array_equal(a.gains(), b.gains())
+    np.testing.assert_array_equal(a.edge_lengths(), b.edge_lengths())
+    np.testing.assert_array_equal(a.ignored(), b.ignored())
+    xa, ua, la = a.edges()
+    xb, ub, lb = b.edges()
+    for i in range(a.size):
+        np.testing.assert_array_equal(xa[i, :la[i]], xb[i, :lb[i]])
+        np.testing.assert_array_equal(ua[i, :la[i]], ub[i, :lb[i]])
+    assert a.plan_best() == b.plan_best()
+
+
+def _counts(st):
+    return (st.attempts, st.accepted, st.waves, st.fix_rounds, st.resteers, st.goal_hits, st.candidates, st.tree_size, st.stop_reason)
+
+
+@pytest.mark.parametrize("name,nodes,wave,seeds", [("boat_advanced", 3000, 256, (1, 2, 3, 4)), ("car", 1500, 128, (5, 6, 7)),
+                                                   ("boat_intermediate", 700, 64, (1, 9)), ("pendulum", 150, 64, (1, 2, 3, 4, 5))])
+def test_every_tree_of_a_multi_call_is_the_tree_its_engine_grows_alone(name, nodes, wave, seeds):
+    from lqrrt_amd.engine import Engine
+    alone, stats_alone = [], []
+    for sd in seeds:
+        _, e = _make(name, nodes + wave + 8, wave, sd)
+        stats_alone.append(_counts(e.extend(wave, node_limit=nodes)))
+        alone.append(e)
+    multi = [_make(name, nodes + wave + 8, wave, sd)[1] for sd in seeds]
+    stats = Engine.extend_multi(multi, wave, node_limit=nodes)
+    for k in range(len(seeds)):
+        assert _counts(stats[k]) == stats_alone[k], (k, _counts(stats[k]), stats_alone[k])
+        _same(multi[k], alone[k])
+    # a second call continues every tree (warm engines, uploaded prototypes, sample pools in mid-stream)
+    more = nodes + 200
+    for e in alone:
+        e.close()
+    alone2 = []
+    for sd in seeds:
+        _, e = _make(name, more + wave + 8, wave, sd)
+        e.extend(wave, node_limit=more)
+        alone2.append(e)
+    # (capacity was sized for `nodes`: fresh engines for the longer run, grown in two multi calls)
+    multi2 = [_make(name, more + wave + 8, wave, sd)[1] for sd in seeds]
+    Engine.extend_multi(multi2, wave, node_limit=nodes)
+    Engine.extend_multi(multi2, wave, node_limit=more)
+    for k in range(len(seeds)):
+        _same(multi2[k], alone2[k])
+
+
+def test_engines_that_stop_at_different_times_and_the_c_oracle():
+    """max_attempts ends every engine after the same number of attempts but after different numbers of ticks; until_size and
+    stop_on_goal end them at different times.  And the multi loop against the sequential C oracle directly."""
+    import coracle
+    from lqrrt_amd.engine import Engine
+    seeds = (1, 2, 3, 4, 5, 6)
+    engs = [_make("boat_advanced", 2600, 256, sd) for sd in seeds]
+    stats = Engine.extend_multi([e for _, e in engs], 256, max_attempts=6000)
+    for (s, e), st, sd in zip(engs, stats, seeds):
+        assert st.attempts == 6000 and st.stop_reason == 1
+        o = coracle.make(s, 2600, seed=sd)
+        o.extend(max_iters=6000)
+        assert e.size == o.size
+        np.testing.assert_array_equal(e.parents(), o.parents())
+        np.testing.assert_array_equal(e.states(), o.states())
+    goal = [_make("car", 1400, 128, sd) for sd in (11, 12, 13)]
+    st_goal = Engine.extend_multi([e for _, e in goal], 128, node_limit=1200, stop_on_goal=True)
+    for (s, e), st, sd in zip(goal, st_goal, (11, 12, 13)):
+        _, ref = _make("car", 1400, 128, sd)
+        rs = ref.extend(128, node_limit=1200, stop_on_goal=True)
+        assert _counts(st) == _counts(rs)
+        _same(e, ref)
+
+
+def test_multi_call_argument_checks():
+    from lqrrt_amd.engine import Engine
+    _, a = _make("car", 600, 64, 1)
+    _, b = _make("boat_advanced", 600, 64, 1)
+    with pytest.raises(ValueError):
+        Engine.extend_multi([a, b], 64, node_limit=100)            # two models
+    with pytest.raises(ValueError):
+        Engine.extend_multi([a, a], 64, node_limit=100)            # the same engine twice
+    with pytest.raises(ValueError):
+        Engine.extend_multi([], 64)
+    _, c = _make("boat_novice_lqr", 300, 64, 1)
+    with pytest.raises(ValueError):
+        Engine.extend_multi([c], 64, node_limit=50)                # Riccati gain: not served by this loop
+
+
+def test_groups_on_host_threads_change_nothing():
+    """Calls with four or more engines are cut into groups, each advanced by its own host thread on its own stream (engine_multi.hpp):
+    nine engines = four groups of 3 / 2 / 2 / 2, launches overlapping on the GPU -- every tree still the one its engine grows alone;
+    and the same call forced onto one thread and onto three (LQRRT_MULTI_THREADS, read once per process: child processes)."""
+    import subprocess
+    from lqrrt_amd.engine import Engine
+    seeds = tuple(range(21, 30))
+    alone, stats_alone = [], []
+    for sd in seeds:
+        _, e = _make("boat_advanced", 1900, 256, sd)
+        stats_alone.append(_counts(e.extend(256, node_limit=1600)))
+        alone.append(e)
+    multi = [_make("boat_advanced", 1900, 256, sd)[1] for sd in seeds]
+    stats = Engine.extend_multi(multi, 256, node_limit=1600)
+    for k in range(len(seeds)):
+        assert _counts(stats[k]) == stats_alone[k]
+        _same(multi[k], alone[k])
+    code = r"""
+import sys, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import test_multi_gpu as t
+from lqrrt_amd.engine import Engine
+engs = [t._make("car", 1100, 128, sd)[1] for sd in (1, 2, 3, 4, 5, 6)]
+st = Engine.extend_multi(engs, 128, node_limit=900)
+h = hashlib.sha256()
+for e, s in zip(engs, st):
+    for a in (e.states(), e.gains(), e.parents()):
+        h.update(np.ascontiguousarray(a).tobytes())
+    h.update(repr(t._counts(s)).encode())
+print("HASH", h.hexdigest())
+""" % (ROOT, os.path.dirname(os.path.abspath(__file__)))
+    hashes = []
+    for nthreads in ("1", "3", "6"):
+        env = dict(os.environ, LQRRT_MULTI_THREADS=nthreads)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        hashes.append([l for l in out.stdout.splitlines() if l.startswith("HASH")][-1])
+    assert hashes[0] == hashes[1] == hashes[2], hashes

@@ -41,6 +41,25 @@ def parse(text):
     return rows
 
 
+def private_memory_instructions(mangled_names, extra=()):
+    """ISA check behind the ScratchSize remark: the steer kernels live at the SGPR limit, and the register allocator sometimes leaves
+    a few dozen bytes of frame RESERVED (an emergency spill slot) that no instruction touches -- `ScratchSize 36` with nothing spilled.
+    Returns {mangled name: number of scratch_* / private buffer_load|store instructions in the kernel's code}."""
+    import tempfile
+    src = os.path.join(ROOT, "lqrrt_amd", "csrc", "engine.hip")
+    out = os.path.join(tempfile.mkdtemp(), "engine.s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-S", "--cuda-device-only", src, "-o", out] + list(extra)
+    subprocess.run(cmd, check=True, capture_output=True, cwd=os.path.dirname(src))
+    text = open(out).read()
+    res = {}
+    for name in mangled_names:
+        name = name.split()[0]                                  # (the remark line carries " [-Rpass-analysis=...]" behind the symbol)
+        a = text.index("\n" + name + ":")
+        body = text[a:text.index("s_endpgm", a)]
+        res[name] = len(re.findall(r"^\s+(scratch_(load|store)\w*|buffer_(load|store)_dword\w*\s+v\d+, (off|v\d+), s\[\d+:\d+\], (0|s\d+) (offen|offset))", body, flags=re.M))
+    return res
+
+
 if __name__ == "__main__":
     filt = sys.argv[1:]
     for r in parse(remarks()):
