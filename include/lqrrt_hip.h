@@ -398,6 +398,10 @@ int lqrrt_engine_extend_sharded(lqrrt_engine* e, lqrrt_comm* c, int scheme, int 
                                 int64_t node_limit, int until_size, int pruning, int stop_on_goal,
                                 lqrrt_extend_stats* out, void* stream);
 
+/* Measurement aid: lqrrt_engine_extend_multi rewinds this engine to its mark (lqrrt_tree_mark) whenever a wave would begin above
+ * `size` nodes; 0 switches it off.  The benches quote the metric with the tree inside a size window. */
+int lqrrt_tree_set_rewind_above(lqrrt_engine* e, int size);
+
 /* Several INDEPENDENT engines (trees) advanced together, natively: the loop of lqrrt_engine_extend for each of the n engines, in
  * lock step, with two kernel launches per step whose grids span all of them (the scans of the engines that begin a wave; every
  * engine's steer launch -- speculative launch, fused repair round or append).  No counterpart in the reference, which plans one

@@ -80,6 +80,7 @@ SIGNATURES = {
     "lqrrt_tree_get_edges": (_I, [_P, _I, _I, _P, _P]),
     "lqrrt_tree_mark": (_I, [_P]),
     "lqrrt_tree_rewind": (_I, [_P]),
+    "lqrrt_tree_set_rewind_above": (_I, [_P, _I]),
     "lqrrt_tree_get_states": (_I, [_P, _I, _I, _P]),
     "lqrrt_tree_get_gains": (_I, [_P, _I, _I, _P]),
     "lqrrt_tree_get_parents": (_I, [_P, _I, _I, _P]),

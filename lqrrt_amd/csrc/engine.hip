@@ -46,6 +46,8 @@
 #include <mutex>
 #include <atomic>
 #include <thread>
+#include <condition_variable>
+#include <functional>
 #include <chrono>
 
 #include <algorithm>

@@ -63,6 +63,18 @@ static int alloc_wave(lqrrt_engine* e) {
 
 static int apply_env_cu_mask(lqrrt_engine* e, int n_cus);
 
+// Round 4 appended one parameter to the blocks of the heading-torque boats: torque_vmin^2 (BoatAdvanced slot 52, BoatIntermediate 21,
+// RosBoat 49; systems.hpp).  A C-ABI caller that still passes the shorter round-3 layout would get 0 from the zero-filled block --
+// the one-atan2 torque at EVERY non-zero speed, the setting measured at 2.7e-9 on one edge instead of 8.4e-11 -- silently.
+// A block that ends exactly where the old layout ended gets the documented default, (0.01 m/s)^2, instead.
+static void default_appended_params(lqrrt_engine* e, const lqrrt_system_desc* sys) {
+    int slot = -1;
+    if (sys->model == LQRRT_MODEL_BOAT_ADVANCED) slot = 52;
+    else if (sys->model == LQRRT_MODEL_BOAT_INTERMEDIATE) slot = 21;
+    else if (sys->model == LQRRT_MODEL_ROS_BOAT) slot = 49;
+    if (slot >= 0 && sys->n_params == slot) e->P.p[slot] = 0.01 * 0.01;
+}
+
 extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int capacity, int max_wave,
                                    lqrrt_engine** out) {
     if (!sys || !out) return fail(LQRRT_E_ARG, "null argument");
@@ -87,6 +99,7 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     e->cap = ((capacity + 63) / 64) * 64; e->maxW = max_wave; e->H = 1;
     memset(&e->P, 0, sizeof e->P);
     memcpy(e->P.p, sys->params, sizeof(double) * sys->n_params);
+    default_appended_params(e, sys);
     int rc = 0;
     if ((sys->n_vertices > 0 && !sys->vps) || (sys->n_obstacles > 0 && !sys->obs)) {
         delete e;
@@ -328,6 +341,7 @@ extern "C" int lqrrt_engine_set_geometry(lqrrt_engine* e, const lqrrt_system_des
     free_geometry(e);
     memset(&e->P, 0, sizeof e->P);
     memcpy(e->P.p, sys->params, sizeof(double) * sys->n_params);
+    default_appended_params(e, sys);
     TRY(upload_geometry(e, sys));
     TRY(upload_weights(e));
     e->d_pool_count = 0;                                      // (per-sample S of the device pool depends on the parameters)

@@ -99,6 +99,53 @@ static void multi_launch(int nwf_steer, bool dense, bool any_scan, dim3 gscan, d
     }
 }
 
+// Host threads of the groups.  They persist between calls: a thread's first HIP call sets up the runtime's per-thread state, which
+// costs more than a call of a few thousand attempts takes (threads spawned per call: 16 trees on 4 threads 2.5e6 attempts/s against
+// 4.3e6 with threads that live on).  One multi call at a time uses the pool; a second caller waits for it.
+struct MultiPool {
+    std::mutex call_m, m;
+    std::condition_variable cv, cv_done;
+    std::vector<std::thread> th;
+    const std::function<void(int)>* job = nullptr;
+    long gen = 0;
+    int want = 0, pending = 0;
+    bool stop = false;
+    void worker(int id) {
+        long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            if (id >= want) continue;
+            const std::function<void(int)>* j = job;
+            lk.unlock();
+            (*j)(id);
+            lk.lock();
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+    void run(int G, const std::function<void(int)>& f) {
+        std::lock_guard<std::mutex> call(call_m);
+        {
+            std::unique_lock<std::mutex> lk(m);
+            while ((int)th.size() < G - 1) { const int id = (int)th.size() + 1; th.emplace_back([this, id] { worker(id); }); }
+            job = &f; want = G; pending = G - 1; ++gen;
+        }
+        cv.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return pending == 0; });
+        job = nullptr;
+    }
+    ~MultiPool() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv.notify_all();
+        for (std::thread& t : th) if (t.joinable()) t.join();
+    }
+};
+static MultiPool& multi_pool() { static MultiPool p; return p; }
+
 // One group of engines in lock step on one stream (the whole call when it runs on one host thread).
 static int multi_run_group(lqrrt_engine** engines, int n, int wave, int64_t max_attempts, int64_t node_limit,
                            int until_size, int pruning, int stop_on_goal, lqrrt_extend_stats* out, hipStream_t st) {
@@ -161,6 +208,7 @@ static int multi_run_group(lqrrt_engine** engines, int n, int wave, int64_t max_
                 if (max_attempts >= 0 && s.acc.attempts >= max_attempts) { s.acc.stop_reason = LQRRT_STOP_ATTEMPTS; s.state = 2; --active; continue; }
                 if (node_limit >= 0 && (int64_t)e->N > node_limit) { s.acc.stop_reason = LQRRT_STOP_NODES; s.state = 2; --active; continue; }
                 if (until_size > 0 && e->N >= until_size) { s.acc.stop_reason = LQRRT_STOP_TARGET; s.state = 2; --active; continue; }
+                if (e->rewind_above > 0 && e->N > e->rewind_above) TRY(lqrrt_tree_rewind(e));     // (bench windows: lqrrt_tree_set_rewind_above)
                 int W = pick_wave(e, std::min(wave, 256));
                 s.cap_attempts = max_attempts >= 0 ? max_attempts - s.acc.attempts : (int64_t)W;
                 if ((int64_t)W > s.cap_attempts) W = (int)s.cap_attempts;
@@ -315,12 +363,12 @@ extern "C" int lqrrt_engine_extend_multi(lqrrt_engine** engines, int n, int wave
         if (!e->has_res) return fail(LQRRT_E_STATE, "set_resolution first");
         if (e->N < 1) return fail(LQRRT_E_STATE, "no tree: call lqrrt_tree_reset");
     }
-    // Host threads.  In lock step every tick is as long as its longest launch, and with n engines nearly every tick holds an engine
-    // that begins a wave (the longest kind): one loop over 16 trees reaches 2.9e6 attempts/s, 4 loops over 4 trees each -- a host
-    // thread and a stream per group, the groups' launches overlapping on the GPU -- 4.3e6, 4 x 8 trees 5.3e6; 8 threads are slower
-    // again (profiles/r05_multi.txt).  LQRRT_MULTI_THREADS overrides; a group holds at most MULTI_MAX engines.
+    // Host threads.  In lock step every tick is as long as its longest launch, and with many engines nearly every tick holds an engine
+    // that begins a wave (the longest kind); two groups on two host threads and two streams overlap their launches on the GPU:
+    // 16 trees 3.3e6 -> 4.0e6 attempts/s, 32 trees 4.0e6 -> 4.9e6; more threads are slower again (4: 2.8e6 / 3.9e6), 64 trees reach
+    // 5.3e6 either way (profiles/r05_multi.txt).  LQRRT_MULTI_THREADS overrides; a group holds at most MULTI_MAX engines.
     static const int threads_env = getenv("LQRRT_MULTI_THREADS") ? atoi(getenv("LQRRT_MULTI_THREADS")) : 0;
-    int G = threads_env > 0 ? threads_env : (n >= 8 ? 4 : (n >= 4 ? 2 : 1));
+    int G = threads_env > 0 ? threads_env : (n >= 4 ? 2 : 1);
     G = std::max(G, (n + MULTI_MAX - 1) / MULTI_MAX);
     G = std::min(G, n);
     TRY(use_device(e0));
@@ -332,7 +380,7 @@ extern "C" int lqrrt_engine_extend_multi(lqrrt_engine** engines, int n, int wave
     std::vector<int> rcs((size_t)G, 0);
     std::vector<std::string> errs((size_t)G);
     std::vector<std::vector<lqrrt_extend_stats>> outs((size_t)G);
-    auto work = [&](int g) {
+    const std::function<void(int)> work = [&](int g) {
         lqrrt_engine* lead = grp[(size_t)g][0];
         int rc = 0;
         if (hipSetDevice(lead->device) != hipSuccess) rc = fail(LQRRT_E_HIP, "hipSetDevice failed in a group thread");
@@ -345,10 +393,7 @@ extern "C" int lqrrt_engine_extend_multi(lqrrt_engine** engines, int n, int wave
         rcs[(size_t)g] = rc;
         if (rc) errs[(size_t)g] = g_err;                          // (the error text is per thread: hand it to the caller's)
     };
-    std::vector<std::thread> th;
-    for (int g = 1; g < G; ++g) th.emplace_back(work, g);
-    work(0);
-    for (std::thread& t : th) t.join();
+    multi_pool().run(G, work);                                    // group 0 on this thread, the others on the pool's (persistent) threads
     for (int g = 0; g < G; ++g)
         if (rcs[(size_t)g]) { g_err = errs[(size_t)g]; return rcs[(size_t)g]; }
     if (out)

@@ -15,6 +15,7 @@ struct RcclApi {
     int (*CommInitRank)(void**, int, lq_nccl_uid, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     int (*CommAbort)(void*) = nullptr;                         // optional
+    int (*CommGetAsyncError)(void*, int*) = nullptr;           // optional
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string error;
@@ -44,6 +45,7 @@ static RcclApi* rccl() {
         api.CommInitRank = (int (*)(void**, int, lq_nccl_uid, int))dlsym(api.lib, "ncclCommInitRank");
         api.CommDestroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
         api.CommAbort = (int (*)(void*))dlsym(api.lib, "ncclCommAbort");
+        api.CommGetAsyncError = (int (*)(void*, int*))dlsym(api.lib, "ncclCommGetAsyncError");
         api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllGather");
         api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
         if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) api.error = "librccl.so lacks the nccl* entry points";
@@ -101,6 +103,22 @@ extern "C" int lqrrt_comm_destroy(lqrrt_comm* c) {
     if (!c) return 0;
     if (c->kind == LQRRT_COMM_RCCL && c->nccl && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->nccl);
     delete c;
+    return 0;
+}
+
+// A rank that fails inside the sharded loop aborts ITS communicator, but its peers are by then inside the next wave's all-gather and
+// their hosts spin on a round word that will never be written: only a peer that looks at its own communicator finds out.
+// The wait for a round word therefore asks RCCL now and then while a sharded loop is running (engine_wave.hpp wait_word); an
+// asynchronous error aborts the local communicator and fails the call.  0: nothing wrong (or nothing to ask).
+static int comm_async_error(lqrrt_engine* e) {
+    lqrrt_comm* c = e->active_comm;
+    if (!c || c->kind != LQRRT_COMM_RCCL || c->world < 2 || !c->nccl || !rccl()->CommGetAsyncError) return 0;
+    int err = 0;
+    if (rccl()->CommGetAsyncError(c->nccl, &err) != 0 || err != 0) {
+        if (rccl()->CommAbort) { (void)rccl()->CommAbort(c->nccl); c->nccl = nullptr; }
+        return fail(LQRRT_E_HIP, "RCCL reports an asynchronous error on this rank's communicator (a peer failed?): %s",
+                    rccl()->GetErrorString ? rccl()->GetErrorString(err) : "?");
+    }
     return 0;
 }
 
@@ -249,6 +267,8 @@ extern "C" int lqrrt_engine_extend_sharded(lqrrt_engine* e, lqrrt_comm* c, int s
     lqrrt_extend_stats acc;
     memset(&acc, 0, sizeof acc);
     const int64_t spec0 = e->tot.speculated;
+    struct ActiveComm { lqrrt_engine* e; ~ActiveComm() { e->active_comm = nullptr; } } active_guard{e};
+    e->active_comm = c;                                           // (the waits of this loop watch the communicator: comm_async_error)
     while (true) {
         if (max_attempts >= 0 && acc.attempts >= max_attempts) { acc.stop_reason = LQRRT_STOP_ATTEMPTS; break; }
         if (node_limit >= 0 && (int64_t)e->N > node_limit) { acc.stop_reason = LQRRT_STOP_NODES; break; }
@@ -278,9 +298,11 @@ extern "C" int lqrrt_engine_extend_sharded(lqrrt_engine* e, lqrrt_comm* c, int s
         }
         if (rc != 0) {
             // A rank that fails here (capacity, a repair that does not converge, a dead stream) leaves its peers inside the next
-            // wave's collective: abort the communicator so that they come back with an error instead of hanging.  The handle
-            // stays valid for lqrrt_comm_destroy; every further collective on it fails.
+            // wave's collective: abort the communicator; the peers find out through ncclCommGetAsyncError, which their waits
+            // poll (comm_async_error), abort theirs and return an error instead of hanging.  The handle stays valid for
+            // lqrrt_comm_destroy; every further collective on it fails.
             if (c->kind == LQRRT_COMM_RCCL && c->world > 1 && c->nccl && rccl()->CommAbort) { (void)rccl()->CommAbort(c->nccl); c->nccl = nullptr; }
+            e->gath_pending = false;                              // (the wave that failed is gone; nothing of it may leak into the next call)
             return rc;
         }
         acc.attempts += ws.attempts; acc.accepted += ws.accepted; acc.waves += 1;

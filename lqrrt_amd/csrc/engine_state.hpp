@@ -83,6 +83,7 @@ struct lqrrt_engine {
     int mark_N = 0, mark_best_end = -1;
     int64_t mark_hits = 0, mark_best_steps = -1;
     std::vector<unsigned long long> mark_ign;
+    int rewind_above = 0;         // > 0: the multi-engine loop rewinds to the mark when a wave would begin above this size (bench windows)
 
     // wave buffers
     RecLayout L{};
@@ -118,6 +119,7 @@ struct lqrrt_engine {
     double* d_blk = nullptr;
     size_t blk_cap = 0;           // doubles
     int* d_blk_cursor = nullptr;
+    struct lqrrt_comm* active_comm = nullptr;   // the communicator of the sharded loop that is running on this engine (watched by its waits)
     int seq = 0;                  // sequence number of the last k_decide
     bool wave_complete = false;   // the last speculate covered the whole wave (single-GPU path)
     static constexpr int MAXCH = 1024;

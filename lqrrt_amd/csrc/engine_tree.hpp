@@ -231,6 +231,16 @@ extern "C" int lqrrt_tree_rewind(lqrrt_engine* e) {
     return 0;
 }
 
+// Measurement aid (bench.py's multi_tree extra, tools/multi_bench.py): the metric is quoted with the tree inside a size window, which
+// the benches keep by rewinding to a mark between native calls; with many engines in one call every engine has to do that on its
+// own, inside the call -- lqrrt_engine_extend_multi rewinds an engine to its mark when a wave would begin above `size` nodes.  0: off.
+extern "C" int lqrrt_tree_set_rewind_above(lqrrt_engine* e, int size) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    if (size < 0 || (size > 0 && (e->mark_N < 1 || size < e->mark_N))) return fail(LQRRT_E_ARG, "rewind size below the mark (or no mark)");
+    e->rewind_above = size;
+    return 0;
+}
+
 static int flush_ignore(lqrrt_engine* e, hipStream_t st, bool sync_first) {
     if (!e->ign_dirty) return 0;
     // only the words that cover nodes which exist (or existed since the last upload) can differ

@@ -19,13 +19,13 @@ extern "C" int lqrrt_wave_records(lqrrt_engine* e, void** p) {
 
 // where the speculative launch of a sample-sharded wave also leaves this rank's records (SteerFuse::sh_*)
 struct ShardOut { double* hdr; double* tail; int* cursor; int hd, tb; };
-static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, const ShardOut* so);
+static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, const ShardOut* so, bool native_loop = false);
 
 extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void* stream) {
     return speculate_impl(e, W, lo, hi, stream, nullptr);
 }
 
-static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, const ShardOut* so) {
+static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, const ShardOut* so, bool native_loop) {
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     e->wave_prepared = false;
     if (W < 1 || W > e->maxW || lo < 0 || hi > W || lo > hi) return fail(LQRRT_E_ARG, "bad wave slice");
@@ -61,9 +61,11 @@ static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, 
     const bool whole = (lo == 0 && hi == W);
     static const int matrix_max = getenv("LQRRT_MATRIX_MAX_W") ? std::min(atoi(getenv("LQRRT_MATRIX_MAX_W")), (int)lqrrt_engine::MATRIX_MAX_W)
                                                                 : (int)lqrrt_engine::MATRIX_MAX_W;
-    // (Riccati systems keep the matrix -- costs under the S about each sample -- when the wave is speculated here as a whole or goes
-    //  through the native all-gather; slices handed to the Python-level sharded classes fall back to the scan of the records)
-    e->wave_matrix = W <= matrix_max && !e->sync_mode && (!e->riccati || whole || so != nullptr);
+    // (Riccati systems keep the matrix -- costs under the S about each sample -- in the native loops: the single-engine loop and the
+    //  native all-gather.  The step-by-step entry point lqrrt_wave_speculate, which the Python-level sharded classes drive with one
+    //  slice per rank, always takes the scan of the records for them: whether a rank's slice happens to be the whole wave must not
+    //  decide which repair path it runs, or the ranks of one world would report different rounds for the same wave -- ADVICE r04.)
+    e->wave_matrix = W <= matrix_max && !e->sync_mode && (!e->riccati || native_loop || so != nullptr);
     if (cnt > 0) {
         // snapshot NN for the slice: records lo..hi-1 get (cost, parent); the reduce also initialises the
         // slice's wave bookkeeping (parent-in-use, changed, stale)
@@ -209,15 +211,16 @@ static bool second_choice_enabled() {
     static const bool on = [] { const char* v = getenv("LQRRT_SECOND_CHOICE"); return !(v && atoi(v) == 0); }();
     return on;
 }
+static int comm_async_error(lqrrt_engine* e);                  // engine_sharded.hpp
 static int wait_word(lqrrt_engine* e, hipStream_t st, int* word, int seq);
 static int wait_summary(lqrrt_engine* e, hipStream_t st) { return wait_word(e, st, e->h_summary + 2, e->seq); }
 // word[0] = counts, word[1] = sequence number (one aligned 64-bit store on the device side)
 static int wait_word(lqrrt_engine* e, hipStream_t st, int* word, int seq) {
     volatile int* flag = word + 1;
-    (void)e;
     const auto t_start = std::chrono::steady_clock::now();
     for (long spin = 0;; ++spin) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
+        if (e->active_comm && (spin & 0x3ffff) == 0x3ffff) TRY(comm_async_error(e));   // a sharded loop: has a peer failed?
         if ((spin & 0xfffff) == 0xfffff) {                     // every ~1M polls: make sure the stream is still alive
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 120.0)
                 return fail(LQRRT_E_HIP, "no wave summary after 120 s (sequence %d): device hung?", seq);
@@ -535,7 +538,7 @@ extern "C" int lqrrt_engine_extend(lqrrt_engine* e, int wave, int64_t max_attemp
             const int64_t l2 = (int64_t)until_size - 1;   // stop once size >= until_size  <=> size > until_size-1
             lim = (lim < 0) ? l2 : std::min(lim, l2);
         }
-        TRY(lqrrt_wave_speculate(e, W, 0, W, stream));
+        TRY(speculate_impl(e, W, 0, W, stream, nullptr, true));
         lqrrt_extend_stats ws;
         TRY(lqrrt_wave_commit(e, W, cap_attempts, lim, pruning, &ws, stream));
         acc.attempts += ws.attempts; acc.accepted += ws.accepted; acc.waves += 1;

@@ -917,8 +917,10 @@ __device__ __forceinline__ void steer_body(const Params& P, const Geo& g, const 
     BLK_T(blk_t0);
     // Riccati systems with four wavefronts: every wavefront runs the whole (single-wavefront) kernel redundantly -- the values of a
     // rollout are uniform, the four of them sit on four SIMDs -- and they share the one stage that has work for 256 lanes, the gain
-    // (dare_lqr<S, 256>).  Stores of the same bits to the same address by all four are harmless; nothing in this path is atomic
-    // (the fused rounds and the sharded hand-over are not instantiated for these systems).
+    // (dare_lqr<S, 256>).  Stores of the same bits to the same address by all four are harmless (par / stale / changed / M / records /
+    // heads).  What must happen ONCE per workgroup is guarded by the FIRST wavefront, and an edit has to keep it that way: the round's
+    // ticket (`threadIdx.x == 0`: one atomic per workgroup, or the closer would see W arrivals after W / 4 workgroups), close_round
+    // and the sharded header / tail hand-over (`threadIdx.x < 64`).  These systems run the fused rounds and the sample-sharded waves.
     constexpr bool COOP = has_dare_gain<S>::value && NWF == 4;
     constexpr int GNT = COOP ? 256 : 64;                       // threads that compute a gain together
     constexpr bool DUO = NWF >= 2 && !COOP;

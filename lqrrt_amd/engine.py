@@ -202,6 +202,10 @@ class Engine(object):
     def tree_mark(self):
         nat.check(nat.lib().lqrrt_tree_mark(self.h))
 
+    def set_rewind_above(self, size):
+        """Measurement aid: extend_multi rewinds this engine to its mark whenever a wave would begin above `size` nodes (0: off)."""
+        nat.check(nat.lib().lqrrt_tree_set_rewind_above(self.h, int(size)))
+
     def tree_rewind(self):
         nat.check(nat.lib().lqrrt_tree_rewind(self.h))
         self.epoch += 1

@@ -44,6 +44,7 @@ def run(n, steps, per_call, nodes=10000, wave=256, threads=1):
     t_grow = time.perf_counter() - t0
     for e in engs:
         e.tree_mark()
+        e.set_rewind_above(hi - wave)                   # every engine keeps its own window inside the native call
     groups = [engs[g::threads] for g in range(threads)]
     streams = [torch.cuda.Stream() for _ in range(threads)]
 
@@ -53,11 +54,7 @@ def run(n, steps, per_call, nodes=10000, wave=256, threads=1):
             done = 0
             left = per_call
             while left > 0:
-                for e in grp:
-                    if e.size > hi - 0.4 * wave:
-                        e.tree_rewind()
-                room = max(wave, int((hi - max(e.size for e in grp)) / 0.3 / 1.3))
-                want = min(left, room)
+                want = left
                 sts = Engine.extend_multi(grp, wave, max_attempts=want)
                 done += sum(s.attempts for s in sts)
                 left -= want
