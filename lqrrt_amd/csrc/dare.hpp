@@ -31,141 +31,73 @@ __device__ __forceinline__ void mm(double* C, const double* A, const double* B, 
     __syncthreads();
 }
 
-// Solves W X = RHS in place (Gauss-Jordan, partial pivoting: largest |entry| of the column, lowest row on ties); W is n x n,
-// RHS is n x q, row-major; W is destroyed, RHS becomes X.  One wavefront; the sums of an entry run in one lane in a fixed order,
-// so every right-hand-side column gets the same bits whether it is solved alone or next to others.
-//   per pivot: every lane scans the column itself (n broadcast LDS reads instead of a 6-stage butterfly), lanes j < n + q
-//   divide the pivot row once, and one pass over the n (n + q) entries scales and eliminates (reads, barrier, writes).
+// Gauss-Jordan elimination of [W | RHS] (W n x n, RHS n x q; partial pivoting: largest |entry| of the column, lowest row on ties)
+// with one COLUMN per lane: lane j < n + q holds c[r] = entry (r, j), r < n, in registers.  A pivot costs n pairs of v_readlane
+// (column p, wave-uniform from then on: the scan for the pivot row, the pivot and every row's multiplier are scalar values), one
+// division and n - 1 multiply-subtracts per lane -- no LDS traffic, no cross-lane gather, no barrier, and the row exchange is a
+// uniform branch around register moves.  (Round 5.  The forms this replaces kept one ENTRY per lane: every pivot then paid two
+// ds_bpermute gathers per register slot plus the exchange's, ~230 instructions per pivot at n = 6 with two slots against ~70 here,
+// and a lone wavefront pays ~6 cycles per instruction whatever it does.)  The sums of an entry run in one lane in a fixed order and
+// a right-hand-side column never looks at another one, so a column gets the same bits whether it is solved alone or next to others
+// -- and the same bits as the entry-per-lane forms gave: same pivots, same quotient, same multiply, same subtraction
+// (tools/dare_ab.sh compares two builds bit for bit; oracle/lqrrt_oracle.c restates the elimination sequentially).
+// On return the RHS columns hold W^-1 RHS (the W columns hold the identity).
 __device__ __forceinline__ double readlane_f64(double v, int l) {        // l wave-uniform
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-// Gauss-Jordan elimination of [W | RHS] (n x (n + q), up to 128 entries) held in registers: entry e = r C + j in lane e % 64,
-// slot e / 64.  A pivot costs no LDS traffic and no barrier: the column scan and the pivot are v_readlane's (uniform positions),
-// the pivot-row entry and the row's multiplier of each lane two cross-lane gathers.  Same operations on the same values as the
-// LDS form in solve_inplace, entry by entry.  On return the RHS columns hold W^-1 RHS.
 template <int n, int q>
-__device__ __forceinline__ void gj_eliminate(double (&v)[(n * (n + q) + 63) / 64], int lane) {
-    constexpr int C = n + q, E = n * C, IT = (E + 63) / 64;
-    static_assert(IT <= 2, "register form: at most 128 entries");
-    int rr[IT], jj[IT];
+__device__ __forceinline__ void gj_columns(double (&c)[n]) {
+    static_assert(n + q <= 64, "one lane per column of [W | RHS]");
 #pragma unroll
-    for (int k = 0; k < IT; ++k) { rr[k] = (lane + 64 * k) / C; jj[k] = (lane + 64 * k) % C; }
-    auto elem = [&](int e) __attribute__((always_inline)) -> double {      // entry e, e wave-uniform
-        double a = readlane_f64(v[0], e & 63);
-        if constexpr (IT > 1) { const double b = readlane_f64(v[1], e & 63); a = e >= 64 ? b : a; }
-        return a;
-    };
-    auto gather = [&](int e) __attribute__((always_inline)) -> double {    // entry e, e per lane
-        double a = __shfl(v[0], e & 63);
-        if constexpr (IT > 1) { const double b = __shfl(v[1], e & 63); a = e >= 64 ? b : a; }
-        return a;
-    };
-#pragma unroll 1
     for (int p = 0; p < n; ++p) {
+        double f[n];                                             // column p: the same values in every lane
+#pragma unroll
+        for (int r = 0; r < n; ++r) f[r] = readlane_f64(c[r], p);
         double best = -1.0;
         int brow = p;
 #pragma unroll
-        for (int r = 0; r < n; ++r) {
-            if (r < p) continue;
-            const double a = fabs(elem(r * C + p));
+        for (int r = p; r < n; ++r) {
+            const double a = fabs(f[r]);
             if (a > best) { best = a; brow = r; }
         }
         brow = __builtin_amdgcn_readfirstlane(brow);
-        if (brow != p) {
-            double t[IT];
 #pragma unroll
-            for (int k = 0; k < IT; ++k) {
-                const int src = rr[k] == p ? brow * C + jj[k] : (rr[k] == brow ? p * C + jj[k] : lane + 64 * k);
-                t[k] = gather(src);
+        for (int r = p + 1; r < n; ++r) {
+            if (brow == r) {                                     // rows p and r change places (uniform branch)
+                const double tc = c[p]; c[p] = c[r]; c[r] = tc;
+                const double tf = f[p]; f[p] = f[r]; f[r] = tf;
             }
-#pragma unroll
-            for (int k = 0; k < IT; ++k) v[k] = t[k];
         }
-        const double piv = elem(p * C + p);
-        double nv[IT];
+        const double y = c[p] / f[p];                            // the scaled pivot row, column of this lane
 #pragma unroll
-        for (int k = 0; k < IT; ++k) {
-            const double y = gather(p * C + jj[k]) / piv;                    // the scaled pivot row, column of this lane
-            const double f = gather(rr[k] * C + p);
-            double x = v[k];
-            x -= f * y;
-            nv[k] = rr[k] == p ? y : x;
+        for (int r = 0; r < n; ++r) {
+            if (r == p) continue;
+            double x = c[r];
+            x -= f[r] * y;
+            c[r] = x;
         }
-#pragma unroll
-        for (int k = 0; k < IT; ++k) v[k] = nv[k];
+        c[p] = y;
     }
 }
 
+// Solves W X = RHS in place; W is n x n, RHS is n x q, row-major, both in LDS; W is left as it was, RHS becomes X.  The first
+// wavefront of the workgroup eliminates (gj_columns), the others wait at the barrier.
 template <int n, int q, int NT = 64>
 __device__ __forceinline__ void solve_inplace(double* W, double* RHS, int tid) {
-    constexpr int C = n + q, E = n * C, IT = (E + 63) / 64;
+    constexpr int C = n + q;
     static_assert(C <= 64, "one lane per column of [W | RHS]");
-    static_assert(NT == 64 || IT <= 2, "larger workgroups: register form only (their first wavefront solves, the others wait)");
-    const int lane = tid & 63;
-    if constexpr (IT <= 2) {
-        if (tid < 64) {
-            double v[IT];
+    if (tid < 64) {
+        double c[n];
 #pragma unroll
-            for (int k = 0; k < IT; ++k) {
-                const int idx = lane + 64 * k, r = idx / C, j = idx % C;
-                v[k] = idx < E ? (j < n ? W[r * n + j] : RHS[r * q + (j - n)]) : 0.0;
-            }
-            gj_eliminate<n, q>(v, lane);
+        for (int r = 0; r < n; ++r) c[r] = tid < n ? W[r * n + tid] : (tid < C ? RHS[r * q + (tid - n)] : 0.0);
+        gj_columns<n, q>(c);
+        if (tid >= n && tid < C) {
 #pragma unroll
-            for (int k = 0; k < IT; ++k) {
-                const int idx = lane + 64 * k, r = idx / C, j = idx % C;
-                if (idx < E && j >= n) RHS[r * q + (j - n)] = v[k];
-            }
+            for (int r = 0; r < n; ++r) RHS[r * q + (tid - n)] = c[r];
         }
-        __syncthreads();
-        return;
     }
-#pragma unroll 1
-    for (int p = 0; p < n; ++p) {
-        double best = -1.0;
-        int brow = p;
-#pragma unroll
-        for (int r = 0; r < n; ++r) {
-            if (r < p) continue;
-            const double v = fabs(W[r * n + p]);
-            if (v > best) { best = v; brow = r; }
-        }
-        brow = __builtin_amdgcn_readfirstlane(brow);
-        if (brow != p) {
-            if (lane < C) {
-                double* a = lane < n ? &W[p * n + lane] : &RHS[p * q + (lane - n)];
-                double* b = lane < n ? &W[brow * n + lane] : &RHS[brow * q + (lane - n)];
-                const double t = *a; *a = *b; *b = t;
-            }
-            __syncthreads();
-        }
-        const double piv = W[p * n + p];
-        double yl = 0.0;
-        if (lane < C) yl = (lane < n ? W[p * n + lane] : RHS[p * q + (lane - n)]) / piv;       // the scaled pivot row
-        double nv[IT];
-#pragma unroll
-        for (int k = 0; k < IT; ++k) {
-            const int idx = lane + 64 * k;
-            const int r = idx / C, j = idx % C;
-            const double y = __shfl(yl, j);
-            nv[k] = y;
-            if (idx < E && r != p) {
-                const double f = W[r * n + p];
-                double x = j < n ? W[r * n + j] : RHS[r * q + (j - n)];
-                x -= f * y;
-                nv[k] = x;
-            }
-        }
-        __syncthreads();                                          // every read of this sweep is done
-#pragma unroll
-        for (int k = 0; k < IT; ++k) {
-            const int idx = lane + 64 * k;
-            const int r = idx / C, j = idx % C;
-            if (idx < E) { if (j < n) W[r * n + j] = nv[k]; else RHS[r * q + (j - n)] = nv[k]; }
-        }
-        __syncthreads();
-    }
+    __syncthreads();
 }
 
 // LDS work space of one problem (one wavefront)
@@ -186,13 +118,11 @@ struct DareLds {
 // Every sum runs in a fixed order inside ONE lane (mm, solve_inplace), so the result does not depend on the lane
 // count and oracle/lqrrt_oracle.c restates it sequentially (two eliminations there, one here: same bits per column).
 // NT = 256 (round 4; the rollouts of Riccati systems, k_steer<S, DENSE, 4>): four wavefronts on four SIMDs.  A lone wavefront pays
-// ~6 cycles per instruction whatever it does, and one doubling iteration at n = 6 is ~700 instructions, two thirds of them the
-// Gauss-Jordan elimination of [I + G H | A_k | G] (108 entries = two register slots per lane).  With four wavefronts every matrix
-// pass has one entry per lane, and the elimination is done FOUR times side by side, each wavefront with [I + G H | n/2 of the 2n
-// right-hand-side columns] in ONE register slot: the pivoting only looks at I + G H, so all four take the same pivots, and a
-// right-hand-side column gets the same bits whoever solves it (gj_eliminate).  Same entries, same sums, same order: the bits of
-// the 64-thread form (which lqrrt_lqr_dare_batch and the per-sample S table keep using), asserted on the GPU
-// (tests/test_dare_gpu.py).
+// ~6 cycles per instruction whatever it does; with four wavefronts every matrix pass of a doubling iteration has one entry per lane.
+// The elimination of [I + G H | A_k | G] is the first wavefront's alone (gj_columns: one column per lane, 3 n lanes; round 5 -- until
+// then it was done four times side by side with one ENTRY per lane, ~2/3 of an iteration's instructions).  Same entries, same sums,
+// same order in both sizes: lqrrt_lqr_dare_batch and the per-sample S table (64 threads) and the rollouts (256) produce the same
+// bits, asserted on the GPU (tests/test_dare_gpu.py).
 template <class S, int NT = 64>
 __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const double* u0, const double* Qd, const double* Rd,
                                         double dt, double eps, int max_iter, double tol, DareLds<S::N, S::M>& L, int tid) {
@@ -241,7 +171,7 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
     int it = 0;
     if constexpr (n * 3 * n <= 128) {
         // Four passes and four barriers per iteration: (1) W = I + G H; (2) [W | A_k | G] into registers, eliminated there
-        // (gj_eliminate), T1 = W^-1 A_k and T2 = W^-1 G out; (3) the three products that only need T1 / T2 side by side; (4) the two
+        // (gj_columns), T1 = W^-1 A_k and T2 = W^-1 G out; (3) the three products that only need T1 / T2 side by side; (4) the two
         // that update H and G, accumulated in place.  A_k and its successor swap buffers instead of being copied.  Every entry is
         // the sum the plain sequence below forms, term by term.
         auto dot = [&](const double* Am, const double* Bq, int i, int j, bool ta, bool tb) __attribute__((always_inline)) -> double {
@@ -258,9 +188,6 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
         double* Akn = AG;                                  // ... of the next one
         double* const W1 = T3;                             // H W^-1 A
         double* const W2 = AG + n * n;                     // A W^-1 G
-        constexpr int C3 = 3 * n, E3 = n * C3, IT3 = (E3 + 63) / 64;
-        constexpr int QW = n / 2, CW = n + QW, EW = n * CW;          // NT = 256: columns of [W | its share of A_k | G] per wavefront
-        static_assert(NT == 64 || (n % 2 == 0 && EW <= 64), "four wavefronts: n/2 right-hand-side columns each, one register slot");
         for (; it < max_iter; ++it) {
             for (int e = tid; e < n * n; e += NT) {
                 const int i = e / n, j = e % n;
@@ -269,27 +196,18 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
                 W[e] = acc;                                                         // W = I + G H
             }
             __syncthreads();
-            if constexpr (NT == 64) {
-                double v[IT3];
+            if (tid < 64) {
+                // lane j < 3 n holds column j of [W | A_k | G]; the workgroup's other wavefronts (NT = 256) wait at the barrier
+                const double* src = lane < n ? W + lane : (lane < 2 * n ? Akc + (lane - n) : (lane < 3 * n ? G + (lane - 2 * n) : W));
+                double c[n];
 #pragma unroll
-                for (int k = 0; k < IT3; ++k) {
-                    const int idx = lane + 64 * k, r = idx / C3, j = idx % C3;
-                    v[k] = idx < E3 ? (j < n ? W[r * n + j] : (j < 2 * n ? Akc[r * n + (j - n)] : G[r * n + (j - 2 * n)])) : 0.0;
-                }
-                gj_eliminate<n, 2 * n>(v, lane);                                    // [T1 | T2] = W^-1 [A | G]
+                for (int r = 0; r < n; ++r) c[r] = lane < 3 * n ? src[r * n] : 0.0;
+                gj_columns<n, 2 * n>(c);                                            // [T1 | T2] = W^-1 [A | G]
+                if (lane >= n && lane < 3 * n) {
+                    double* dst = lane < 2 * n ? T1 + (lane - n) : T2 + (lane - 2 * n);
 #pragma unroll
-                for (int k = 0; k < IT3; ++k) {
-                    const int idx = lane + 64 * k, r = idx / C3, j = idx % C3;
-                    if (idx < E3 && j >= n) { if (j < 2 * n) T1[r * n + (j - n)] = v[k]; else T2[r * n + (j - 2 * n)] = v[k]; }
+                    for (int r = 0; r < n; ++r) dst[r * n] = c[r];
                 }
-            } else {
-                // wavefront w solves columns [w QW, (w+1) QW) of [A_k | G]: w = 0, 1 give T1, w = 2, 3 give T2
-                const int w = tid >> 6, r = lane / CW, j = lane % CW;
-                const int col = w * QW + (j - n);                                   // column of [A_k | G] (j >= n)
-                double v[1];
-                v[0] = lane < EW ? (j < n ? W[r * n + j] : (col < n ? Akc[r * n + col] : G[r * n + (col - n)])) : 0.0;
-                gj_eliminate<n, QW>(v, lane);
-                if (lane < EW && j >= n) { if (col < n) T1[r * n + col] = v[0]; else T2[r * n + (col - n)] = v[0]; }
             }
             __syncthreads();
             for (int idx = tid; idx < 3 * n * n; idx += NT) {
