@@ -11,6 +11,7 @@
 // One problem per wavefront; all matrices (n <= 12) live in LDS; the 64 lanes split matrix
 // elements.  ~9 doubling iterations reach 1e-14 where plain Riccati sweeps need >100.
 #pragma once
+#include "measure.hpp"
 #include "systems.hpp"
 
 namespace lq {
@@ -46,27 +47,50 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {        // l wa
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
+// Maximum over the 64 lanes, the same value in every lane on return.  Data-parallel-primitive moves inside the VALU (four shifts
+// within a row of 16, two row broadcasts, one v_readlane pair) instead of six butterfly stages through the LDS crossbar
+// (ds_bpermute: ~100 cycles of latency each for a lone wavefront).  Lanes without a source keep their own value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+    const int hi = __double2hiint(v), lo = __double2loint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ double wave_max(double v) {
+    v = fmax(v, dpp_move_f64<0x111, 0xf>(v));                    // row_shr:1
+    v = fmax(v, dpp_move_f64<0x112, 0xf>(v));                    // row_shr:2
+    v = fmax(v, dpp_move_f64<0x114, 0xf>(v));                    // row_shr:4
+    v = fmax(v, dpp_move_f64<0x118, 0xf>(v));                    // row_shr:8: lane 15 of a row holds the row's maximum
+    v = fmax(v, dpp_move_f64<0x142, 0xa>(v));                    // row_bcast:15 into rows 1 and 3
+    v = fmax(v, dpp_move_f64<0x143, 0xc>(v));                    // row_bcast:31 into rows 2 and 3: lane 63 holds the maximum
+    return readlane_f64(v, 63);
+}
+
 template <int n, int q>
 __device__ __forceinline__ void gj_columns(double (&c)[n]) {
     static_assert(n + q <= 64, "one lane per column of [W | RHS]");
 #pragma unroll
     for (int p = 0; p < n; ++p) {
+        // the scan for the pivot row: every lane scans its own column in its own registers, lane p's answer is the one that counts
+        double best = -1.0;
+        int brow_v = p;
+#pragma unroll
+        for (int r = p; r < n; ++r) {
+            const double a = fabs(c[r]);
+            if (a > best) { best = a; brow_v = r; }
+        }
+        int brow = __builtin_amdgcn_readlane(brow_v, p);
         double f[n];                                             // column p: the same values in every lane
 #pragma unroll
         for (int r = 0; r < n; ++r) f[r] = readlane_f64(c[r], p);
-        double best = -1.0;
-        int brow = p;
+        if (brow != p) {                                         // rows p and brow change places: rare, and a real (uniform) branch --
+            asm volatile("; row exchange");                      // the empty asm keeps the compiler from turning it into 4 (n - p - 1) selects on every pivot
 #pragma unroll
-        for (int r = p; r < n; ++r) {
-            const double a = fabs(f[r]);
-            if (a > best) { best = a; brow = r; }
-        }
-        brow = __builtin_amdgcn_readfirstlane(brow);
-#pragma unroll
-        for (int r = p + 1; r < n; ++r) {
-            if (brow == r) {                                     // rows p and r change places (uniform branch)
-                const double tc = c[p]; c[p] = c[r]; c[r] = tc;
-                const double tf = f[p]; f[p] = f[r]; f[r] = tf;
+            for (int r = p + 1; r < n; ++r) {
+                if (brow == r) {
+                    const double tc = c[p]; c[p] = c[r]; c[r] = tc;
+                    const double tf = f[p]; f[p] = f[r]; f[r] = tf;
+                }
             }
         }
         const double y = c[p] / f[p];                            // the scaled pivot row, column of this lane
@@ -132,6 +156,7 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
     double *A = L.A, *Bm = L.Bm, *Ak = L.Ak, *G = L.G, *Hm = L.Hm, *W = L.W, *T1 = L.T1, *T2 = L.T2, *T3 = L.T3;
     double *Rm = L.Rm, *X = L.X, *Y = L.Y, *Z = L.Z, *red = L.red, *AG = L.AG;
     __syncthreads();                                             // the previous user of the work space is done
+    DARE_TS(ts0);
     // ---- central differences: lane j < n perturbs state j, lanes n..n+m-1 perturb effort j-n; lanes 32.. take the minus side
     static_assert(n + m <= 32, "plus and minus sides of the difference quotients share the wavefront");
     if (tid < 64) {
@@ -160,6 +185,7 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
     for (int i = tid; i < m * m; i += NT) Rm[i] = Rd[i];
     for (int i = tid; i < n * n; i += NT) Hm[i] = Qd[i];
     __syncthreads();
+    DARE_TS(ts1); DARE_ACC(0, ts0, ts1);
     for (int i = tid; i < n * n; i += NT) Ak[i] = A[i];
     // ---- G0 = B R^-1 B'
     for (int i = tid; i < m * n; i += NT) X[i] = Bm[(i % n) * m + (i / n)];     // X = B' (m x n)
@@ -167,13 +193,15 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
     __syncthreads();
     solve_inplace<m, n, NT>(Z, X, tid);                                        // X = R^-1 B'
     mm<NT>(G, Bm, X, n, m, n, false, false, tid);
+    DARE_TS(ts2); DARE_ACC(1, ts1, ts2);
     // ---- doubling
     int it = 0;
     if constexpr (n * 3 * n <= 128) {
         // Four passes and four barriers per iteration: (1) W = I + G H; (2) [W | A_k | G] into registers, eliminated there
         // (gj_columns), T1 = W^-1 A_k and T2 = W^-1 G out; (3) the three products that only need T1 / T2 side by side; (4) the two
         // that update H and G, accumulated in place.  A_k and its successor swap buffers instead of being copied.  Every entry is
-        // the sum the plain sequence below forms, term by term.
+        // the sum the plain sequence below forms, term by term.  Pass (1) of iteration k + 1 runs beside the reduction of iteration
+        // k's convergence test (round 5): the test's verdict is read behind the barrier that pass (1) needs anyway.
         auto dot = [&](const double* Am, const double* Bq, int i, int j, bool ta, bool tb) __attribute__((always_inline)) -> double {
             double acc = 0.0;
 #pragma unroll
@@ -188,20 +216,28 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
         double* Akn = AG;                                  // ... of the next one
         double* const W1 = T3;                             // H W^-1 A
         double* const W2 = AG + n * n;                     // A W^-1 G
-        for (; it < max_iter; ++it) {
-            for (int e = tid; e < n * n; e += NT) {
-                const int i = e / n, j = e % n;
+        static_assert(n * n <= 64, "an n x n pass fits one wavefront");
+        constexpr int HW = NT > 64 ? 1 : 0;                // the wavefront that owns the entries of H in pass (4) and reduces the test's maxima
+        auto pass_W = [&]() __attribute__((always_inline)) {
+            if (tid < n * n) {
+                const int i = tid / n, j = tid % n;
                 double acc = dot(G, Hm, i, j, false, false);
                 if (i == j) acc += 1.0;
-                W[e] = acc;                                                         // W = I + G H
+                W[tid] = acc;                                                       // W = I + G H
             }
-            __syncthreads();
+        };
+        DARE_TS(ta0);
+        pass_W();
+        __syncthreads();
+        DARE_TS(tb0); DARE_ACC(2, ta0, tb0);
+        while (it < max_iter) {
+            DARE_TS(tb);
             if (tid < 64) {
                 // lane j < 3 n holds column j of [W | A_k | G]; the workgroup's other wavefronts (NT = 256) wait at the barrier
                 const double* src = lane < n ? W + lane : (lane < 2 * n ? Akc + (lane - n) : (lane < 3 * n ? G + (lane - 2 * n) : W));
                 double c[n];
 #pragma unroll
-                for (int r = 0; r < n; ++r) c[r] = lane < 3 * n ? src[r * n] : 0.0;
+                for (int r = 0; r < n; ++r) c[r] = src[r * n];                      // (lanes >= 3 n: column 0 once more, never stored)
                 gj_columns<n, 2 * n>(c);                                            // [T1 | T2] = W^-1 [A | G]
                 if (lane >= n && lane < 3 * n) {
                     double* dst = lane < 2 * n ? T1 + (lane - n) : T2 + (lane - 2 * n);
@@ -210,37 +246,45 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
                 }
             }
             __syncthreads();
+            DARE_TS(tc); DARE_ACC(3, tb, tc);
             for (int idx = tid; idx < 3 * n * n; idx += NT) {
                 const int w = idx / (n * n), e = idx % (n * n), i = e / n, j = e % n;
                 const double acc = dot(w == 0 ? Hm : Akc, w == 1 ? T2 : T1, i, j, false, false);
                 (w == 0 ? W1 : (w == 1 ? W2 : Akn))[e] = acc;                       // H W^-1 A | A W^-1 G | A W^-1 A
             }
             __syncthreads();
+            DARE_TS(td); DARE_ACC(4, tc, td);
+            // (4) G in the first wavefront; H in wavefront HW (the first one again when there is only one), which keeps |increment| and
+            // |entry| of its lane for the test
             double dmax = 0.0, hmax = 0.0;
-            for (int idx = tid; idx < 2 * n * n; idx += NT) {
-                const int w = idx / (n * n), e = idx % (n * n), i = e / n, j = e % n;
-                if (w == 0) {
-                    const double t3 = dot(Akc, W1, i, j, true, false);              // A' H W^-1 A
-                    const double hn = Hm[e] + t3;
-                    dmax = fmax(dmax, fabs(t3)); hmax = fmax(hmax, fabs(hn));
-                    Hm[e] = hn;
-                } else {
-                    const double t3 = dot(W2, Akc, i, j, false, true);              // A W^-1 G A'
-                    G[e] += t3;
-                }
+            if (tid < n * n) {
+                const int i = tid / n, j = tid % n;
+                const double t3 = dot(W2, Akc, i, j, false, true);                  // A W^-1 G A'
+                G[tid] += t3;
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { dmax = fmax(dmax, __shfl_xor(dmax, off)); hmax = fmax(hmax, __shfl_xor(hmax, off)); }
-            if constexpr (NT > 64) {                                                // (a maximum does not care about the order)
-                if (lane == 0) { L.redw[2 * (tid >> 6)] = dmax; L.redw[2 * (tid >> 6) + 1] = hmax; }
+            const int eh = tid - 64 * HW;
+            if (eh >= 0 && eh < n * n) {
+                const int i = eh / n, j = eh % n;
+                const double t3 = dot(Akc, W1, i, j, true, false);                  // A' H W^-1 A
+                const double hn = Hm[eh] + t3;
+                dmax = fabs(t3); hmax = fabs(hn);
+                Hm[eh] = hn;
             }
-            __syncthreads();                                                        // H, G (and the wavefronts' maxima) are there
-            if constexpr (NT > 64) {                                                // (redw is next written three barriers from here)
-#pragma unroll
-                for (int w = 0; w < NT / 64; ++w) { dmax = fmax(dmax, L.redw[2 * w]); hmax = fmax(hmax, L.redw[2 * w + 1]); }
+            __syncthreads();                                                        // H, G are there
+            DARE_TS(te); DARE_ACC(5, td, te);
+            // The next iteration's W beside the reduction of the test's maxima (two wavefronts when there are four; W is wasted when the
+            // test then says stop -- it is a scratch matrix)
+            pass_W();
+            if ((tid >> 6) == HW) {
+                dmax = wave_max(dmax); hmax = wave_max(hmax);                       // (a maximum does not care about the order)
+                if (lane == 0) { L.redw[0] = dmax; L.redw[1] = hmax; }
             }
+            __syncthreads();                                                        // W and the maxima are there
+            dmax = L.redw[0]; hmax = L.redw[1];                                     // (redw is next written four barriers from here)
             double* tsw = Akc; Akc = Akn; Akn = tsw;
-            if (dmax <= tol * fmax(1.0, hmax)) { ++it; break; }
+            ++it;
+            DARE_TS(tf); DARE_ACC(2, te, tf); DARE_ACC(8, 0ull, 1ull);
+            if (dmax <= tol * fmax(1.0, hmax)) break;
         }
     } else {
     static_assert(NT == 64 || n * 3 * n <= 128, "the four-wavefront form exists for the register elimination only");
@@ -272,6 +316,7 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
         if (red[0] <= tol * fmax(1.0, red[1])) { ++it; break; }
     }
     }
+    DARE_TS(ts3);
     // ---- symmetrise, K = (R + B'SB)^-1 B'SA
     for (int i = tid; i < n * n; i += NT) T1[i] = 0.5 * (Hm[i] + Hm[(i % n) * n + (i / n)]);
     __syncthreads();
@@ -292,6 +337,7 @@ __device__ __forceinline__ int dare_lqr(const double* P, const double* x0, const
     __syncthreads();
     solve_inplace<m, n, NT>(Z, Y, tid);                                        // Y = K
     __syncthreads();
+    DARE_TS(ts4); DARE_ACC(6, ts3, ts4); DARE_ACC(7, 0ull, 1ull);
     return it;
 }
 

@@ -5,6 +5,8 @@
 //   -DABL_NOFEAS / -DABL_NORUDDER / -DABL_NOTRIG   ablations of a rollout step (tools/ablate_steer.py): the collision sweep, the
 //                    heading torque, the elementary functions replaced by something free -- the RESULTS are wrong, the timing
 //                    difference is the cost of the piece
+//   -DDARE_TIMING    device timestamps in dare_lqr (tools/dare_phases.py): per-phase sums of thread 0 of workgroup 0 -- linearisation,
+//                    G0, the four passes of a doubling iteration, the gain -- read back through lqrrt_debug_dare_acc
 // Without these defines every macro below expands to nothing and kernels.hpp / systems.hpp compile to the product.
 #pragma once
 
@@ -40,6 +42,16 @@ __device__ unsigned long long g_pro_acc[16];        // prologue of rolling workg
 #define STEER_T_PROLOGUE(mode, t0, tp, tq, t1) do { (void)(t0); (void)(tp); (void)(tq); (void)(t1); } while (0)
 #define STEER_T_LOOP(steps, t0, t1) do { (void)(t0); (void)(t1); } while (0)
 #define STEER_T_KERNEL(steps, t0) do { (void)(t0); } while (0)
+#endif
+
+#ifdef DARE_TIMING
+__device__ unsigned long long g_dare_acc[16];       // [0] linearisation [1] G0 [2] W = I + G H [3] elimination [4] three products [5] H / G update + test
+                                                    // [6] gain [7] gains [8] iterations   (100 MHz ticks of workgroup 0's thread 0)
+#define DARE_TS(v) const unsigned long long v = wall_clock64()
+#define DARE_ACC(i, a, b) do { if (blockIdx.x == 0 && tid == 0) g_dare_acc[i] += (b) - (a); } while (0)
+#else
+#define DARE_TS(v) do {} while (0)
+#define DARE_ACC(i, a, b) do {} while (0)
 #endif
 
 #ifdef ABL_NOFEAS
