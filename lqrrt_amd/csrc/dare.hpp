@@ -71,25 +71,35 @@ __device__ __forceinline__ void gj_columns(double (&c)[n]) {
     static_assert(n + q <= 64, "one lane per column of [W | RHS]");
 #pragma unroll
     for (int p = 0; p < n; ++p) {
-        // the scan for the pivot row: every lane scans its own column in its own registers, lane p's answer is the one that counts
-        double best = -1.0;
-        int brow_v = p;
-#pragma unroll
-        for (int r = p; r < n; ++r) {
-            const double a = fabs(c[r]);
-            if (a > best) { best = a; brow_v = r; }
-        }
-        int brow = __builtin_amdgcn_readlane(brow_v, p);
         double f[n];                                             // column p: the same values in every lane
 #pragma unroll
         for (int r = 0; r < n; ++r) f[r] = readlane_f64(c[r], p);
-        if (brow != p) {                                         // rows p and brow change places: rare, and a real (uniform) branch --
-            asm volatile("; row exchange");                      // the empty asm keeps the compiler from turning it into 4 (n - p - 1) selects on every pivot
+        if (p + 1 < n) {                                         // (p is a compile-time value: the loop is unrolled)
+            // Does row p stay?  It does unless a row below holds a strictly larger |entry| (lowest row on ties).  Every lane asks
+            // its own column in its own registers (n - p - 1 v_max and one compare); lane p's answer is the one that counts.  Only
+            // when it says no -- rare -- is the row looked for and exchanged: a real (uniform) branch, the empty asm keeps the
+            // compiler from turning the exchange into 4 (n - p - 1) selects on every pivot.  (A NaN in row p answers no and takes
+            // the scan, which then does what it always did.)
+            double rest = -1.0;
 #pragma unroll
-            for (int r = p + 1; r < n; ++r) {
-                if (brow == r) {
-                    const double tc = c[p]; c[p] = c[r]; c[r] = tc;
-                    const double tf = f[p]; f[p] = f[r]; f[r] = tf;
+            for (int r = p + 1; r < n; ++r) rest = fmax(rest, fabs(c[r]));
+            const bool stays = fabs(c[p]) >= rest;
+            if (!((__ballot(stays) >> p) & 1ull)) {
+                asm volatile("; row exchange");
+                double best = -1.0;
+                int brow_v = p;
+#pragma unroll
+                for (int r = p; r < n; ++r) {
+                    const double a = fabs(c[r]);
+                    if (a > best) { best = a; brow_v = r; }
+                }
+                const int brow = __builtin_amdgcn_readlane(brow_v, p);
+#pragma unroll
+                for (int r = p + 1; r < n; ++r) {
+                    if (brow == r) {
+                        const double tc = c[p]; c[p] = c[r]; c[r] = tc;
+                        const double tf = f[p]; f[p] = f[r]; f[r] = tf;
+                    }
                 }
             }
         }
