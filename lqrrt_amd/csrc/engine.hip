@@ -26,7 +26,7 @@
 //   LQRRT_REFILL_AHEAD           1        refill_ahead             0: the sample pool's feasibility batch and filter only when the pool runs dry
 //   LQRRT_IGNORE_PATCH           1        speculate_impl           0: the ignore words a goal hit changed are uploaded, not passed as scan arguments
 //   LQRRT_HOSTPROF               unset    hostprof_on              host time per wave, printed when an engine is destroyed
-//   LQRRT_DARE_WAVEFRONTS        auto     steer_wavefronts         1|4: wavefronts per rollout of a Riccati system (auto: 4 for n >= 6, they share the gain)
+//   LQRRT_DARE_WAVEFRONTS        auto     steer_wavefronts         1|4: wavefronts per rollout of a Riccati system (auto: 4, they share the gain)
 //   LQRRT_NN_WG4                 0        launch_nn                1: two-level reduction of the tree scan's partial minima (four wavefronts per workgroup)
 //   LQRRT_SHARD_FOLD             1        gathered_wave_fuses      0: a gathered wave is unpacked by a launch of its own instead of by its first round
 //   LQRRT_CU_XCDS                unset    apply_env_cu_mask        k[:first]: engines run their native loops on a stream restricted to k of the 8 XCDs

@@ -299,12 +299,13 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
 // LQRRT_STEER_WAVEFRONTS=2|3 forces a form (tests/test_fuzz_gpu.py runs the fuzzer with each).
 template <class S> static int steer_wavefronts(int count) {
     if constexpr (has_dare_gain<S>::value) {
-        // Riccati systems with n >= 6: four wavefronts share the gain (kernels.hpp COOP; boat_novice_lqr +23 %) unless
-        // LQRRT_DARE_WAVEFRONTS=1; at n = 4 the matrix passes fit one wavefront's lanes anyway and the four-wavefront
-        // barriers only cost (pendulum_lqr -10 %, profiles/r04_riccati_ab.txt): one wavefront unless LQRRT_DARE_WAVEFRONTS=4
+        // Riccati systems: four wavefronts share the gain (kernels.hpp COOP) unless LQRRT_DARE_WAVEFRONTS=1.  Round 4 kept one
+        // wavefront at n = 4 (the matrix passes fit its lanes and the barriers only cost: -10 %); since round 5 the G and H updates
+        // and the convergence test of an iteration run in different wavefronts, which pays at n = 4 too (pendulum_lqr +4.5 %,
+        // boat_novice_lqr +10 %, profiles/r05_dare_wavefronts.txt).  Same bits either way (tests/test_switches_gpu.py).
         static const int dw = getenv("LQRRT_DARE_WAVEFRONTS") ? atoi(getenv("LQRRT_DARE_WAVEFRONTS")) : 0;
         (void)count;
-        return dw == 1 ? 1 : (dw == 4 || S::N >= 6) ? 4 : 1;
+        return dw == 1 ? 1 : 4;
     }
     if (steer_wavefronts_max<S>() <= 2) return steer_wavefronts_max<S>();
     static const int forced = getenv("LQRRT_STEER_WAVEFRONTS") ? atoi(getenv("LQRRT_STEER_WAVEFRONTS")) : 0;

@@ -57,6 +57,49 @@ def test_switches_do_not_change_the_tree():
         assert _run(env) == base, env
 
 
+RICCATI_SCRIPT = r"""
+import hashlib, sys
+sys.path.insert(0, %r)
+import numpy as np
+import lqrrt_amd
+from lqrrt_amd.engine import Engine
+name, nodes = sys.argv[1], int(sys.argv[2])
+s = lqrrt_amd.systems.SYSTEMS[name](0)
+eng = Engine(s, capacity=nodes + 256 + 64, max_wave=256)
+kw = s.plan_kwargs
+eng.set_resolution(kw["dt"], kw["FPR"], int(kw["horizon"] / kw["dt"]), np.abs(s.error_tol), s.goal, np.abs(s.goal_buffer))
+space = np.array(s.sample_space, dtype=np.float64)
+eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), np.array(s.goal_bias, dtype=np.float64), 10)
+st = np.random.RandomState(2).get_state()
+eng.set_mt19937(st[1], st[2])
+eng.tree_reset(s.x0)
+stats = eng.extend(256, node_limit=nodes)
+h = hashlib.sha256()
+for a in (eng.states(), eng.gains(), eng.parents(), eng.edge_lengths()):
+    h.update(np.ascontiguousarray(a).tobytes())
+print("TREE", eng.size, stats.attempts, stats.fix_rounds, h.hexdigest())
+""" % ROOT
+
+
+@pytest.mark.parametrize("name,nodes", [("boat_novice_lqr", 400), ("pendulum_lqr", 250)])
+def test_riccati_rollouts_one_or_four_wavefronts_same_tree(name, nodes):
+    """The Riccati gain inside a rollout is computed by one wavefront (dare_lqr<S, 64>) or by four that share it (dare_lqr<S, 256>:
+    the elimination in the first, G / H updates and the convergence test spread over two); states, gains, parents and edge lengths of
+    the grown tree are the same bits either way.  (The default is four for every Riccati system since round 5.)"""
+    def run(dw):
+        env = dict(os.environ)
+        env.pop("LQRRT_DARE_WAVEFRONTS", None)
+        if dw:
+            env["LQRRT_DARE_WAVEFRONTS"] = str(dw)
+        out = subprocess.run([sys.executable, "-c", RICCATI_SCRIPT, name, str(nodes)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [l for l in out.stdout.splitlines() if l.startswith("TREE")][-1]
+    base = run(None)
+    assert int(base.split()[1]) > nodes
+    assert run(1) == base
+    assert run(4) == base
+
+
 def _grow(system_name, nodes, seed=1, xcds=None, wave=1024):
     import numpy as np
     import lqrrt_amd

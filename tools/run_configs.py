@@ -45,18 +45,22 @@ for label, name, kw_sys, nodes, mod in CONFIGS:
         continue
     eng.tree_mark()
     eng.profile_enable(True, steer=True)
-    done = acc = 0
+    done = acc = waves = rounds = resteers = 0
     t0 = time.perf_counter()
     for _ in range(60):
         if eng.size > hi - 0.7 * wave:
             eng.tree_rewind()
         st_ = eng.extend(wave, max_attempts=wave)
         done += st_.attempts; acc += st_.accepted
+        waves += st_.waves; rounds += st_.fix_rounds; resteers += st_.resteers
     dt = time.perf_counter() - t0
     pr = eng.profile_read()
     print("%-58s %9.0f attempts/s  yield %4.1f %%  grow %6.2f s (%7d attempts)  NN %6.1f us x%-5d %6.2f TB/s alg.  steer %6.1f us" % (
         label, done / dt, 100.0 * acc / max(1, done), t_grow, g.attempts, 1e3 * pr["nn_ms"] / max(1, pr["nn_launches"]), pr["nn_launches"],
         pr["nn_bytes"] / 1e12 / max(1e-9, pr["nn_ms"] / 1e3), 1e3 * pr["steer_ms"] / max(1, pr["steer_launches"])))
+    if os.environ.get("RC_DETAIL"):
+        k = 1024.0 / max(1, done)
+        print("%-58s per 1024 attempts: %.1f waves (mean %.0f samples), %.1f repair rounds, %.0f re-steers" % ("", k * waves, done / max(1, waves), k * rounds, k * resteers))
     if getattr(s, "riccati", False):
         # what one Riccati gain costs: the batched operator, one wavefront per problem (what the rollout calls per recorded step)
         import torch
