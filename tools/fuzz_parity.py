@@ -196,6 +196,14 @@ def run(cases, seed, only=-1, wave_override=None, names=None):
     bad = []
     for k in range(cases):
         c = draw_case(rng, rng2, names, rng3)
+        if os.environ.get("FUZZ_RICCATI"):
+            # every case on a Riccati system (per-step doubling DARE inside the rollouts, S about every sample): the pendulum and
+            # the 6-state boat in turn; small trees, the sequential oracle solves a Riccati equation per recorded step too
+            import lqrrt_amd
+            nm = ("pendulum_lqr", "boat_novice_lqr")[k & 1]
+            c["name"], c["system"] = nm, lqrrt_amd.systems.SYSTEMS[nm](int(k >> 1) & 3)
+            c["nodes"] = min(c["nodes"], 150)
+            c["adaptive"], c["horizon"], c["ogrid"] = False, c["system"].plan_kwargs["horizon"], False
         if wave_override:
             c["wave"] = int(wave_override)
         if only >= 0 and k != only:
