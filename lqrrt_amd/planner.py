@@ -68,6 +68,7 @@ class Planner:
         self.printing = printing
         self.killed = False
         self.stats = None
+        self.xrand_gen_sees_tree = False        # True: a user sampling function is called once per iteration, on the current tree
         self.warm_up()
 
     # ------------------------------------------------------------------------------------------ engine
@@ -124,9 +125,11 @@ class Planner:
 
         user_sampler = not (xrand_gen is None or type(xrand_gen) is int)
         if user_sampler:
-            # planner.py:213-216.  The function is called once per sample, in order, but a batch ahead of the wave that
-            # consumes the samples: it sees the tree as of the batch start, not of the previous iteration (documented
-            # deviation; the default sampler never looks at the tree).
+            # planner.py:213-216.  The function is called once per sample, in order, but by default a batch ahead of the wave
+            # that consumes the samples: it then sees the tree as of the batch start, not of the previous iteration (the default
+            # sampler never looks at the tree).  A function that does read planner.tree / planner.plan_reached_goal sets
+            # `planner.xrand_gen_sees_tree = True`: one sample per native call, the reference's order of events exactly
+            # (planner.py:236 -- sample, extend, goal bookkeeping, next sample), at the price of a host turn per iteration.
             if not _callable(xrand_gen):
                 raise ValueError("Expected xrand_gen to be None, an integer >= 1,  or a function.")
         else:
@@ -180,6 +183,8 @@ class Planner:
         while True:
             exit_at = min_time if self.plan_reached_goal else max_time
             budget = self._attempt_budget(rate, exit_at - time_elapsed)
+            if user_sampler and self.xrand_gen_sees_tree:
+                budget = 1
             if user_sampler:
                 missing = budget - eng.queued_samples()
                 if missing > 0:

@@ -384,6 +384,47 @@ def test_finish_on_goal_and_user_sampler():
         pb.update_plan(c.x0, c.sample_space, xrand_gen="nope")                              # planner.py:216
 
 
+def test_user_sampler_that_reads_the_tree():
+    """planner.py:236: `xrand = xrand_gen(self)` runs at the top of EVERY iteration, so a sampling function may look at the
+    tree the previous iteration left.  With planner.xrand_gen_sees_tree = True the HIP planner keeps that order of events (one
+    sample per native call); the function below samples around a random EXISTING node and stops exploring once a plan exists,
+    so any staleness of the view changes the sample stream and with it the tree.  Against the NumPy oracle, iteration by
+    iteration."""
+    from systems_np import SYSTEMS, make_oracle_planner
+
+    def make_sampler(seed, space):
+        rng = np.random.RandomState(seed)
+        lo, hi = np.array(space, dtype=np.float64).T
+        seen = []
+
+        def sampler(planner):
+            n = planner.tree.size
+            seen.append(n)
+            around = np.array(planner.tree.state[rng.randint(n)], dtype=np.float64)
+            spread = 0.05 if planner.plan_reached_goal else 0.25
+            return np.clip(around + spread * (hi - lo) * rng.uniform(-1, 1, len(lo)), lo, hi)
+        return sampler, seen
+
+    c = _system("car")
+    p = _planner(c, 250, wave_size=64)          # fake clock at 0: the plan ends when the tree outgrows max_nodes
+    p.xrand_gen_sees_tree = True
+    fn, seen = make_sampler(5, c.sample_space)
+    assert p.update_plan(c.x0, c.sample_space, xrand_gen=fn) is False
+    rc = SYSTEMS["car"](0)
+    ref = make_oracle_planner(rc, 250, min_time=2, max_time=3)
+    fn_ref, seen_ref = make_sampler(5, rc.sample_space)
+    assert ref.update_plan(rc.x0, rc.sample_space, xrand_gen=fn_ref) is False
+    assert seen == seen_ref                                    # the tree size the function saw at every iteration
+    assert p.tree.size == ref.tree.size and list(p.tree.pID) == list(ref.tree.pID)
+    np.testing.assert_allclose(p.tree.state, np.array(ref.tree.state), rtol=0, atol=ATOL)
+    assert p.plan_reached_goal == ref.plan_reached_goal
+    # the default (batched) form calls the function the same number of times but ahead of the wave: it must still run
+    q = _planner(c, 250, wave_size=64)
+    fn_q, seen_q = make_sampler(5, c.sample_space)
+    q.update_plan(c.x0, c.sample_space, xrand_gen=fn_q)
+    assert q.tree.size > 1 and seen_q != seen_ref             # (a stale view: which is why the switch exists)
+
+
 def test_replanning_and_control_surface():
     """Repeated update_plan on one Planner (a brand-new tree each call, planner.py:172), set_goal / set_runtime /
     set_resolution between calls, kill_update (:596-601), guide fallback (:311-328) and specific_time."""
