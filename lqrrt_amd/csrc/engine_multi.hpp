@@ -93,6 +93,13 @@ static void multi_launch(int nwf_steer, bool dense, bool any_scan, dim3 gscan, d
                 else hipLaunchKernelGGL((k_steer_multi<S, 0, 2>), gsteer, dim3(128), lds, st, pt, ta);
                 return;
             }
+            if (nwf_steer == 1) {
+                // (one wavefront per rollout, the packed step: the longest rollouts, the fewest wavefront slots -- for calls with so
+                //  many trees that the slots, not the ticks, are what runs out)
+                if (dense) hipLaunchKernelGGL((k_steer_multi<S, 1, 1>), gsteer, dim3(64), lds, st, pt, ta);
+                else hipLaunchKernelGGL((k_steer_multi<S, 0, 1>), gsteer, dim3(64), lds, st, pt, ta);
+                return;
+            }
         }
         if (dense) hipLaunchKernelGGL((k_steer_multi<S, 1, NWF>), gsteer, dim3(64 * NWF), lds, st, pt, ta);
         else hipLaunchKernelGGL((k_steer_multi<S, 0, NWF>), gsteer, dim3(64 * NWF), lds, st, pt, ta);
@@ -148,7 +155,7 @@ static MultiPool& multi_pool() { static MultiPool p; return p; }
 
 // One group of engines in lock step on one stream (the whole call when it runs on one host thread).
 static int multi_run_group(lqrrt_engine** engines, int n, int wave, int64_t max_attempts, int64_t node_limit,
-                           int until_size, int pruning, int stop_on_goal, lqrrt_extend_stats* out, hipStream_t st) {
+                           int until_size, int pruning, int stop_on_goal, lqrrt_extend_stats* out, hipStream_t st, int n_call) {
     lqrrt_engine* e0 = engines[0];
     TRY(use_device(e0));
     std::vector<MultiSlot> slots((size_t)n);
@@ -167,9 +174,15 @@ static int multi_run_group(lqrrt_engine** engines, int n, int wave, int64_t max_
     std::vector<int64_t> spec0((size_t)n);
     for (int i = 0; i < n; ++i) spec0[i] = engines[i]->tot.speculated;
     static const bool patch_on = [] { const char* v = getenv("LQRRT_IGNORE_PATCH"); return !(v && atoi(v) == 0); }();
-    // LQRRT_MULTI_NWF=2|3: wavefronts per rollout of the heading-torque boats in a multi-engine launch; LQRRT_MULTI_ORDER=0: engines in
+    // LQRRT_MULTI_NWF=1|2|3: wavefronts per rollout of the heading-torque boats in a multi-engine launch; LQRRT_MULTI_ORDER=0: engines in
     // call order inside the launches instead of wave-beginners first (both: measurement levers, profiles/r05_multi.txt)
-    static const int multi_nwf = getenv("LQRRT_MULTI_NWF") ? atoi(getenv("LQRRT_MULTI_NWF")) : 0;
+    // Default: three wavefronts per rollout (the chain rollout, the fastest single rollout) while the call's engines leave the chip
+    // room for it, two from 24 engines on -- the steer kernels hold two wavefronts per SIMD, so a tick of many engines runs out of
+    // wavefront SLOTS before it runs out of anything else, and a two-wavefront rollout takes a third fewer: 32 trees 4.9 -> 5.6e6
+    // attempts/s, 64 trees 5.3 -> 6.6e6, 16 trees 4.0e6 either way; one wavefront (the packed step, 384 registers: one wavefront
+    // per SIMD) is slower than two at every size (profiles/r05_multi.txt section 4).  Same trees whatever the form.
+    static const int multi_nwf_env = getenv("LQRRT_MULTI_NWF") ? atoi(getenv("LQRRT_MULTI_NWF")) : 0;
+    const int multi_nwf = multi_nwf_env ? multi_nwf_env : (n_call >= 24 ? 2 : 3);
     static const bool heavy_first = !(getenv("LQRRT_MULTI_ORDER") && atoi(getenv("LQRRT_MULTI_ORDER")) == 0);
     int active = n, bg = 0;
     double hp_build = 0, hp_launch = 0, hp_wait = 0, hp_commit = 0;       // LQRRT_HOSTPROF: where the host's time goes per tick
@@ -372,7 +385,7 @@ extern "C" int lqrrt_engine_extend_multi(lqrrt_engine** engines, int n, int wave
     G = std::max(G, (n + MULTI_MAX - 1) / MULTI_MAX);
     G = std::min(G, n);
     TRY(use_device(e0));
-    if (G == 1) return multi_run_group(engines, n, wave, max_attempts, node_limit, until_size, pruning, stop_on_goal, out, (hipStream_t)stream);
+    if (G == 1) return multi_run_group(engines, n, wave, max_attempts, node_limit, until_size, pruning, stop_on_goal, out, (hipStream_t)stream, n);
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));           // what the caller queued is finished before the groups' own streams start
     std::vector<std::vector<lqrrt_engine*>> grp((size_t)G);
     std::vector<std::vector<int>> idx((size_t)G);
@@ -388,7 +401,7 @@ extern "C" int lqrrt_engine_extend_multi(lqrrt_engine** engines, int n, int wave
             rc = fail(LQRRT_E_HIP, "hipStreamCreate failed in a group thread");
         outs[(size_t)g].resize(grp[(size_t)g].size());
         if (!rc) rc = multi_run_group(grp[(size_t)g].data(), (int)grp[(size_t)g].size(), wave, max_attempts, node_limit, until_size, pruning,
-                                      stop_on_goal, outs[(size_t)g].data(), lead->multi_stream);
+                                      stop_on_goal, outs[(size_t)g].data(), lead->multi_stream, n);
         if (!rc && hipStreamSynchronize(lead->multi_stream) != hipSuccess) rc = fail(LQRRT_E_HIP, "a group's stream failed");
         rcs[(size_t)g] = rc;
         if (rc) errs[(size_t)g] = g_err;                          // (the error text is per thread: hand it to the caller's)

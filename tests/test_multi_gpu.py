@@ -160,3 +160,21 @@ print("HASH", h.hexdigest())
         assert out.returncode == 0, out.stderr[-2000:]
         hashes.append([l for l in out.stdout.splitlines() if l.startswith("HASH")][-1])
     assert hashes[0] == hashes[1] == hashes[2], hashes
+
+
+def test_many_engines_take_the_two_wavefront_rollout_and_grow_the_same_trees():
+    """From 24 engines on, a multi call rolls the heading-torque boats out with two wavefronts per rollout instead of three (fewer
+    wavefront slots per rollout: engine_multi.hpp, profiles/r05_multi.txt section 4).  The form of the rollout is not allowed to
+    change a bit: 26 small trees of the headline problem, each against the tree its engine grows alone (three wavefronts)."""
+    from lqrrt_amd.engine import Engine
+    seeds = tuple(range(41, 67))
+    alone, stats_alone = [], []
+    for sd in seeds:
+        _, e = _make("boat_advanced", 700, 128, sd)
+        stats_alone.append(_counts(e.extend(128, node_limit=420)))
+        alone.append(e)
+    multi = [_make("boat_advanced", 700, 128, sd)[1] for sd in seeds]
+    stats = Engine.extend_multi(multi, 128, node_limit=420)
+    for k in range(len(seeds)):
+        assert _counts(stats[k]) == stats_alone[k]
+        _same(multi[k], alone[k])
