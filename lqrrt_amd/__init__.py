@@ -10,12 +10,13 @@ lqrrt_amd -- MI355X-native expansion engine behind the jnez71/lqRRT Python API.
     planner.update_plan(boat.x0, boat.sample_space, goal_bias=boat.goal_bias)
 
 Exports mirror lqrrt/__init__.py:1-2 of the reference (Constraints, Planner) plus Tree and
-the native problem plugins (systems).  Importing works without a GPU; computing does not.
+the native problem plugins (systems), and update_plans (several planners through shared native calls: one GPU, many
+trees -- planner.py).  Importing works without a GPU; computing does not.
 """
 from .constraints import Constraints
-from .planner import Planner
+from .planner import Planner, update_plans
 from .tree import Tree
 from . import systems
 from . import dare
 
-__all__ = ["Constraints", "Planner", "Tree", "systems", "dare"]
+__all__ = ["Constraints", "Planner", "Tree", "systems", "dare", "update_plans"]

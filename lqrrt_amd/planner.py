@@ -115,16 +115,37 @@ class Planner:
 
         Returns True if it ran to completion, False if it was halted (killed, tree larger than max_nodes, no goal).
         """
+        run = self._plan_begin(x0, sample_space, goal_bias, guide, xrand_gen, pruning, finish_on_goal, specific_time)
+        if run is None:
+            return False
+        # Each native call grows the tree by a few waves.  The clock and the kill flag are looked at between calls, so a
+        # call is sized to what the time budget still allows.
+        while True:
+            budget = self._plan_budget(run)
+            # The call only has to come back AT a goal hit when that hit can end the plan (min_time already elapsed,
+            # planner.py:293); before that, hits are bookkept by the engine (lqrrt_plan_best) and reported with the call.
+            t_call = time.perf_counter()
+            st = run.eng.extend(self.wave_size, max_attempts=budget, node_limit=int(self.max_nodes),
+                                pruning=pruning, stop_on_goal=bool(run.time_elapsed >= run.min_time))
+            if self._plan_after_call(run, st, time.perf_counter() - t_call):
+                break
+        return self._plan_end(run)
+
+    # The three phases of update_plan, separately callable so that several planners can share native calls (update_plans below):
+    # set-up (planner.py:157-231), what follows each native call (:260-311 as far as the host is concerned), wrap-up (:313-336).
+    def _plan_begin(self, x0, sample_space, goal_bias, guide, xrand_gen, pruning, finish_on_goal, specific_time, seed=None):
         x0 = np.array(x0, dtype=np.float64)
         if self.goal is None:
             print("No goal has been set yet!")
             self.get_state = lambda t: x0
             self.get_effort = lambda t: np.zeros(self.ncontrols)
-            return False
-        min_time, max_time = (self.min_time, self.max_time) if specific_time is None else (specific_time, specific_time)
+            return None
+        run = _PlanRun()
+        run.min_time, run.max_time = (self.min_time, self.max_time) if specific_time is None else (specific_time, specific_time)
+        run.pruning, run.finish_on_goal, run.xrand_gen = pruning, finish_on_goal, xrand_gen
 
-        user_sampler = not (xrand_gen is None or type(xrand_gen) is int)
-        if user_sampler:
+        run.user_sampler = not (xrand_gen is None or type(xrand_gen) is int)
+        if run.user_sampler:
             # planner.py:213-216.  The function is called once per sample, in order, but by default a batch ahead of the wave
             # that consumes the samples: it then sees the tree as of the batch start, not of the previous iteration (the default
             # sampler never looks at the tree).  A function that does read planner.tree / planner.plan_reached_goal sets
@@ -152,7 +173,7 @@ class Planner:
         # the device tree is about to be overwritten: a Tree object from the previous plan keeps its contents
         if self.tree is not None:
             self.tree._detach()
-        eng = self._get_engine()
+        eng = run.eng = self._get_engine()
         if self.hfactor:
             # adaptive horizon: rollouts may run hspan[1] steps (include/lqrrt_hip.h, lqrrt_resolution.adaptive)
             eng.set_resolution(self.dt, self.FPR, int(self.hspan[1]), self.error_tol, self.goal, self.constraints.goal_buffer,
@@ -160,9 +181,14 @@ class Planner:
         else:
             eng.set_resolution(self.dt, self.FPR, self.horizon_iters, self.error_tol, self.goal, self.constraints.goal_buffer)
         eng.tree_reset(x0)                                          # planner.py:172
-        if not user_sampler:
+        run.own_stream = seed is not None                           # (update_plans: a sample stream per planner, np.random untouched)
+        if not run.user_sampler:
             eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), bias, tries_limit)
-            eng.seed_from_numpy_global()
+            if run.own_stream:
+                st = np.random.RandomState(seed).get_state()
+                eng.set_mt19937(st[1], st[2])
+            else:
+                eng.seed_from_numpy_global()
         S0 = self.system.Smatrix()
         self.tree = Tree(x0, (S0, np.zeros((self.ncontrols, self.nstates))))
         self.tree._bind(eng, S0)
@@ -171,81 +197,83 @@ class Planner:
             print("\n...planning...")
         self.plan_reached_goal = False
         self.T = np.inf
-        time_elapsed = 0
-        time_start = self.sys_time()
-        best_end = -1
-        total = None
-        rate = None                                                 # attempts per second of real time, measured
-        adopted = False
+        run.time_elapsed = 0
+        run.time_start = self.sys_time()
+        run.best_end = -1
+        run.total = None
+        run.rate = None                                             # attempts per second of real time, measured
+        run.adopted = False
+        return run
 
-        # Each native call grows the tree by a few waves.  The clock and the kill flag are looked at between calls, so a
-        # call is sized to what the time budget still allows.
-        while True:
-            exit_at = min_time if self.plan_reached_goal else max_time
-            budget = self._attempt_budget(rate, exit_at - time_elapsed)
-            if user_sampler and self.xrand_gen_sees_tree:
-                budget = 1
-            if user_sampler:
-                missing = budget - eng.queued_samples()
-                if missing > 0:
-                    eng.push_samples(np.array([np.array(xrand_gen(self), dtype=np.float64) for _ in range(missing)]))
-            # The call only has to come back AT a goal hit when that hit can end the plan (min_time already elapsed,
-            # planner.py:293); before that, hits are bookkept by the engine (lqrrt_plan_best) and reported with the call.
-            t_call = time.perf_counter()
-            st = eng.extend(self.wave_size, max_attempts=budget, node_limit=int(self.max_nodes),
-                            pruning=pruning, stop_on_goal=bool(time_elapsed >= min_time))
-            dt_call = time.perf_counter() - t_call
-            if st.attempts > 0 and dt_call > 0:
-                rate = st.attempts / dt_call if rate is None else 0.5 * rate + 0.5 * st.attempts / dt_call
-            total = st if total is None else _add_stats(total, st)
+    def _plan_budget(self, run):
+        """Attempts the next native call may commit for this plan; a user sampling function is called for as many samples."""
+        exit_at = run.min_time if self.plan_reached_goal else run.max_time
+        budget = self._attempt_budget(run.rate, exit_at - run.time_elapsed)
+        if run.user_sampler and self.xrand_gen_sees_tree:
+            budget = 1
+        if run.user_sampler:
+            missing = budget - run.eng.queued_samples()
+            if missing > 0:
+                run.eng.push_samples(np.array([np.array(run.xrand_gen(self), dtype=np.float64) for _ in range(missing)]))
+        return budget
 
-            if st.goal_hits:
-                self.plan_reached_goal = True
-                end, steps, _ = eng.plan_best()
-                if end != best_end:                                 # a faster plan (planner.py:276)
-                    best_end = end
-                    self.T = steps * self.dt
-                    if self.printing:
-                        print("Found plan at elapsed time: {} s".format(np.round(time_elapsed, 6)))
+    def _plan_after_call(self, run, st, dt_call):
+        """Goal bookkeeping, clock, kill flag and exit rules after a native call (planner.py:260-323); True when the plan is over."""
+        eng = run.eng
+        if st.attempts > 0 and dt_call > 0:
+            run.rate = st.attempts / dt_call if run.rate is None else 0.5 * run.rate + 0.5 * st.attempts / dt_call
+        run.total = st if run.total is None else _add_stats(run.total, st)
 
-            time_elapsed = self.sys_time() - time_start
-
-            if self.killed:
-                break
-            if self.plan_reached_goal and time_elapsed >= min_time:
-                self._adopt_plan(best_end)
-                adopted = True
-                if finish_on_goal:
-                    self._finish_on_goal()
+        if st.goal_hits:
+            self.plan_reached_goal = True
+            end, steps, _ = eng.plan_best()
+            if end != run.best_end:                                 # a faster plan (planner.py:276)
+                run.best_end = end
+                self.T = steps * self.dt
                 if self.printing:
-                    print("Tree size: {0}\nETA: {1} s".format(self.tree.size, np.round(self.T, 2)))
-                self._prepare_interpolators()
-                break
-            if time_elapsed >= max_time or self.tree.size > self.max_nodes:
-                # no goal hit (or not enough time spent): plan to the node nearest the guide state (planner.py:311-323)
-                if getattr(self.system, "riccati", False):
-                    self.system._engine(self.dt)       # the lqr handle of a Riccati system linearises with THIS planner's dt
-                Sguide = np.array(self.lqr(self.xguide, np.zeros(self.ncontrols))[0], dtype=np.float64)
-                Sguide[:, np.isinf(np.asarray(self.constraints.goal_buffer, dtype=np.float64))] = 0
-                ids, _ = eng.nn_argmin(self.xguide.reshape(1, -1), S=Sguide, use_ignore=False)
-                self._adopt_plan(int(ids[0]))
-                adopted = True
-                if self.printing:
-                    print("Didn't reach goal.\nTree size: {0}\nETA: {1} s".format(self.tree.size, np.round(self.T, 2)))
-                self._prepare_interpolators()
-                break
+                    print("Found plan at elapsed time: {} s".format(np.round(run.time_elapsed, 6)))
 
-        if not user_sampler:
+        run.time_elapsed = self.sys_time() - run.time_start
+
+        if self.killed:
+            return True
+        if self.plan_reached_goal and run.time_elapsed >= run.min_time:
+            self._adopt_plan(run.best_end)
+            run.adopted = True
+            if run.finish_on_goal:
+                self._finish_on_goal()
+            if self.printing:
+                print("Tree size: {0}\nETA: {1} s".format(self.tree.size, np.round(self.T, 2)))
+            self._prepare_interpolators()
+            return True
+        if run.time_elapsed >= run.max_time or self.tree.size > self.max_nodes:
+            # no goal hit (or not enough time spent): plan to the node nearest the guide state (planner.py:311-323)
+            if getattr(self.system, "riccati", False):
+                self.system._engine(self.dt)       # the lqr handle of a Riccati system linearises with THIS planner's dt
+            Sguide = np.array(self.lqr(self.xguide, np.zeros(self.ncontrols))[0], dtype=np.float64)
+            Sguide[:, np.isinf(np.asarray(self.constraints.goal_buffer, dtype=np.float64))] = 0
+            ids, _ = eng.nn_argmin(self.xguide.reshape(1, -1), S=Sguide, use_ignore=False)
+            self._adopt_plan(int(ids[0]))
+            run.adopted = True
+            if self.printing:
+                print("Didn't reach goal.\nTree size: {0}\nETA: {1} s".format(self.tree.size, np.round(self.T, 2)))
+            self._prepare_interpolators()
+            return True
+        return False
+
+    def _plan_end(self, run):
+        eng = run.eng
+        if not run.user_sampler and not run.own_stream:
             eng.sync_numpy_global()
         if self.hfactor:
             self.horizon_iters = eng.horizon_iters_state()           # planner.py:421,424: the heuristic's state persists
-        self.stats = total.as_dict() if total is not None else None
+        self.stats = run.total.as_dict() if run.total is not None else None
 
         if self.killed or self.tree.size > self.max_nodes:
             # The reference keeps node_seq / x_seq / u_seq / t_seq up to date inside the loop (planner.py:276-281), so
             # after a kill they describe the best plan of THIS tree whenever one was found.
-            if self.killed and not adopted and best_end >= 0:
-                self._adopt_plan(best_end)
+            if self.killed and not run.adopted and run.best_end >= 0:
+                self._adopt_plan(run.best_end)
             if self.printing:
                 print("Plan update terminated abruptly!")
             self.killed = False
@@ -412,6 +440,71 @@ class Planner:
             print("There is no plan to visualize!")
             return None
         return self.tree.visualize(dx, dy, node_seq=self.node_seq, show=show)
+
+
+class _PlanRun(object):
+    """What update_plan keeps between native calls of one plan."""
+
+
+def update_plans(jobs):
+    """
+    Several planners plan at once on one GPU: `jobs` is a list of dicts, each with the keys `planner`, `x0`, `sample_space` and,
+    optionally, update_plan's keyword arguments (goal_bias, guide, xrand_gen, pruning, finish_on_goal, specific_time) plus `seed`.
+    Every planner gets exactly what its own update_plan would give it -- its tree is the one it grows alone from the same sample
+    stream -- but the native calls are shared: lqrrt_engine_extend_multi advances all trees in lock step with two kernel launches
+    per tick whatever their number (csrc/engine_multi.hpp), which is how one MI355X is filled by planners that each use ~2 % of it
+    (a fleet's vehicles, the behaviours of one vehicle, restarts of one query: 16 trees 6 x, 64 trees 10 x the throughput of one).
+    `seed`: the default sampler of that planner draws from np.random.RandomState(seed) and np.random itself is left alone; without it
+    every planner starts from np.random's current state, as its own update_plan would, and np.random is left where the FIRST
+    planner's sampler stopped.  The planners must share the native system type, horizon, max_nodes, wave_size, pruning and device,
+    and run exact waves of an analytic-gain system (ValueError otherwise: plan those one by one).  Returns the list of
+    update_plan's return values.  Not in the reference: its Planner plans one tree on one core.
+    """
+    keys = ("goal_bias", "guide", "xrand_gen", "pruning", "finish_on_goal", "specific_time", "seed")
+    jobs = [dict(j) for j in jobs]
+    if not jobs:
+        return []
+    planners = [j["planner"] for j in jobs]
+    if len(set(id(p) for p in planners)) != len(planners):
+        raise ValueError("update_plans: a planner appears twice.")
+    p0 = planners[0]
+    prun0 = jobs[0].get("pruning", True)
+    for p, j in zip(planners, jobs):
+        unknown = set(j) - set(keys) - {"planner", "x0", "sample_space"}
+        if unknown:
+            raise ValueError("update_plans: unknown job key(s) %s." % sorted(unknown))
+        same = (type(p.system) is type(p0.system) and tuple(int(v) for v in p.hspan) == tuple(int(v) for v in p0.hspan)
+                and p.hfactor == p0.hfactor and int(p.max_nodes) == int(p0.max_nodes) and p.wave_size == p0.wave_size
+                and p.device == p0.device and bool(j.get("pruning", True)) == bool(prun0))
+        if not same:
+            raise ValueError("update_plans: the planners must share system type, horizon, max_nodes, wave_size, pruning and device.")
+        if p.wave_mode != "exact" or getattr(p.system, "riccati", False):
+            raise ValueError("update_plans: exact waves of analytic-gain systems only.")
+    results = [None] * len(jobs)
+    runs = []
+    for k, (p, j) in enumerate(zip(planners, jobs)):
+        run = p._plan_begin(j["x0"], j["sample_space"], j.get("goal_bias", 0), j.get("guide"), j.get("xrand_gen"),
+                            bool(j.get("pruning", True)), j.get("finish_on_goal", False), j.get("specific_time"), seed=j.get("seed"))
+        if run is None:
+            results[k] = False
+        else:
+            runs.append((k, p, run))
+    active = list(runs)
+    while active:
+        budget = min(p._plan_budget(run) for _, p, run in active)
+        stop = any(run.time_elapsed >= run.min_time for _, _, run in active)
+        t_call = time.perf_counter()
+        sts = Engine.extend_multi([run.eng for _, _, run in active], p0.wave_size, max_attempts=budget, node_limit=int(p0.max_nodes),
+                                  pruning=bool(prun0), stop_on_goal=bool(stop))
+        dt_call = time.perf_counter() - t_call
+        active = [(k, p, run) for (k, p, run), st in zip(active, sts) if not p._plan_after_call(run, st, dt_call)]
+    first = True
+    for k, p, run in runs:
+        if not first and not run.user_sampler and not run.own_stream:
+            run.own_stream = True                                # (np.random: left where the first planner's sampler stopped)
+        results[k] = p._plan_end(run)
+        first = False
+    return results
 
 
 def _add_stats(a, b):

@@ -250,3 +250,39 @@ def test_planner_call_budget_follows_the_clock():
     assert q._attempt_budget(4e5, 1e-3) == 256 and q._attempt_budget(4e5, 2e-3) == 256 and q._attempt_budget(4e5, 1.0) == 1024
     assert p.tree is None and p._engine is None                         # no GPU here: nothing was created, nothing raised
     assert isinstance(p.warm_up_error, Exception)                       # ... and the reason is on record (diagnosable before the first plan)
+
+
+def test_update_plans_argument_rules():
+    """Host logic of lqrrt_amd.update_plans (several planners through shared native calls): which combinations it refuses, before
+    anything touches a device."""
+    boat = lqrrt_amd.systems.BoatAdvanced(0)
+    cons = lqrrt_amd.Constraints(6, 3, boat.goal_buffer, boat.is_feasible)
+
+    def mk(**over):
+        kw = dict(error_tol=boat.error_tol, erf=boat.erf, goal0=boat.goal, printing=False, wave_size=256, **boat.plan_kwargs)
+        kw.update(over)
+        return lqrrt_amd.Planner(boat.dynamics, boat.lqr, cons, **kw)
+    assert lqrrt_amd.update_plans([]) == []
+    a, b = mk(), mk()
+    job = lambda p, **kw: dict(planner=p, x0=boat.x0, sample_space=boat.sample_space, goal_bias=boat.goal_bias, **kw)
+    with pytest.raises(ValueError):
+        lqrrt_amd.update_plans([job(a), job(a)])                                     # the same planner twice
+    with pytest.raises(ValueError):
+        lqrrt_amd.update_plans([job(a), job(mk(max_nodes=5000))])                    # different node limits
+    with pytest.raises(ValueError):
+        lqrrt_amd.update_plans([job(a), job(mk(wave_size=128))])
+    with pytest.raises(ValueError):
+        lqrrt_amd.update_plans([job(a), job(b, pruning=False)])
+    with pytest.raises(ValueError):
+        lqrrt_amd.update_plans([job(a), job(mk(wave_mode="synchronous"))])
+    with pytest.raises(ValueError):
+        lqrrt_amd.update_plans([job(a), job(b, nonsense=1)])
+    car = lqrrt_amd.systems.Car()
+    ccons = lqrrt_amd.Constraints(car.nstates, car.ncontrols, car.goal_buffer, car.is_feasible)
+    c = lqrrt_amd.Planner(car.dynamics, car.lqr, ccons, error_tol=car.error_tol, erf=car.erf, goal0=car.goal, printing=False,
+                          wave_size=256, **car.plan_kwargs)
+    with pytest.raises(ValueError):
+        lqrrt_amd.update_plans([job(a), dict(planner=c, x0=car.x0, sample_space=car.sample_space)])   # two system types
+    a.set_goal(None)
+    b.set_goal(None)
+    assert lqrrt_amd.update_plans([job(a), job(b)]) == [False, False]                # no goal: update_plan's answer, per planner

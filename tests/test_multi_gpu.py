@@ -178,3 +178,56 @@ def test_many_engines_take_the_two_wavefront_rollout_and_grow_the_same_trees():
     for k in range(len(seeds)):
         assert _counts(stats[k]) == stats_alone[k]
         _same(multi[k], alone[k])
+
+
+def test_update_plans_gives_every_planner_its_own_update_plan():
+    """lqrrt_amd.update_plans: several Planner objects through shared native calls.  Each planner's tree, plan and statistics are
+    those of its own update_plan from the same sample stream (fake clock: the plans end by the node limit / at the first goal
+    hit after min_time exactly like the solo ones)."""
+    import lqrrt_amd
+
+    def mk(max_nodes, **over):
+        s = lqrrt_amd.systems.SYSTEMS["boat_advanced"](0)
+        cons = lqrrt_amd.Constraints(s.nstates, s.ncontrols, s.goal_buffer, s.is_feasible)
+        kw = dict(s.plan_kwargs)
+        kw.update(error_tol=s.error_tol, erf=s.erf, min_time=2, max_time=3, max_nodes=max_nodes, goal0=s.goal,
+                  sys_time=lambda: 0.0, printing=False, wave_size=256)
+        kw.update(over)
+        return s, lqrrt_amd.Planner(s.dynamics, s.lqr, cons, **kw)
+
+    seeds = (3, 4, 5, 6, 7)
+    solo = []
+    for sd in seeds:
+        s, p = mk(1200)
+        np.random.seed(sd)
+        assert p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10) is False       # ended by the node limit
+        solo.append(p)
+    fleet = [mk(1200) for _ in seeds]
+    before = np.random.get_state()[1].copy()
+    res = lqrrt_amd.update_plans([dict(planner=p, x0=s.x0, sample_space=s.sample_space, goal_bias=s.goal_bias, xrand_gen=10, seed=sd)
+                                  for (s, p), sd in zip(fleet, seeds)])
+    assert res == [False] * len(seeds)
+    assert np.array_equal(np.random.get_state()[1], before)                           # per-planner streams: np.random untouched
+    for (s, p), q in zip(fleet, solo):
+        assert p.tree.size == q.tree.size and list(p.tree.pID) == list(q.tree.pID)
+        np.testing.assert_array_equal(p.tree.state, q.tree.state)
+        assert p.plan_reached_goal == q.plan_reached_goal and list(p.node_seq) == list(q.node_seq) and p.T == q.T
+        np.testing.assert_array_equal(np.array(p.x_seq), np.array(q.x_seq))
+        np.testing.assert_array_equal(np.array(p.u_seq), np.array(q.u_seq))
+        for key in ("attempts", "accepted", "candidates", "goal_hits", "tree_size"):       # (waves / rounds depend on where the calls end)
+            assert p.stats[key] == q.stats[key], key
+        np.testing.assert_array_equal(p.get_state(0.5 * p.T), q.get_state(0.5 * q.T))
+    # a clock that lets the plans finish: every planner returns True with a plan that ends in its goal region, finish_on_goal included
+    t = [0.0]
+
+    def clock():
+        t[0] += 0.05
+        return t[0]
+    fleet2 = [mk(60000, sys_time=clock, min_time=0.5, max_time=400.0) for _ in range(3)]
+    res2 = lqrrt_amd.update_plans([dict(planner=p, x0=s.x0, sample_space=s.sample_space, goal_bias=s.goal_bias, seed=10 + k,
+                                        finish_on_goal=(k == 0)) for k, (s, p) in enumerate(fleet2)])
+    assert res2 == [True, True, True]
+    for k, (s, p) in enumerate(fleet2):
+        assert p.plan_reached_goal and p.node_seq == p.tree.climb(p.node_seq[-1])
+        assert p._in_goal(p.x_seq[-1]) or k == 0
+    np.testing.assert_array_equal(fleet2[0][1].tree.state[-1], np.array(fleet2[0][0].goal, dtype=np.float64))
