@@ -489,6 +489,9 @@ def update_plans(jobs):
             results[k] = False
         else:
             runs.append((k, p, run))
+    # every planner's clock starts when the shared loop does: the others' set-up is not part of its time budget
+    for _, p, run in runs:
+        run.time_start, run.time_elapsed = p.sys_time(), 0
     active = list(runs)
     while active:
         budget = min(p._plan_budget(run) for _, p, run in active)

@@ -10,7 +10,8 @@ Two residences:
   * device  During Planner.update_plan the planner binds the tree to its engine: the nodes are then the engine's
             SoA buffers in HBM and every feature is copied out on access (cached until the tree grows).  When the
             engine is about to be reused for the next plan the planner detaches the tree first, i.e. snapshots
-            all features to the host in a handful of bulk copies -- so a Tree object kept from an earlier plan
+            all features to the host in five bulk copies (kept as arrays: per-node rows are made on access, as for a
+            bound tree -- a 35k-node tree detaches in milliseconds) -- so a Tree object kept from an earlier plan
             (the ROS node does that: lqrrt_node.py:477 keeps planner.tree and reads it at :889, :1149 while the
             next plan grows) stays what it was, and never touches the engine again.
 
@@ -42,6 +43,30 @@ class _Rows(object):
         return (self._get(k) for k in range(len(self)))
 
 
+class _Snapshot(object):
+    """The nodes of a detached tree: the engine's five bulk copies behind the getters a bound Tree reads its engine through."""
+
+    epoch = 0
+
+    def __init__(self, e):
+        self.size = e.size
+        self._state, self._pid, self._K = e.states(), e.parents(), e.gains()
+        self._xe, self._ue, self._ln = e.edges()
+
+    def states(self):
+        return self._state
+
+    def parents(self):
+        return self._pid
+
+    def gains(self):
+        return self._K
+
+    def edge(self, i):
+        n = int(self._ln[i])
+        return self._xe[i, :n], self._ue[i, :n]
+
+
 class Tree:
     """
     Tree(seed_state, seed_lqr): seed_state is the state of the root, seed_lqr the (S, K) tuple of local LQR
@@ -61,6 +86,7 @@ class Tree:
         self._h_u = [[np.zeros(self.ncontrols)]]                # tree.py:70
         # device residence
         self._e = None
+        self._snap = None                                       # nodes [0, snap.size) of a detached tree (host arrays)
         self._generation = None
         self._S = None
         self._cache = {}
@@ -73,6 +99,7 @@ class Tree:
     def _bind(self, engine, S):
         """The engine's tree (just reset to this tree's seed) becomes the storage of nodes [0, engine.size)."""
         self._e = engine
+        self._snap = None
         self._generation = engine.generation
         self._S = S
         self._cache, self._cache_size = {}, -1
@@ -88,25 +115,21 @@ class Tree:
             raise RuntimeError("this Tree's engine was reset for another plan before the tree was detached")
         return self._e
 
+    def _src(self):
+        """Where nodes [0, _ndev()) live: the engine (after checking that it still holds THIS tree), a detached tree's snapshot, or None."""
+        return self._dev() if self._e is not None else self._snap
+
     def _detach(self):
-        """Snapshots every feature to the host (bulk copies) and lets go of the engine."""
+        """Snapshots every feature to the host (five bulk copies) and lets go of the engine."""
         if self._e is None:
             return
-        e = self._dev()
-        N = e.size
-        state, pid, K = e.states(), e.parents().tolist(), e.gains()
-        xe, ue, ln = e.edges()
-        tail = (self._h_state, self._h_pID, self._h_lqr, self._h_x, self._h_u)
-        self._h_state = [state[i] for i in range(N)] + tail[0]
-        self._h_pID = pid + tail[1]
-        self._h_lqr = [(self._S, K[i]) for i in range(N)] + tail[2]
-        self._h_x = [[xe[i, k] for k in range(ln[i])] for i in range(N)] + tail[3]
-        self._h_u = [[ue[i, k] for k in range(ln[i])] for i in range(N)] + tail[4]
+        self._snap = _Snapshot(self._dev())
         self._e, self._generation, self._cache, self._cache_size = None, None, {}, -1
 
     # -- features -----------------------------------------------------------------------------------
     def _ndev(self):
-        return self._dev().size if self._e is not None else 0
+        src = self._src()
+        return src.size if src is not None else 0
 
     @property
     def size(self):
@@ -114,7 +137,7 @@ class Tree:
 
     def _fresh(self):
         # keyed on (size, epoch): a truncate or rewind followed by regrowth to the same size must not serve old nodes
-        key = (self._ndev(), getattr(self._e, "epoch", 0))
+        key = (self._ndev(), getattr(self._src(), "epoch", 0))
         if key != self._cache_size:
             self._cache, self._cache_size = {}, key
         return self._cache
@@ -122,20 +145,20 @@ class Tree:
     @property
     def state(self):
         host = np.array(self._h_state, dtype=np.float64).reshape(len(self._h_state), self.nstates)
-        if self._e is None:
+        if self._src() is None:
             return host
         c = self._fresh()
         if "state" not in c:
-            c["state"] = self._dev().states()
+            c["state"] = self._src().states()
         return np.vstack((c["state"], host)) if len(host) else c["state"]
 
     @property
     def pID(self):
-        if self._e is None:
+        if self._src() is None:
             return self._h_pID
         c = self._fresh()
         if "pID" not in c:
-            c["pID"] = self._dev().parents().tolist()
+            c["pID"] = self._src().parents().tolist()
         return c["pID"] + self._h_pID if self._h_pID else c["pID"]
 
     def _lqr_of(self, i):
@@ -144,7 +167,7 @@ class Tree:
             return self._h_lqr[i - n]
         c = self._fresh()
         if "K" not in c:
-            c["K"] = self._dev().gains()
+            c["K"] = self._src().gains()
         return (self._S, c["K"][i])
 
     def _edge(self, i):
@@ -154,7 +177,7 @@ class Tree:
         c = self._fresh()
         key = ("edge", i)
         if key not in c:
-            x, u = self._dev().edge(i)
+            x, u = self._src().edge(i)
             c[key] = (list(x), list(u))
         return c[key]
 

@@ -231,3 +231,14 @@ def test_update_plans_gives_every_planner_its_own_update_plan():
         assert p.plan_reached_goal and p.node_seq == p.tree.climb(p.node_seq[-1])
         assert p._in_goal(p.x_seq[-1]) or k == 0
     np.testing.assert_array_equal(fleet2[0][1].tree.state[-1], np.array(fleet2[0][0].goal, dtype=np.float64))
+
+
+def test_fleet_example_runs():
+    """examples/fleet_gpu.py: real clock, a quarter of a second per plan -- four planners one by one, then together through update_plans;
+    together they must get more attempts per second of wall clock than one by one (on a shared box: any gain at all)."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "fleet_gpu.py"), "4"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("attempts per second")][-1]
+    solo, joint = [float(tok) for tok in line.replace(",", " ").split() if tok[0].isdigit() and "e" in tok]
+    assert joint > solo, line
