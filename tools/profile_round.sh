@@ -12,6 +12,10 @@
 # then, back in the container: python tools/summarize_profiles.py rNN
 R=/root/repo
 O=$R/gpurun_out/prof
+# the micro-benchmarks are built artefacts (git-ignored): a fresh checkout has none -- build what is missing here (hipcc is on the box)
+for b in launch_floor launch_chain issue barrier; do
+  [ -x $R/tools/micro/$b.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $R/tools/micro/$b.bin $R/tools/micro/$b.hip > /dev/null 2>&1
+done
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python $R/bench.py --steps 20 --warmup 5 > $O/bench_plain.json 2> $O/bench_plain.err < /dev/null
