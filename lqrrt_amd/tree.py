@@ -51,7 +51,7 @@ class _Snapshot(object):
     def __init__(self, e):
         self.size = e.size
         self._state, self._pid, self._K = e.states(), e.parents(), e.gains()
-        self._xe, self._ue, self._ln = e.edges()
+        self._xe, self._ue, self._ln = e.edges(pinned=True)
 
     def states(self):
         return self._state
