@@ -92,7 +92,9 @@ def plugin_system(fn, kind):
         return fn.system
     raise ValueError(
         "Expected %s to be a native plugin (e.g. lqrrt_amd.systems.BoatAdvanced().%s): lqrrt_amd "
-        "evaluates the problem on the GPU and cannot call arbitrary Python functions." % (kind, kind))
+        "evaluates the problem on the GPU and cannot call arbitrary Python functions.  A problem of your own is one C++ header "
+        "(dynamics / lqr / erf / is_feasible, see examples/user_system/unicycle.hpp) compiled in by tools/build_user_system.py "
+        "and wrapped by lqrrt_amd.systems.UserSystem -- INTEGRATION.md section 5." % (kind, kind))
 
 
 class NativeSystem(object):

@@ -18,9 +18,29 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 def build(header, out):
     header = os.path.abspath(header)
     csrc = os.path.join(ROOT, "lqrrt_amd", "csrc")
+    define = "-DLQRRT_USER_SYSTEM=\"%s\"" % header
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-DLQRRT_USER_SYSTEM=\"%s\"" % header, os.path.join(csrc, "engine.hip"), "-o", os.path.abspath(out)]
-    subprocess.check_call(cmd, cwd=csrc)
+           define, os.path.join(csrc, "engine.hip"), "-o", os.path.abspath(out)]
+    # By-products for the CPU tests that pin registers / occupancy / ISA (tests/test_abi_cpu.py via tools/kernel_resources.py): the
+    # resource-usage remarks of THIS compile, and the device assembly from a compile that runs beside it -- so that those tests
+    # read a cache instead of compiling engine.hip two more times (~3 min each).
+    import kernel_resources as kr
+    asm = None
+    try:
+        if not os.path.exists(kr.cache_file("s", [define])):
+            os.makedirs(kr.CACHE, exist_ok=True)
+            asm_tmp = kr.cache_file("s", [define]) + ".tmp%d.s" % os.getpid()
+            asm = (subprocess.Popen(kr.device_asm_command(asm_tmp, [define]), cwd=csrc, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL), asm_tmp)
+    except OSError:
+        asm = None
+    done = subprocess.run(cmd + [kr.REMARK_FLAG], cwd=csrc, stderr=subprocess.PIPE, text=True)
+    if done.returncode != 0:
+        sys.stderr.write(done.stderr)
+        raise subprocess.CalledProcessError(done.returncode, cmd)
+    if "Function Name" in done.stderr:
+        kr.store("remarks", [define], done.stderr)
+    if asm is not None and asm[0].wait() == 0:
+        os.replace(asm[1], kr.cache_file("s", [define]))
     return os.path.abspath(out)
 
 

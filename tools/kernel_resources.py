@@ -12,11 +12,70 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
+REMARK_FLAG = "-Rpass-analysis=kernel-resource-usage"
+CACHE = os.path.join(ROOT, "build", "isa_cache")                # git-ignored; keyed by the content of every source the compile reads
+
+
+def source_key(extra=()):
+    """Hash of what a compile of csrc/engine.hip with `extra` depends on: csrc/*, include/*, a user header named by
+    -DLQRRT_USER_SYSTEM and the flags themselves."""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for d in (os.path.join(ROOT, "lqrrt_amd", "csrc"), os.path.join(ROOT, "include")):
+        files += [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith((".hip", ".hpp", ".def", ".h"))]
+    for x in extra:
+        h.update(x.encode())
+        m = re.match(r'-DLQRRT_USER_SYSTEM="?([^"]+)"?$', x)
+        if m:
+            files.append(m.group(1))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:24]
+
+
+def cache_file(kind, extra=()):
+    return os.path.join(CACHE, "%s.%s" % (source_key(extra), kind))
+
+
+def store(kind, extra, text):
+    os.makedirs(CACHE, exist_ok=True)
+    tmp = cache_file(kind, extra) + ".tmp%d" % os.getpid()
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, cache_file(kind, extra))
+
+
 def remarks(extra=()):
+    """hipcc's kernel-resource-usage remarks for csrc/engine.hip (a ~3 min compile), cached by source content: __graft_entry__.build()
+    captures them from the compile it runs anyway (tools/build_user_system.py), so the CPU tests that read them cost nothing after a build."""
+    path = cache_file("remarks", extra)
+    if os.path.exists(path):
+        return open(path).read()
     src = os.path.join(ROOT, "lqrrt_amd", "csrc", "engine.hip")
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c", src, "-o", "/dev/null",
-           "-Rpass-analysis=kernel-resource-usage"] + list(extra)
-    return subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.dirname(src)).stderr
+           REMARK_FLAG] + list(extra)
+    text = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.dirname(src)).stderr
+    if "Function Name" in text:
+        store("remarks", extra, text)
+    return text
+
+
+def device_asm_command(out, extra=()):
+    src = os.path.join(ROOT, "lqrrt_amd", "csrc", "engine.hip")
+    return [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-S", "--cuda-device-only", src, "-o", out] + list(extra)
+
+
+def device_asm(extra=()):
+    """The gfx950 assembly of csrc/engine.hip (cached like remarks(); build() produces it beside its own compiles)."""
+    path = cache_file("s", extra)
+    if not os.path.exists(path):
+        os.makedirs(CACHE, exist_ok=True)
+        tmp = path + ".tmp%d.s" % os.getpid()
+        subprocess.run(device_asm_command(tmp, extra), check=True, capture_output=True, cwd=os.path.join(ROOT, "lqrrt_amd", "csrc"))
+        os.replace(tmp, path)
+    return open(path).read()
 
 
 def demangle(names):
@@ -45,12 +104,7 @@ def private_memory_instructions(mangled_names, extra=()):
     """ISA check behind the ScratchSize remark: the steer kernels live at the SGPR limit, and the register allocator sometimes leaves
     a few dozen bytes of frame RESERVED (an emergency spill slot) that no instruction touches -- `ScratchSize 36` with nothing spilled.
     Returns {mangled name: number of scratch_* / private buffer_load|store instructions in the kernel's code}."""
-    import tempfile
-    src = os.path.join(ROOT, "lqrrt_amd", "csrc", "engine.hip")
-    out = os.path.join(tempfile.mkdtemp(), "engine.s")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-S", "--cuda-device-only", src, "-o", out] + list(extra)
-    subprocess.run(cmd, check=True, capture_output=True, cwd=os.path.dirname(src))
-    text = open(out).read()
+    text = device_asm(extra)
     res = {}
     for name in mangled_names:
         name = name.split()[0]                                  # (the remark line carries " [-Rpass-analysis=...]" behind the symbol)
