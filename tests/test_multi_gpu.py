@@ -242,3 +242,60 @@ def test_fleet_example_runs():
     line = [l for l in out.stdout.splitlines() if l.startswith("attempts per second")][-1]
     solo, joint = [float(tok) for tok in line.replace(",", " ").split() if tok[0].isdigit() and "e" in tok]
     assert joint > solo, line
+
+
+def test_update_plans_mixed_jobs_on_the_car():
+    """Jobs of one update_plans call need not look alike: the default sampler, one try per sample (xrand_gen = 1), a user sampling
+    function, a different start state and finish_on_goal -- each planner still ends with what its own update_plan gives."""
+    import lqrrt_amd
+
+    def mk():
+        s = lqrrt_amd.systems.SYSTEMS["car"](0)
+        cons = lqrrt_amd.Constraints(s.nstates, s.ncontrols, s.goal_buffer, s.is_feasible)
+        kw = dict(s.plan_kwargs)
+        kw.update(error_tol=s.error_tol, erf=s.erf, min_time=0, max_time=3, max_nodes=900, goal0=s.goal, sys_time=lambda: 0.0,
+                  printing=False, wave_size=128)
+        p = lqrrt_amd.Planner(s.dynamics, s.lqr, cons, **kw)
+        p.force_arrive_max_steps = 5000
+        return s, p
+
+    def sampler_for(seed, s):
+        rng = np.random.RandomState(seed)
+        lo, hi = np.array(s.sample_space, dtype=np.float64).T
+        goal = np.array(s.goal, dtype=np.float64)
+        return lambda planner: goal.copy() if rng.uniform() < 0.3 else lo + (hi - lo) * rng.uniform(size=len(lo))
+
+    s0 = mk()[0]
+    x1 = np.array(s0.x0, dtype=np.float64) + np.array([1.0, -0.5, 0.1, 0.0, 0.0])[:s0.nstates]
+    specs = [dict(goal_bias=s0.goal_bias, xrand_gen=10, seed=31),
+             dict(goal_bias=s0.goal_bias, xrand_gen=1, seed=32, finish_on_goal=True),
+             dict(xrand_gen="fn33"),
+             dict(goal_bias=s0.goal_bias, seed=34, x0=x1)]
+    outcomes = []
+    for joint in (False, True):
+        fleet = [mk() for _ in specs]
+        jobs = []
+        for (s, p), sp in zip(fleet, specs):
+            j = dict(planner=p, x0=sp.get("x0", s.x0), sample_space=s.sample_space)
+            j.update({k: v for k, v in sp.items() if k != "x0"})
+            if j.get("xrand_gen") == "fn33":
+                j["xrand_gen"] = sampler_for(33, s)
+            jobs.append(j)
+        if joint:
+            res = lqrrt_amd.update_plans(jobs)
+        else:
+            res = []
+            for j in jobs:
+                kw = {k: v for k, v in j.items() if k not in ("planner", "x0", "sample_space", "seed")}
+                if "seed" in j:
+                    np.random.seed(j["seed"])
+                res.append(j["planner"].update_plan(j["x0"], j["sample_space"], **kw))
+        outcomes.append((res, [p for _, p in fleet]))
+    (res_a, pa), (res_b, pb) = outcomes
+    assert res_a == res_b
+    for a, b in zip(pa, pb):
+        assert a.tree.size == b.tree.size and list(a.tree.pID) == list(b.tree.pID)
+        np.testing.assert_array_equal(a.tree.state, b.tree.state)
+        assert a.plan_reached_goal == b.plan_reached_goal and list(a.node_seq) == list(b.node_seq)
+        np.testing.assert_array_equal(np.array(a.x_seq), np.array(b.x_seq))
+        np.testing.assert_array_equal(np.array(a.u_seq), np.array(b.u_seq))
