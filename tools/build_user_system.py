@@ -41,6 +41,7 @@ def build(header, out):
         kr.store("remarks", [define], done.stderr)
     if asm is not None and asm[0].wait() == 0:
         os.replace(asm[1], kr.cache_file("s", [define]))
+        kr.prune(protect=(kr.source_key([define]),))
     return os.path.abspath(out)
 
 

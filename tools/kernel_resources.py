@@ -39,6 +39,20 @@ def cache_file(kind, extra=()):
     return os.path.join(CACHE, "%s.%s" % (source_key(extra), kind))
 
 
+def prune(keep=2, protect=()):
+    """The assembly files are ~70 MB each: only the newest `keep` stay (with their remarks), plus the keys in `protect`."""
+    try:
+        asm = sorted((f for f in os.listdir(CACHE) if f.endswith(".s")), key=lambda f: os.path.getmtime(os.path.join(CACHE, f)), reverse=True)
+        for f in asm[keep:]:
+            if f[:-2] in protect:
+                continue
+            for g in (f, f[:-2] + ".remarks"):
+                if os.path.exists(os.path.join(CACHE, g)):
+                    os.remove(os.path.join(CACHE, g))
+    except OSError:
+        pass
+
+
 def store(kind, extra, text):
     os.makedirs(CACHE, exist_ok=True)
     tmp = cache_file(kind, extra) + ".tmp%d" % os.getpid()
@@ -75,6 +89,7 @@ def device_asm(extra=()):
         tmp = path + ".tmp%d.s" % os.getpid()
         subprocess.run(device_asm_command(tmp, extra), check=True, capture_output=True, cwd=os.path.join(ROOT, "lqrrt_amd", "csrc"))
         os.replace(tmp, path)
+        prune(protect=(source_key(extra),))
     return open(path).read()
 
 
