@@ -174,6 +174,13 @@ class Planner:
         if self.tree is not None:
             self.tree._detach()
         eng = run.eng = self._get_engine()
+        run.own_stream = seed is not None                           # (update_plans: a sample stream per planner, np.random untouched)
+        if run.own_stream and not run.user_sampler:
+            # (seeded before anything else: set_resolution rewinds the generator to the first uncommitted candidate of the plan before --
+            #  a replay of every draw that plan consumed, milliseconds after a long one -- unless the stream has just been replaced;
+            #  update_plan's own path ends with sync_numpy_global, which leaves nothing to replay)
+            st = np.random.RandomState(seed).get_state()
+            eng.set_mt19937(st[1], st[2])
         if self.hfactor:
             # adaptive horizon: rollouts may run hspan[1] steps (include/lqrrt_hip.h, lqrrt_resolution.adaptive)
             eng.set_resolution(self.dt, self.FPR, int(self.hspan[1]), self.error_tol, self.goal, self.constraints.goal_buffer,
@@ -181,7 +188,6 @@ class Planner:
         else:
             eng.set_resolution(self.dt, self.FPR, self.horizon_iters, self.error_tol, self.goal, self.constraints.goal_buffer)
         eng.tree_reset(x0)                                          # planner.py:172
-        run.own_stream = seed is not None                           # (update_plans: a sample stream per planner, np.random untouched)
         if not run.user_sampler:
             eng.set_sampler(np.mean(space, axis=1), np.diff(space).flatten(), bias, tries_limit)
             if run.own_stream:
