@@ -63,6 +63,18 @@ extern "C" {
 #define LQRRT_MODEL_USER               100  /* an out-of-tree problem compiled in with -DLQRRT_USER_SYSTEM='"header.hpp"'
                                              * (lqrrt_amd/csrc/models.def) */
 
+#define LQRRT_MODEL_GENERIC            200  /* NO plugins compiled in: the reference's plugin API proper, arbitrary host callables
+                                             * (planner.py:35-59, constraints.py:27).  The caller runs sample / steer / feasibility on the
+                                             * host, in the reference's order (lqrrt_amd/callback.py), and the engine holds what the
+                                             * reference spends 74-95 % of its time on: the node table (SoA states + cos/sin of the angular
+                                             * ones, parents, ignore set) and Planner._costs_to_go + the nearest selection
+                                             * (planner.py:239-247, 340-350).  lqrrt_system_desc: nstates 1..LQRRT_MAX_STATES, ncontrols (kept,
+                                             * not used), params[0] = number of angular states (erf wraps them, e.g. demo_car.py:115-126),
+                                             * params[1..] = their indices, ascending; no geometry.  Entry points that work: lqrrt_engine_create /
+                                             * destroy, lqrrt_tree_reset / load / append / truncate / mark / rewind / size / set_ignored /
+                                             * get_states / get_parents / get_ignored, lqrrt_nn_argmin, lqrrt_nn_argmin_host, lqrrt_nn_argmin_errors,
+                                             * lqrrt_costs_to_go; every other one returns LQRRT_E_STATE. */
+
 #define LQRRT_MAX_STATES   12
 #define LQRRT_MAX_CONTROLS 6
 #define LQRRT_MAX_PARAMS   96
@@ -135,6 +147,9 @@ typedef struct {
     int64_t resteers;        /* samples re-steered in repair rounds                        */
     int64_t goal_hits;       /* accepted nodes inside the goal region                      */
     int64_t speculated;      /* samples evaluated (>= attempts: discarded tails included)  */
+    int64_t chain_slots;     /* sum over waves of 1 + the longest chain of in-wave parents among the committed samples: the
+                              * rollouts that HAD to run one after another (a child cannot be steered before the parent it
+                              * starts from exists) -- the dependency bound of the exact-mode schedule, in launches          */
     int32_t tree_size;       /* nodes after the call                                       */
     int32_t stop_reason;     /* LQRRT_STOP_*                                               */
 } lqrrt_extend_stats;
@@ -147,6 +162,10 @@ typedef struct {
 /* ---------------------------------------------------------------- lifecycle ---------- */
 
 const char* lqrrt_last_error(void);
+
+/* The environment switches this library reads (each once per process), one per line: "NAME  (default d)  effect" -- generated from
+ * the one table lqrrt_amd/csrc/switches.def.  None of them changes a result; they are measurement and test levers. */
+const char* lqrrt_switches_describe(void);
 int lqrrt_abi_version(void);
 
 /* Number of usable HIP devices (0 when there is no GPU: every compute call then fails). */
@@ -157,6 +176,11 @@ int lqrrt_device_count(void);
 int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int capacity, int max_wave,
                         lqrrt_engine** out);
 int lqrrt_engine_destroy(lqrrt_engine* e);
+
+/* Memory this engine holds: device_bytes (HBM: node pools sized by `capacity` -- per node 8 (n + 3 nw + 2 + m n) + 8 bytes and the
+ * edge pools 8 horizon_iters (n + m); wave buffers sized by max_wave; geometry) and pinned_bytes (page-locked host memory).  Either
+ * pointer may be NULL.  No counterpart in the reference, whose tree is Python lists; INTEGRATION.md section 6 tabulates it. */
+int lqrrt_engine_footprint(lqrrt_engine* e, int64_t* device_bytes, int64_t* pinned_bytes);
 
 /* Replaces the model parameters, hull points, obstacle table and occupancy grid of an existing engine (same
  * model); the tree is kept, queued samples are regenerated from the first uncommitted row of the stream.
@@ -223,6 +247,13 @@ int lqrrt_tree_load(lqrrt_engine* e, int count, const double* states_host, const
                     const int32_t* edge_len_host, const double* xedge_host, const double* uedge_host,
                     const uint8_t* ignored_host, void* stream);
 
+/* Tree.add_node(pID, state, lqr, x_seq, u_seq) (tree.py:77-96) from host data: appends ONE node.  K [m][n] = lqr[1]; the edge is
+ * `len` rows of xseq [len][n] / useq [len][m] (NULL xseq: the state itself, NULL useq: zeros), 1 <= len <= horizon_iters.
+ * LQRRT_MODEL_GENERIC: only state and parent go to the device (as arguments of one small launch, asynchronous on `stream`); K, xseq
+ * and useq stay with the caller and must be NULL.  A non-existent parent is LQRRT_E_ARG with tree.py:84's message. */
+int lqrrt_tree_append(lqrrt_engine* e, int parent, const double* state_host, const double* K_host, int len,
+                      const double* xseq_host, const double* useq_host, void* stream);
+
 /* Forgets every node with id >= size (nodes are only ever appended, so the first `size` nodes are exactly the tree
  * as it stood when it had that size).  Ignore bits of the dropped nodes are cleared, those of kept nodes stay: if a
  * dropped node was a goal hit, the caller restates the ignore set of the kept nodes with lqrrt_tree_set_ignored.  The best
@@ -287,6 +318,19 @@ int lqrrt_lqr_dare_batch(lqrrt_engine* e, const double* x_dev, const double* u_d
  * use_ignore = 0 reproduces pruning=False (np.argmin, planner.py:247). */
 int lqrrt_nn_argmin(lqrrt_engine* e, const double* xs_dev /*[W][n]*/, int W, const double* S_dev,
                     int use_ignore, int32_t* id_dev, double* cost_dev, void* stream);
+
+/* The same for ONE query given and answered in host memory (x [n]; S [n][n] or NULL = the system's own S, identity for
+ * LQRRT_MODEL_GENERIC) -- the form a host loop that steers with Python callables between two queries needs: synchronous, the
+ * query travels as kernel arguments and the answer returns through mapped pinned memory (LQRRT_MODEL_GENERIC: two launches and
+ * one wait, no copy).  cost_out may be NULL. */
+int lqrrt_nn_argmin_host(lqrrt_engine* e, const double* x_host /*[n]*/, const double* S_host, int use_ignore,
+                         int32_t* id_out, double* cost_out, void* stream);
+
+/* LQRRT_MODEL_GENERIC only: the selection for a query whose error rows erf(x, node i) the caller evaluated itself
+ * (errors_host [tree_size][n] row-major; planner.py:588's erf_v for an erf that is not of the subtract-and-wrap form):
+ * contraction with S (NULL = identity), ignore set and tie rule as above.  One host-to-device copy of the rows per call. */
+int lqrrt_nn_argmin_errors(lqrrt_engine* e, const double* errors_host, const double* S_host, int use_ignore,
+                           int32_t* id_out, double* cost_out, void* stream);
 
 /* Full cost vector of one sample against the tree (planner.py:340-350), cost [tree_size]. */
 int lqrrt_costs_to_go(lqrrt_engine* e, const double* x_dev /*[n]*/, const double* S_dev,

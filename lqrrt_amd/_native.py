@@ -16,6 +16,7 @@ MAX_STATES, MAX_CONTROLS, MAX_PARAMS = 12, 6, 96
 MODEL_BOAT_ADVANCED, MODEL_BOAT_INTERMEDIATE, MODEL_BOAT_NOVICE = 1, 2, 3
 MODEL_CAR, MODEL_PENDULUM, MODEL_DOUBLE_INTEGRATOR, MODEL_ROS_BOAT, MODEL_PENDULUM_LQR = 4, 5, 6, 7, 8
 MODEL_BOAT_NOVICE_LQR = 9
+MODEL_GENERIC = 200       # no plugins compiled in: node table + nearest-neighbour stage for host callables (lqrrt_amd/callback.py)
 MODEL_USER = 100          # an out-of-tree problem compiled in (csrc/models.def)
 
 E_ARG, E_HIP, E_NODEVICE, E_CAPACITY, E_STATE = -1, -2, -3, -4, -5
@@ -47,7 +48,7 @@ class SamplerDesc(C.Structure):
 class ExtendStats(C.Structure):
     _fields_ = [("attempts", C.c_int64), ("accepted", C.c_int64), ("candidates", C.c_int64),
                 ("waves", C.c_int64), ("fix_rounds", C.c_int64), ("resteers", C.c_int64),
-                ("goal_hits", C.c_int64), ("speculated", C.c_int64), ("tree_size", C.c_int32),
+                ("goal_hits", C.c_int64), ("speculated", C.c_int64), ("chain_slots", C.c_int64), ("tree_size", C.c_int32),
                 ("stop_reason", C.c_int32)]
 
     def as_dict(self):
@@ -59,10 +60,12 @@ _P = C.c_void_p
 _I, _I64, _D = C.c_int, C.c_int64, C.c_double
 SIGNATURES = {
     "lqrrt_last_error": (C.c_char_p, []),
+    "lqrrt_switches_describe": (C.c_char_p, []),
     "lqrrt_abi_version": (_I, []),
     "lqrrt_device_count": (_I, []),
     "lqrrt_engine_create": (_I, [C.POINTER(SystemDesc), _I, _I, _I, C.POINTER(_P)]),
     "lqrrt_engine_destroy": (_I, [_P]),
+    "lqrrt_engine_footprint": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "lqrrt_engine_set_geometry": (_I, [_P, C.POINTER(SystemDesc), _P]),
     "lqrrt_engine_set_wave_mode": (_I, [_P, _I]),
     "lqrrt_engine_set_cu_mask": (_I, [_P, _P, _I]),
@@ -75,6 +78,7 @@ SIGNATURES = {
     "lqrrt_tree_reset": (_I, [_P, _P, _P]),
     "lqrrt_tree_size": (_I, [_P]),
     "lqrrt_tree_load": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "lqrrt_tree_append": (_I, [_P, _I, _P, _P, _I, _P, _P, _P]),
     "lqrrt_tree_truncate": (_I, [_P, _I]),
     "lqrrt_tree_set_ignored": (_I, [_P, _I, _I, _P]),
     "lqrrt_tree_get_edges": (_I, [_P, _I, _I, _P, _P]),
@@ -93,6 +97,8 @@ SIGNATURES = {
     "lqrrt_erf_batch": (_I, [_P, _P, _P, _I, _P, _P]),
     "lqrrt_lqr_dare_batch": (_I, [_P, _P, _P, _I, _P, _P, _D, _P, _P, _P, _P, _P, _P]),
     "lqrrt_nn_argmin": (_I, [_P, _P, _I, _P, _I, _P, _P, _P]),
+    "lqrrt_nn_argmin_host": (_I, [_P, _P, _P, _I, C.POINTER(C.c_int32), C.POINTER(_D), _P]),
+    "lqrrt_nn_argmin_errors": (_I, [_P, _P, _P, _I, C.POINTER(C.c_int32), C.POINTER(_D), _P]),
     "lqrrt_costs_to_go": (_I, [_P, _P, _P, _P, _P]),
     "lqrrt_steer_batch": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "lqrrt_steer_force": (_I, [_P, _I, _P, _I, _D, _D, _P, _P, _P, _P]),

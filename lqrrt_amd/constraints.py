@@ -1,12 +1,12 @@
 """
 Constraints -- same class surface as the reference's lqrrt/constraints.py:17-61: state and
-effort dimensionality, the goal buffer, and the feasibility function.  The feasibility
-function must be the `.is_feasible` plugin handle of a native system (lqrrt_amd.systems):
-the collision sweep runs inside the HIP steer kernel, one problem per wavefront.
+effort dimensionality, the goal buffer, and the feasibility function: the `.is_feasible`
+plugin handle of a native system (lqrrt_amd.systems; the collision sweep then runs inside the
+HIP steer kernel, one problem per wavefront) or any Python callable (callback mode).
 """
 import numpy as np
 
-from .systems import plugin_system
+from .systems import native_system_of
 
 
 class Constraints:
@@ -19,8 +19,8 @@ class Constraints:
 
     goal_buffer: Half-edge lengths of box defining goal region.
 
-    is_feasible: The `.is_feasible` handle of an lqrrt_amd.systems object
-                 (callable as is_feasible(x, u) -> bool, evaluated on the GPU).
+    is_feasible: Function is_feasible(x, u) -> bool: the `.is_feasible` handle of an
+                 lqrrt_amd.systems object (evaluated on the GPU) or any Python callable.
 
     """
 
@@ -39,19 +39,23 @@ class Constraints:
                 raise ValueError("The goal_buffer must have same dimensionality as state.")
 
     def set_feasibility_function(self, is_feasible):
-        """constraints.py:53-61, restricted to native plugin handles."""
+        """constraints.py:53-61.  The `.is_feasible` handle of a native system (the sweep then runs inside the HIP steer kernel) or
+        any Python callable is_feasible(x, u) -> bool (the planner then runs in callback mode, lqrrt_amd/callback.py)."""
         if not hasattr(is_feasible, '__call__'):
             raise ValueError("Expected is_feasible to be a function.")
-        system = plugin_system(is_feasible, "is_feasible")
-        if system.nstates != self.nstates or system.ncontrols != self.ncontrols:
+        system = native_system_of(is_feasible, "is_feasible")
+        if system is not None and (system.nstates != self.nstates or system.ncontrols != self.ncontrols):
             raise ValueError("The feasibility plugin is for a %d-state/%d-effort system." % (system.nstates, system.ncontrols))
         self.is_feasible = is_feasible
         self.system = system
 
     # -- batched evaluation (build-only additions; the reference calls is_feasible once per state) ------
     def feasible_batch(self, X, U=None):
-        """is_feasible for every row of X (and U, zeros when omitted) in one device launch."""
+        """is_feasible for every row of X (and U, zeros when omitted) in one device launch (a Python callable: row by row)."""
         X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        if self.system is None:
+            U = np.zeros((len(X), self.ncontrols)) if U is None else np.atleast_2d(np.asarray(U, dtype=np.float64))
+            return np.array([bool(self.is_feasible(x, u)) for x, u in zip(X, U)], dtype=bool)
         return self.system._engine().feasible_batch(X, None if U is None else np.atleast_2d(np.asarray(U, dtype=np.float64)))
 
     def first_infeasible(self, X, U=None):

@@ -7,38 +7,18 @@
 // (systems.hpp).  There is no CPU compute path: without a HIP device every compute entry
 // point returns LQRRT_E_NODEVICE.
 //
-// Environment switches read in this file (each once per process; NONE changes a result -- they are measurement and test
-// levers, and the parity tests run with several of them forced):
-//   switch                       default  read by                  effect
-//   LQRRT_FUSED_ROUNDS           1        fused_rounds_enabled     0: k_decide + re-steer + k_append instead of fused repair rounds
-//   LQRRT_STEER_WAVEFRONTS       auto     steer_wavefronts         2|3: wavefronts per rollout of the heading-torque boats (3: the chain rollout)
-//   LQRRT_STEER_TRIO_MAX         512      steer_wavefronts         launch sizes up to which 3 wavefronts are used
-//   LQRRT_CTL_CUT / _MIN / _LO / _HI  1.0 / 128 / 2 / 10  tune_wave   wave-size controller
-//   LQRRT_EXACT_WAVE_MAX         256      pick_wave                largest exact-mode wave the controller chooses (1024: as before round 3)
-//   LQRRT_MATRIX_MAX_W           256      lqrrt_wave_speculate     largest wave that keeps an in-wave cost matrix
-//   LQRRT_NN_WAVES / _NN_MIN_CHUNK    auto / 16  pick_chunks       scan decomposition (wavefronts per launch, nodes per chunk)
-//   LQRRT_TRI_CHUNK              32       tri_chunk                chunk of the in-wave (triangular) scan
-//   LQRRT_S_DENSE                unset    lqrrt_engine_set_dense_S generic dense-S scan even for a diagonal / banded S
-//   LQRRT_SHARD_TAIL             0.4      shard_tail_fraction      share of the worst-case edge payload a sharded rank's block reserves
-//   LQRRT_RCCL                   unset    rccl                     path of the librccl.so to resolve (default: the one in the process)
-//   LQRRT_POISON                 unset    dalloc                   fill every device allocation with 0xff (reads of unwritten memory show)
-//   LQRRT_TRACE                  unset    trace_on                 per-round trace on stderr (2: + every fused round's per-sample state, tools/round_trace.py)
-//   LQRRT_REFILL_AHEAD           1        refill_ahead             0: the sample pool's feasibility batch and filter only when the pool runs dry
-//   LQRRT_IGNORE_PATCH           1        speculate_impl           0: the ignore words a goal hit changed are uploaded, not passed as scan arguments
-//   LQRRT_HOSTPROF               unset    hostprof_on              host time per wave, printed when an engine is destroyed
-//   LQRRT_DARE_WAVEFRONTS        auto     steer_wavefronts         1|4: wavefronts per rollout of a Riccati system (auto: 4, they share the gain)
-//   LQRRT_NN_WG4                 0        launch_nn                1: two-level reduction of the tree scan's partial minima (four wavefronts per workgroup)
-//   LQRRT_SHARD_FOLD             1        gathered_wave_fuses      0: a gathered wave is unpacked by a launch of its own instead of by its first round
-//   LQRRT_CU_XCDS                unset    apply_env_cu_mask        k[:first]: engines run their native loops on a stream restricted to k of the 8 XCDs
-//   LQRRT_SECOND_CHOICE          1        second_choice_enabled    0: a sample whose wanted in-wave parent is being redone waits idly instead of steering from its best standing candidate
+// Environment switches: ONE table, csrc/switches.def (name, default, effect), read once per process through sw() (switches.hpp);
+// lqrrt_switches_describe() returns the listing.  NONE changes a result -- they are measurement and test levers.
 // (Python side: LQRRT_LIB -- load another build of this library, lqrrt_amd/_native.py; LQRRT_FORCE_SHARDED and
 //  LQRRT_BENCH_EVENTS_EVERY -- bench.py; LQRRT_TORQUE_VMIN -- default of the boats' torque_vmin, lqrrt_amd/systems.py, the one
-//  lever here that is a PARAMETER of the problem: it changes the arithmetic of the heading torque below that speed)
+//  lever that is a PARAMETER of the problem: it changes the arithmetic of the heading torque below that speed)
 // Compile-time (measurement builds only): -DSTEER_TIMING (device timestamps and placement counters in k_steer,
 // tools/steer_phases_bench.py), -DLQRRT_NO_KERNARG_TOUCH (k_steer without the touch of its argument block), -DABL_* (ablations,
 // tools/ablate_steer.py), -DLQRRT_USER_SYSTEM='"header"' (an out-of-tree problem as LQRRT_MODEL_USER, tools/build_user_system.py).
 #include "../../include/lqrrt_hip.h"
 #include "kernels.hpp"
+#include "generic.hpp"
+#include "switches.hpp"
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -95,6 +75,7 @@ static int fail(int code, const char* fmt, ...) {
 #include "engine_state.hpp"       // MT19937, struct lqrrt_engine
 #include "engine_launch.hpp"      // models.def dispatch, profiling events, launch wrappers of the scan and the steer
 #include "engine_geometry.hpp"    // hull / obstacle / occupancy / box-grid tables, Riccati weights
+#include "engine_generic.hpp"     // LQRRT_MODEL_GENERIC: node table + nearest-neighbour stage for problems whose plugins are host callables
 #include "engine_lifecycle.hpp"   // ABI: create / destroy / set_*
 #include "engine_tree.hpp"        // ABI: tree_*
 #include "engine_ops.hpp"         // ABI: batched operators

@@ -1,0 +1,179 @@
+// ABI: LQRRT_MODEL_GENERIC engines (no plugins compiled in: node table + nearest-neighbour stage only, generic.hpp), and the two
+// host-form entry points the callback planner drives them with: lqrrt_tree_append and lqrrt_nn_argmin_host.  Fragment of engine.hip.
+// --------------------------------------------------------------------------------------------
+
+#define NOT_GENERIC(e)                                                                                                  \
+    do {                                                                                                                \
+        if ((e) && (e)->generic)                                                                                        \
+            return fail(LQRRT_E_STATE, "%s: not available for LQRRT_MODEL_GENERIC (no dynamics / lqr / feasibility compiled in; " \
+                        "the caller evaluates its own plugins)", __func__);                                             \
+    } while (0)
+
+// the padded kernel width for the engine's n (generic.hpp: 7 or 12 states, trailing zeros change no bit)
+static int generic_width(const lqrrt_engine* e) { return e->n < 8 ? 7 : 12; }
+
+// partial minima of a generic scan: per sample, per 256-node workgroup, {eligible, overall}
+static size_t generic_blocks(const lqrrt_engine* e) { return ((size_t)e->cap + 255) / 256; }
+
+static int generic_create(lqrrt_engine* e, const lqrrt_system_desc* sys) {
+    // params[0] = number of angular states, params[1 ..] their indices (ascending, distinct)
+    const int n = sys->nstates;
+    if (n < 1 || n > LQRRT_MAX_STATES) return fail(LQRRT_E_ARG, "LQRRT_MODEL_GENERIC: nstates must be 1..%d, got %d", LQRRT_MAX_STATES, n);
+    if (sys->ncontrols < 0) return fail(LQRRT_E_ARG, "LQRRT_MODEL_GENERIC: bad ncontrols");
+    if (sys->n_params < 1) return fail(LQRRT_E_ARG, "LQRRT_MODEL_GENERIC: params[0] must hold the number of angular states");
+    const int nw = (int)sys->params[0];
+    if (nw < 0 || nw > n || sys->n_params < 1 + nw || (double)nw != sys->params[0]) return fail(LQRRT_E_ARG, "LQRRT_MODEL_GENERIC: bad number of angular states");
+    memset(&e->gsh, 0, sizeof e->gsh);
+    e->gsh.n = n; e->gsh.nw = nw;
+    for (int k = 0; k < nw; ++k) {
+        const int d = (int)sys->params[1 + k];
+        if (d < 0 || d >= n || (double)d != sys->params[1 + k] || (k > 0 && d <= e->gsh.wd[k - 1]))
+            return fail(LQRRT_E_ARG, "LQRRT_MODEL_GENERIC: angular state indices must be distinct, ascending and < nstates");
+        e->gsh.wd[k] = d;
+    }
+    e->generic = true;
+    e->n = n; e->m = sys->ncontrols; e->nw = nw;
+    e->tv.cap = e->cap;
+    TRY(dalloc(&e->tv.state, (size_t)n * e->cap));
+    TRY(dalloc(&e->tv.trig, (size_t)(2 * nw + 1) * e->cap));
+    TRY(dalloc(&e->tv.pID, (size_t)e->cap));
+    TRY(dalloc(&e->tv.ignore, (size_t)e->cap / 64 + 1));
+    HIPCHK(hipMemset(e->tv.ignore, 0, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1)));
+    TRY(dalloc(&e->d_pcost, generic_blocks(e) * 2 * e->maxW));
+    TRY(dalloc(&e->d_pidx, generic_blocks(e) * 2 * e->maxW));
+    if (hipHostMalloc((void**)&e->h_ign_pin, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1), hipHostMallocDefault) != hipSuccess)
+        return fail(LQRRT_E_HIP, "hipHostMalloc failed");
+    e->h_pid.reserve(e->cap);
+    e->h_ign.assign((size_t)e->cap / 64 + 1, 0ull);
+    return 0;
+}
+
+// mapped pinned result block of the host-form query {cost, id, sequence} (+ a device scratch for compiled-in models)
+static int query_buffers(lqrrt_engine* e) {
+    if (e->h_gres) return 0;
+    if (hipHostMalloc((void**)&e->h_gres, sizeof(double) * 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+        return fail(LQRRT_E_HIP, "hipHostMalloc failed");
+    HIPCHK(hipHostGetDevicePointer((void**)&e->h_gres_dev, e->h_gres, 0));
+    memset(e->h_gres, 0, sizeof(double) * 8);
+    return 0;
+}
+
+static GenericView generic_view(const lqrrt_engine* e, bool use_ignore) {
+    GenericView v;
+    v.state = e->tv.state; v.trig = e->tv.trig; v.ignore = use_ignore ? e->tv.ignore : nullptr;
+    v.errors = nullptr;
+    v.cap = e->cap; v.count = e->N;
+    return v;
+}
+
+static void generic_fill_query(const lqrrt_engine* e, const double* x, const double* S, GenericQuery* q) {
+    memset(q, 0, sizeof *q);
+    for (int d = 0; d < e->n; ++d) q->x[d] = x[d];
+    for (int k = 0; k < e->gsh.nw; ++k) lq_sincos(x[e->gsh.wd[k]], &q->trig[2 * k + 1], &q->trig[2 * k]);
+    if (S) {
+        const int w = generic_width(e);
+        for (int j = 0; j < e->n; ++j)
+            for (int k = 0; k < e->n; ++k) q->S[j * w + k] = S[j * e->n + k];
+    }
+}
+
+#define GENERIC_N(e, ...)                                                             \
+    do {                                                                              \
+        if (generic_width(e) == 7) { constexpr int GN = 7; __VA_ARGS__; }             \
+        else { constexpr int GN = 12; __VA_ARGS__; }                                  \
+    } while (0)
+
+// scan + reduce of W queries.  Host form: q != null (W = 1), the answer goes to e->h_gres.  Device form: xs [W][n], S_dev or null.
+static int generic_nn(lqrrt_engine* e, const GenericQuery* q, bool dense, const double* xs, const double* S_dev, int W, bool use_ignore,
+                      int32_t* id_dev, double* cost_dev, hipStream_t st, double seq, const double* errors_dev = nullptr) {
+    GenericView v = generic_view(e, use_ignore);
+    v.errors = errors_dev;
+    const int nb = (e->N + 255) / 256;
+    dim3 grid(nb, W);
+    GenericQuery q0;
+    if (!q) { memset(&q0, 0, sizeof q0); q = &q0; }
+    if (xs && S_dev) {                                       // device form with a dense S: re-laid to the kernel's row stride
+        const int w = generic_width(e);
+        if (!e->d_Sop) TRY(dalloc(&e->d_Sop, (size_t)MAXN * MAXN));
+        hipLaunchKernelGGL(k_generic_pad_S, dim3(1), dim3(256), 0, st, S_dev, e->n, w, e->d_Sop);
+        S_dev = e->d_Sop;
+    }
+#define GENERIC_SCAN(DENSE, BYVAL) \
+    GENERIC_N(e, hipLaunchKernelGGL((k_generic_scan<GN, DENSE, BYVAL>), grid, dim3(256), 0, st, v, e->gsh, *q, xs, S_dev, e->d_pcost, e->d_pidx))
+    if (xs) { if (dense) { GENERIC_SCAN(S_DENSE, false); } else { GENERIC_SCAN(S_IDENT, false); } }
+    else { if (dense) { GENERIC_SCAN(S_DENSE, true); } else { GENERIC_SCAN(S_IDENT, true); } }
+#undef GENERIC_SCAN
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_generic_reduce, dim3(W), dim3(64), 0, st, e->d_pcost, e->d_pidx, nb, id_dev, cost_dev,
+                       xs ? nullptr : e->h_gres_dev, seq);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int generic_costs(lqrrt_engine* e, const double* x_dev, const double* S_dev, double* cost_dev, hipStream_t st) {
+    const GenericView v = generic_view(e, false);
+    if (S_dev) {
+        if (!e->d_Sop) TRY(dalloc(&e->d_Sop, (size_t)MAXN * MAXN));
+        hipLaunchKernelGGL(k_generic_pad_S, dim3(1), dim3(256), 0, st, S_dev, e->n, generic_width(e), e->d_Sop);
+        S_dev = e->d_Sop;
+    }
+    dim3 grid((e->N + 255) / 256);
+    if (S_dev) {
+        GENERIC_N(e, hipLaunchKernelGGL((k_generic_costs<GN, S_DENSE>), grid, dim3(256), 0, st, v, e->gsh, x_dev, S_dev, cost_dev));
+    } else {
+        GENERIC_N(e, hipLaunchKernelGGL((k_generic_costs<GN, S_IDENT>), grid, dim3(256), 0, st, v, e->gsh, x_dev, S_dev, cost_dev));
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int generic_put_node(lqrrt_engine* e, int i, int parent, const double* state, hipStream_t st) {
+    GenericQuery q;
+    generic_fill_query(e, state, nullptr, &q);
+    hipLaunchKernelGGL(k_generic_append, dim3(1), dim3(64), 0, st, e->tv.state, e->tv.trig, e->tv.pID, e->cap, i, parent, e->gsh, q);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static void tree_bookkeeping_reset(lqrrt_engine* e) {
+    std::fill(e->h_ign.begin(), e->h_ign.end(), 0ull);
+    e->ign_dirty = false;
+    e->goal_hits = 0; e->best_end = -1; e->best_steps = -1;
+    e->mark_N = 0;
+    memset(&e->tot, 0, sizeof e->tot);
+}
+
+static int generic_reset(lqrrt_engine* e, const double* x0_host, hipStream_t st) {
+    HIPCHK(hipMemsetAsync(e->tv.ignore, 0, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1), st));
+    TRY(generic_put_node(e, 0, -1, x0_host, st));
+    e->N = 1;
+    e->h_pid.assign(1, -1);
+    e->h_elen.assign(1, 1);
+    tree_bookkeeping_reset(e);
+    e->tot.tree_size = 1;
+    return 0;
+}
+
+static int generic_load(lqrrt_engine* e, int count, const double* states, const int32_t* pID, const uint8_t* ignored, hipStream_t st) {
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<double> soa((size_t)count);
+    for (int d = 0; d < e->n; ++d) {
+        for (int i = 0; i < count; ++i) soa[i] = states[(size_t)i * e->n + d];
+        HIPCHK(hipMemcpy(e->tv.state + (size_t)d * e->cap, soa.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(e->tv.pID, pID, sizeof(int) * count, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_generic_trig, dim3((count + 255) / 256), dim3(256), 0, st, e->tv.state, e->tv.trig, e->cap, 0, count, e->gsh);
+    HIPCHK(hipGetLastError());
+    e->h_pid.assign(pID, pID + count);
+    e->h_elen.assign(count, 1);
+    tree_bookkeeping_reset(e);
+    if (ignored)
+        for (int i = 0; i < count; ++i)
+            if (ignored[i]) e->h_ign[i >> 6] |= 1ull << (i & 63);
+    HIPCHK(hipMemsetAsync(e->tv.ignore, 0, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1), st));
+    e->ign_hi = std::max(e->ign_hi, std::max(e->N, count));
+    e->ign_dirty = true; e->ign_patch_valid = false;
+    e->N = count;
+    e->tot.tree_size = count;
+    return 0;
+}

@@ -73,15 +73,19 @@ static int use_device(lqrrt_engine* e) {
     return 0;
 }
 
+// bytes of device memory handed out by dalloc on this thread since the counter was last cleared: lqrrt_engine_create and the
+// re-layout of the edge pools clear it, allocate, and book the sum on the engine (lqrrt_engine_footprint)
+static thread_local size_t g_dalloc_bytes = 0;
+
 template <class T>
 static int dalloc(T** p, size_t count) {
     *p = nullptr;
     if (count == 0) count = 1;
     HIPCHK(hipMalloc((void**)p, count * sizeof(T)));
+    g_dalloc_bytes += count * sizeof(T);
     // LQRRT_POISON=1 (test runs): fresh device memory is usually zero, recycled memory is not -- fill every allocation
     // with 0xff (NaNs, set bits, negative ints) so that a read of something never written shows up at once
-    static const bool poison = getenv("LQRRT_POISON") != nullptr;
-    if (poison) HIPCHK(hipMemset(*p, 0xff, count * sizeof(T)));
+    if (sw().poison) HIPCHK(hipMemset(*p, 0xff, count * sizeof(T)));
     return 0;
 }
 
@@ -155,26 +159,17 @@ static void prof_end(lqrrt_engine* e, hipStream_t, EvPair* ev, int kind, double 
 // --------------------------------------------------------------------------------------------
 // kernel launch wrappers
 
-static bool trace_on() {
-    static const bool on = getenv("LQRRT_TRACE") != nullptr;     // read once: getenv walks the environment
-    return on;
-}
+static bool trace_on() { return sw().trace >= 1; }
 // LQRRT_TRACE=2: every fused round also dumps its samples' state (blocking copies: a debugging aid, tools/round_trace.py)
-static bool trace_rounds_on() {
-    static const bool on = [] { const char* v = getenv("LQRRT_TRACE"); return v && atoi(v) >= 2; }();
-    return on;
-}
+static bool trace_rounds_on() { return sw().trace >= 2; }
 
 // LQRRT_HOSTPROF=1: where the host's time goes per wave (printed when the engine is destroyed)
 struct HostProf { double wait = 0, book = 0, flush = 0, nn = 0, steer = 0, other = 0; long waves = 0; };
 static HostProf g_hp;
-static bool hostprof_on() { static const bool on = getenv("LQRRT_HOSTPROF") != nullptr; return on; }
+static bool hostprof_on() { return sw().hostprof; }
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-static int tri_chunk() {
-    static const int c = getenv("LQRRT_TRI_CHUNK") ? atoi(getenv("LQRRT_TRI_CHUNK")) : 32;
-    return c;
-}
+static int tri_chunk() { return sw().tri_chunk; }
 
 static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
     // One wavefront per (64-sample group, node chunk).  The scan hides its scalar-load latency behind the other
@@ -182,8 +177,7 @@ static void pick_chunks(int count, int W, int* chunk, int* n_chunks) {
     // chunks are multiples of 8 nodes (aligned 4-node scalar loads, whole quads).
     const int groups = (W + 63) / 64;
     // (small waves: 2048 -- as fast as 4096 there, and half the partial minima to store and reduce)
-    static const int target_env = getenv("LQRRT_NN_WAVES") ? atoi(getenv("LQRRT_NN_WAVES")) : 0;
-    static const int min_chunk = getenv("LQRRT_NN_MIN_CHUNK") ? atoi(getenv("LQRRT_NN_MIN_CHUNK")) : 16;
+    const int target_env = sw().nn_waves, min_chunk = sw().nn_min_chunk;
     const int target_waves = target_env > 0 ? target_env : (groups >= 8 ? 4096 : 2048);
     int want = target_waves / (groups > 0 ? groups : 1);
     want = std::max(1, std::min(want, (int)lqrrt_engine::MAXCH));
@@ -222,7 +216,7 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     if (tri) { chunk = tri_chunk(); n_chunks = (nv.count + chunk - 1) / chunk; }   // in-wave pass: the reduction is fused into k_decide
     else pick_chunks(nv.count, W, &chunk, &n_chunks);
     // two-level reduction (kernels.hpp k_nn_scan WPB = 4): four wavefronts per workgroup, one partial per four chunks
-    static const int wg4_env = getenv("LQRRT_NN_WG4") ? atoi(getenv("LQRRT_NN_WG4")) : -1;
+    const int wg4_env = sw().nn_wg4;
     const int sm_pre = Spers ? -1 : (!(Sd ? Sd : e->d_S) ? S_IDENT : (Sd ? S_DENSE : e->smode));
     const bool wg4_has = !tri && !(patch && patch->n > 0) && !Spers &&
                          (sm_pre == S_IDENT || sm_pre == S_DENSE || (sm_pre == S_BAND2 && e->model == LQRRT_MODEL_DOUBLE_INTEGRATOR));
@@ -241,20 +235,20 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     if (profile) prof_begin(e, st, &ev, 0);
 #define NN_LAUNCH(DENSE, TRI)                                                                            \
     DISPATCH(e, hipExtLaunchKernelGGL((k_nn_scan<S, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
-                                      e->d_pcost, e->d_pidx, ps_c, ps_t, pt))
+                                      (Part*)e->d_pcost, e->d_pidx, ps_c, ps_t, pt))
 #define NN_LAUNCH4(DENSE)                                                                                \
     DISPATCH(e, hipExtLaunchKernelGGL((k_nn_scan<S, DENSE, false, false, 4>), grid, dim3(256), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
-                                      e->d_pcost, e->d_pidx, ps_c, ps_t, pt))
+                                      (Part*)e->d_pcost, e->d_pidx, ps_c, ps_t, pt))
     // (the instantiation that looks at the patch is a launch of its own: the scan's inner loop lives at the SGPR limit, and the
     //  plain one must not pay for what two launches in three do not need)
 #define NN_LAUNCH_PATCH(DENSE)                                                                          \
     DISPATCH(e, hipExtLaunchKernelGGL((k_nn_scan<S, DENSE, false, true>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
-                                      e->d_pcost, e->d_pidx, ps_c, ps_t, pt))
+                                      (Part*)e->d_pcost, e->d_pidx, ps_c, ps_t, pt))
     // structured forms of the engine's own S are instantiated only for the systems that have them
     const int sm = !S_use ? S_IDENT : (Sd ? S_DENSE : e->smode);
 #define NN_ONE(SYS, DENSE, TRI)                                                                            \
     hipExtLaunchKernelGGL((k_nn_scan<SYS, DENSE, TRI>), grid, dim3(64), 0, st, ev.a, ev.b, 0, nv, xs, xtrig, W, S_use, chunk, \
-                          e->d_pcost, e->d_pidx, ps_c, ps_t, pt)
+                          (Part*)e->d_pcost, e->d_pidx, ps_c, ps_t, pt)
     if (pt.n > 0 && (tri || Spers || Sd || !scan_takes_patch(e))) return fail(LQRRT_E_STATE, "this scan variant takes no ignore patch");
     if (Spers) {
         if (!e->riccati) return fail(LQRRT_E_ARG, "per-sample S is only instantiated for Riccati systems");
@@ -262,7 +256,7 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     } else if (sm == S_BAND2 && e->model == LQRRT_MODEL_DOUBLE_INTEGRATOR) {
         if (tri) NN_ONE(DoubleIntegratorT<6>, S_BAND2, true);
         else if (wg4) hipExtLaunchKernelGGL((k_nn_scan<DoubleIntegratorT<6>, S_BAND2, false, false, 4>), grid, dim3(256), 0, st, ev.a, ev.b, 0,
-                                            nv, xs, xtrig, W, S_use, chunk, e->d_pcost, e->d_pidx, ps_c, ps_t, pt);
+                                            nv, xs, xtrig, W, S_use, chunk, (Part*)e->d_pcost, e->d_pidx, ps_c, ps_t, pt);
         else NN_ONE(DoubleIntegratorT<6>, S_BAND2, false);
     } else if (sm == S_DIAG && e->model == LQRRT_MODEL_ROS_BOAT) {
         if (tri) NN_ONE(RosBoat, S_DIAG, true); else NN_ONE(RosBoat, S_DIAG, false);
@@ -282,7 +276,7 @@ static int launch_nn(lqrrt_engine* e, const NodeView& nv, const double* xs, int 
     // fallback of planner.py:241,245 is decided later, over the candidates of all ranges (k_steer prologue)
     if (range_candidates) nvr.ignore = nullptr;
 #define RED_LAUNCH(DENSE)                                                                                 \
-    DISPATCH(e, hipLaunchKernelGGL((k_nn_reduce<S, DENSE>), dim3(W), dim3(64), 0, st, e->d_pcost, e->d_pidx, W, n_chunks, nvr, \
+    DISPATCH(e, hipLaunchKernelGGL((k_nn_reduce<S, DENSE>), dim3(W), dim3(64), 0, st, (const Part*)e->d_pcost, W, n_chunks, nvr, \
                                    xs, S_use, s_stride, out_id, out_cost, rec, e->L.R, e->L.off_cost, e->L.off_parent,     \
                                    wave_lo >= 0 ? e->d_par_done + wave_lo : nullptr,                                      \
                                    wave_lo >= 0 ? e->d_changed + wave_lo : nullptr,                                       \
@@ -303,14 +297,14 @@ template <class S> static int steer_wavefronts(int count) {
         // wavefront at n = 4 (the matrix passes fit its lanes and the barriers only cost: -10 %); since round 5 the G and H updates
         // and the convergence test of an iteration run in different wavefronts, which pays at n = 4 too (pendulum_lqr +4.5 %,
         // boat_novice_lqr +10 %, profiles/r05_dare_wavefronts.txt).  Same bits either way (tests/test_switches_gpu.py).
-        static const int dw = getenv("LQRRT_DARE_WAVEFRONTS") ? atoi(getenv("LQRRT_DARE_WAVEFRONTS")) : 0;
+        const int dw = sw().dare_wavefronts;
         (void)count;
         return dw == 1 ? 1 : 4;
     }
     if (steer_wavefronts_max<S>() <= 2) return steer_wavefronts_max<S>();
-    static const int forced = getenv("LQRRT_STEER_WAVEFRONTS") ? atoi(getenv("LQRRT_STEER_WAVEFRONTS")) : 0;
+    const int forced = sw().steer_wavefronts;
     if (forced >= 2 && forced <= 3) return forced;
-    static const int trio_max = getenv("LQRRT_STEER_TRIO_MAX") ? atoi(getenv("LQRRT_STEER_TRIO_MAX")) : 512;
+    const int trio_max = sw().steer_trio_max;
     return count <= trio_max ? 3 : 2;
 }
 template <class S, bool DENSE, int NWF>

@@ -41,6 +41,8 @@ static void free_all(lqrrt_engine* e) {
     if (e->h_summary) (void)hipHostFree(e->h_summary);
     if (e->h_rank) (void)hipHostFree(e->h_rank);
     if (e->h_round) (void)hipHostFree(e->h_round);
+    if (e->h_gres) (void)hipHostFree(e->h_gres);
+    if (e->d_q) (void)hipFree(e->d_q);
 }
 
 static int alloc_wave(lqrrt_engine* e) {
@@ -49,6 +51,7 @@ static int alloc_wave(lqrrt_engine* e) {
     for (void* p : old)
         if (p) (void)hipFree(p);
     e->tv.xedge = e->tv.uedge = nullptr; e->d_rec = nullptr;
+    const size_t before = g_dalloc_bytes;
     e->L = make_layout(e->n, e->m, e->nw, e->H);
     e->tv.H = e->H;
     TRY(dalloc(&e->tv.xedge, (size_t)e->cap * e->H * e->n));
@@ -58,6 +61,7 @@ static int alloc_wave(lqrrt_engine* e) {
     //  max_wave = 1 faulted once the allocator placed the buffer at the end of a mapping (round 4, tools/fuzz_parity.py 60 12 33))
     TRY(dalloc(&e->d_rec, (size_t)(e->maxW + 4) * e->L.R));
     HIPCHK(hipMemset(e->d_rec, 0, (size_t)(e->maxW + 4) * e->L.R * sizeof(double)));
+    e->bytes_wave = g_dalloc_bytes - before;
     return 0;
 }
 
@@ -80,6 +84,25 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     if (!sys || !out) return fail(LQRRT_E_ARG, "null argument");
     *out = nullptr;
     int n, m, nw;
+    if (sys->model == LQRRT_MODEL_GENERIC) {
+        // no plugins compiled in: the node table and the nearest-neighbour stage only (engine_generic.hpp)
+        if (capacity < 2 || max_wave < 1 || max_wave > 4096) return fail(LQRRT_E_ARG, "capacity must be >= 2 and 1 <= max_wave <= 4096");
+        if (sys->n_params < 0 || sys->n_params > LQRRT_MAX_PARAMS) return fail(LQRRT_E_ARG, "bad n_params");
+        if (lqrrt_device_count() <= device || device < 0)
+            return fail(LQRRT_E_NODEVICE, "HIP device %d not available (found %d)", device, lqrrt_device_count());
+        HIPCHK(hipSetDevice(device));
+        lqrrt_engine* g = new lqrrt_engine();
+        g_dalloc_bytes = 0;
+        g->device = device; g->model = sys->model;
+        g->cap = ((capacity + 63) / 64) * 64; g->maxW = max_wave; g->H = 1;
+        int grc = generic_create(g, sys);
+        if (!grc) grc = query_buffers(g);
+        if (grc) { free_all(g); delete g; return grc; }
+        g->bytes_fixed = g_dalloc_bytes;
+        g->bytes_pinned = sizeof(unsigned long long) * ((size_t)g->cap / 64 + 1) + sizeof(double) * 8;
+        *out = g;
+        return 0;
+    }
     if (!model_dims(sys->model, &n, &m, &nw)) return fail(LQRRT_E_ARG, "unknown model %d", sys->model);
     if (sys->nstates != n || sys->ncontrols != m)
         return fail(LQRRT_E_ARG, "model %d expects nstates=%d ncontrols=%d, got %d/%d", sys->model, n, m,
@@ -95,6 +118,7 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     if (prop.warpSize != 64) return fail(LQRRT_E_NODEVICE, "wavefront size %d != 64 (gfx950 expected)", prop.warpSize);
 
     lqrrt_engine* e = new lqrrt_engine();
+    g_dalloc_bytes = 0;
     e->device = device; e->model = sys->model; e->n = n; e->m = m; e->nw = nw;
     e->cap = ((capacity + 63) / 64) * 64; e->maxW = max_wave; e->H = 1;
     memset(&e->P, 0, sizeof e->P);
@@ -119,8 +143,8 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
     if (!rc) rc = dalloc(&e->tv.ignore, (size_t)e->cap / 64 + 1);
     if (!rc && hipMemset(e->tv.ignore, 0, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1)) != hipSuccess) rc = fail(LQRRT_E_HIP, "hipMemset failed");
     const size_t pw = (size_t)lqrrt_engine::MAXCH * e->maxW;
-    if (!rc) rc = dalloc(&e->d_pcost, pw);
-    if (!rc) rc = dalloc(&e->d_pidx, pw);
+    if (!rc) rc = dalloc(&e->d_pcost, 2 * pw);               // the tree scans' partial minima: [pw] 16-byte words (kernels.hpp Part)
+    if (!rc) rc = dalloc(&e->d_pidx, pw);                    // (in-wave scans of waves > 256 samples: costs in d_pcost, ids here)
     if (!rc) rc = dalloc(&e->d_M, (size_t)lqrrt_engine::MATRIX_MAX_W * lqrrt_engine::MATRIX_MAX_W);
     if (!rc) rc = dalloc(&e->d_par_done, (size_t)e->maxW);
     if (!rc) rc = dalloc(&e->d_par_want, (size_t)e->maxW);
@@ -156,6 +180,9 @@ extern "C" int lqrrt_engine_create(const lqrrt_system_desc* sys, int device, int
         rc = fail(LQRRT_E_HIP, "hipHostMalloc failed");
     if (!rc) rc = alloc_wave(e);
     if (rc) { free_all(e); delete e; return rc; }
+    e->bytes_fixed = g_dalloc_bytes - e->bytes_wave;
+    e->bytes_pinned = sizeof(int) * (4 + 3 * (size_t)e->maxW) + sizeof(int) * (size_t)e->maxW + sizeof(int) * (8 + 3 * (size_t)e->maxW) +
+                      sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1);
     e->h_pid.reserve(e->cap); e->h_elen.reserve(e->cap);
     e->h_ign.assign((size_t)e->cap / 64 + 1, 0ull);
     for (int i = 0; i < 624; ++i) e->mt_gen.key[i] = 0;
@@ -194,7 +221,7 @@ extern "C" int lqrrt_engine_set_cu_mask(lqrrt_engine* e, const uint32_t* mask, i
 // LQRRT_CU_XCDS=k[:first]: every engine created in this process gets a stream on k of the 8 XCDs (all their CUs), engine number i
 // on XCDs (first + i * k) mod 8 ... -- the A/B lever of profiles/r05_cu_mask.txt; unset = the caller's stream, the whole chip.
 static int apply_env_cu_mask(lqrrt_engine* e, int n_cus) {
-    const char* v = getenv("LQRRT_CU_XCDS");
+    const char* v = sw().cu_xcds;
     if (!v || !*v) return 0;
     const int k = atoi(v);
     if (k < 1 || k >= 8) return 0;
@@ -209,6 +236,20 @@ static int apply_env_cu_mask(lqrrt_engine* e, int n_cus) {
         if (mine) mask[(size_t)b >> 5] |= 1u << (b & 31);
     }
     return lqrrt_engine_set_cu_mask(e, mask.data(), (int)mask.size());
+}
+
+// What this engine holds: device_bytes = HBM allocated for it so far (node pools sized by `capacity`: per node 8 (n + 2 nw + 1 + nw + 1 + m n)
+// + 8 bytes + the edge pools 8 H (n + m); wave records, partial minima, in-wave matrices sized by max_wave; geometry), pinned_bytes =
+// page-locked host memory (round summaries, ignore-set staging).  Lazily allocated pieces (sample pools, all-gather blocks) appear
+// once they exist.  No counterpart in the reference (its tree is Python lists).
+extern "C" int lqrrt_engine_footprint(lqrrt_engine* e, int64_t* device_bytes, int64_t* pinned_bytes) {
+    if (!e) return fail(LQRRT_E_ARG, "null engine");
+    size_t lazy = 0;
+    lazy += (size_t)e->d_pool_cap * e->n * sizeof(double) + (size_t)e->cand_cap * (e->n * sizeof(double) + 1);
+    lazy += e->blk_cap * sizeof(double);
+    if (device_bytes) *device_bytes = (int64_t)(e->bytes_fixed + e->bytes_wave + lazy);
+    if (pinned_bytes) *pinned_bytes = (int64_t)e->bytes_pinned;
+    return 0;
 }
 
 extern "C" int lqrrt_engine_destroy(lqrrt_engine* e) {
@@ -235,6 +276,7 @@ extern "C" int lqrrt_engine_destroy(lqrrt_engine* e) {
 }
 
 extern "C" int lqrrt_engine_set_dense_S(lqrrt_engine* e, const double* S_host) {
+    NOT_GENERIC(e);
     // constant dense cost-to-go matrix of the system (lqr(x,u)[0]); NULL restores identity
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     TRY(use_device(e));
@@ -252,12 +294,13 @@ extern "C" int lqrrt_engine_set_dense_S(lqrrt_engine* e, const double* S_host) {
                 if (nz && band2 && (j % h) != (k % h)) band2 = false;
             }
         e->smode = diag ? S_DIAG : (band2 ? S_BAND2 : S_DENSE);
-        if (getenv("LQRRT_S_DENSE")) e->smode = S_DENSE;
+        if (sw().s_dense) e->smode = S_DENSE;
     }
     return 0;
 }
 
 extern "C" int lqrrt_engine_set_resolution(lqrrt_engine* e, const lqrrt_resolution* r) {
+    NOT_GENERIC(e);
     if (!e || !r) return fail(LQRRT_E_ARG, "null argument");
     if (r->horizon_iters < 1 || r->horizon_iters > 4096) return fail(LQRRT_E_ARG, "horizon_iters out of range");
     if (!(r->dt > 0)) return fail(LQRRT_E_ARG, "dt must be positive");
@@ -293,7 +336,7 @@ extern "C" int lqrrt_engine_set_resolution(lqrrt_engine* e, const lqrrt_resoluti
     return 0;
 }
 
-extern "C" int lqrrt_engine_horizon_iters(lqrrt_engine* e) { return e ? e->h_iters : LQRRT_E_ARG; }
+extern "C" int lqrrt_engine_horizon_iters(lqrrt_engine* e) { NOT_GENERIC(e); return e ? e->h_iters : LQRRT_E_ARG; }
 
 // Queued (not yet committed) samples depend on the goal, the sampler settings and the feasibility of the world:
 // drop them and rewind the generator to the first uncommitted candidate row.
@@ -308,6 +351,7 @@ static void invalidate_samples(lqrrt_engine* e) {
 }
 
 extern "C" int lqrrt_engine_set_sampler(lqrrt_engine* e, const lqrrt_sampler_desc* s) {
+    NOT_GENERIC(e);
     if (!e || !s) return fail(LQRRT_E_ARG, "null argument");
     if (s->tries_limit < 1) return fail(LQRRT_E_ARG, "tries_limit must be >= 1");
     e->smp = *s;
@@ -330,6 +374,7 @@ extern "C" int lqrrt_engine_set_sampler(lqrrt_engine* e, const lqrrt_sampler_des
 }
 
 extern "C" int lqrrt_engine_set_geometry(lqrrt_engine* e, const lqrrt_system_desc* sys, void* stream) {
+    NOT_GENERIC(e);
     if (!e || !sys) return fail(LQRRT_E_ARG, "null argument");
     if (sys->model != e->model || sys->nstates != e->n || sys->ncontrols != e->m)
         return fail(LQRRT_E_ARG, "set_geometry cannot change the model (engine: model %d, %d states)", e->model, e->n);
@@ -350,6 +395,7 @@ extern "C" int lqrrt_engine_set_geometry(lqrrt_engine* e, const lqrrt_system_des
 }
 
 extern "C" int lqrrt_engine_set_wave_mode(lqrrt_engine* e, int mode) {
+    NOT_GENERIC(e);
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     if (mode != LQRRT_WAVE_EXACT && mode != LQRRT_WAVE_SYNCHRONOUS) return fail(LQRRT_E_ARG, "unknown wave mode %d", mode);
     e->sync_mode = mode == LQRRT_WAVE_SYNCHRONOUS;
@@ -357,6 +403,7 @@ extern "C" int lqrrt_engine_set_wave_mode(lqrrt_engine* e, int mode) {
 }
 
 extern "C" int lqrrt_engine_set_mt19937(lqrrt_engine* e, const uint32_t* key624, int pos) {
+    NOT_GENERIC(e);
     if (!e || !key624) return fail(LQRRT_E_ARG, "null argument");
     if (pos < 0 || pos > 624) return fail(LQRRT_E_ARG, "bad MT19937 position");
     memcpy(e->mt_gen.key, key624, sizeof(uint32_t) * 624);
@@ -371,6 +418,7 @@ extern "C" int lqrrt_engine_set_mt19937(lqrrt_engine* e, const uint32_t* key624,
 }
 
 extern "C" int lqrrt_engine_get_mt19937(lqrrt_engine* e, uint32_t* key624, int* pos) {
+    NOT_GENERIC(e);
     if (!e || !key624 || !pos) return fail(LQRRT_E_ARG, "null argument");
     MT g = e->mt_base;
     for (int64_t i = 0; i < (e->committed_row - e->base_row) * (int64_t)(e->n + 1); ++i) (void)g.next_double();

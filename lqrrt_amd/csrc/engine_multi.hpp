@@ -35,7 +35,7 @@ static void multi_build_proto(lqrrt_engine* e, EngineProto& p) {
     memset(&p, 0, sizeof p);
     p.P = e->P; p.g = e->geo; p.r = e->res; p.tv = e->tv; p.rec = e->d_rec; p.L = e->L;
     SteerFuse& f = p.f;
-    f.pcost = e->d_pcost; f.pidx = e->d_pidx;
+    f.part = (const Part*)e->d_pcost;
     f.nv = tree_view(e, true);
     f.nv.count = 0;                                               // (per launch: ScanDyn / SteerDyn::N)
     f.Sd = e->d_S; f.s_stride = 0;
@@ -43,7 +43,6 @@ static void multi_build_proto(lqrrt_engine* e, EngineProto& p) {
     f.M = e->d_M;
     f.lf0 = e->d_lf[0]; f.round_ctl = e->d_rctl;
     RoundArgs& ra = p.ra;
-    ra.second_choice = second_choice_enabled() ? 1 : 0;
     ra.M[0] = e->d_M; ra.M[1] = e->d_M2;
     ra.lf[0] = e->d_lf[0]; ra.lf[1] = e->d_lf[1];
     ra.par[0] = e->d_par_done; ra.par[1] = e->d_par2;
@@ -173,7 +172,6 @@ static int multi_run_group(lqrrt_engine** engines, int n, int wave, int64_t max_
     const bool dense = e0->d_S != nullptr;
     std::vector<int64_t> spec0((size_t)n);
     for (int i = 0; i < n; ++i) spec0[i] = engines[i]->tot.speculated;
-    static const bool patch_on = [] { const char* v = getenv("LQRRT_IGNORE_PATCH"); return !(v && atoi(v) == 0); }();
     // LQRRT_MULTI_NWF=1|2|3: wavefronts per rollout of the heading-torque boats in a multi-engine launch; LQRRT_MULTI_ORDER=0: engines in
     // call order inside the launches instead of wave-beginners first (both: measurement levers, profiles/r05_multi.txt)
     // Default: three wavefronts per rollout (the chain rollout, the fastest single rollout) while the call's engines leave the chip
@@ -181,9 +179,9 @@ static int multi_run_group(lqrrt_engine** engines, int n, int wave, int64_t max_
     // wavefront SLOTS before it runs out of anything else, and a two-wavefront rollout takes a third fewer: 32 trees 4.9 -> 5.6e6
     // attempts/s, 64 trees 5.3 -> 6.6e6, 16 trees 4.0e6 either way; one wavefront (the packed step, 384 registers: one wavefront
     // per SIMD) is slower than two at every size (profiles/r05_multi.txt section 4).  Same trees whatever the form.
-    static const int multi_nwf_env = getenv("LQRRT_MULTI_NWF") ? atoi(getenv("LQRRT_MULTI_NWF")) : 0;
+    const int multi_nwf_env = sw().multi_nwf;
     const int multi_nwf = multi_nwf_env ? multi_nwf_env : (n_call >= 24 ? 2 : 3);
-    static const bool heavy_first = !(getenv("LQRRT_MULTI_ORDER") && atoi(getenv("LQRRT_MULTI_ORDER")) == 0);
+    const bool heavy_first = sw().multi_heavy_first;
     int active = n, bg = 0;
     double hp_build = 0, hp_launch = 0, hp_wait = 0, hp_commit = 0;       // LQRRT_HOSTPROF: where the host's time goes per tick
     long hp_ticks = 0, hp_scans = 0, hp_blocks = 0;
@@ -240,7 +238,7 @@ static int multi_run_group(lqrrt_engine** engines, int n, int wave, int64_t max_
                 s.W = W;
                 TRY(ensure_samples(e, e->cursor + W, st));
                 // the ignore words of the last goal hit: in the arguments of this tick's scan if a slot is left, uploaded otherwise
-                if (patch_on && e->ign_dirty && e->ign_patch_valid && !e->ign_patch.empty() && scan_takes_patch(e) && patches < MULTI_PATCHES) {
+                if (e->ign_dirty && e->ign_patch_valid && !e->ign_patch.empty() && scan_takes_patch(e) && patches < MULTI_PATCHES) {
                     IgnPatch& pp = sa.patch[patches];
                     memset(&pp, 0, sizeof pp);
                     pp.n = (int)e->ign_patch.size();
@@ -333,6 +331,7 @@ static int multi_run_group(lqrrt_engine** engines, int n, int wave, int64_t max_
                 if (hostprof_on()) hp_commit += now_us() - hc0;
                 s.acc.attempts += s.ws.attempts; s.acc.accepted += s.ws.accepted; s.acc.waves += 1;
                 s.acc.fix_rounds += s.ws.fix_rounds; s.acc.resteers += s.ws.resteers; s.acc.goal_hits += s.ws.goal_hits;
+                s.acc.chain_slots += s.ws.chain_slots;
                 s.state = 0; s.waiting = false;
                 if (stop_on_goal && s.ws.goal_hits) { s.acc.stop_reason = LQRRT_STOP_GOAL; s.state = 2; --active; }
                 continue;
@@ -367,6 +366,7 @@ extern "C" int lqrrt_engine_extend_multi(lqrrt_engine** engines, int n, int wave
     for (int i = 0; i < n; ++i) {
         lqrrt_engine* e = engines[i];
         if (!e) return fail(LQRRT_E_ARG, "null engine");
+        NOT_GENERIC(e);
         for (int j = 0; j < i; ++j)
             if (engines[j] == e) return fail(LQRRT_E_ARG, "engine %d appears twice", i);
         if (e->device != e0->device || e->model != e0->model || e->H != e0->H || (e->d_S != nullptr) != (e0->d_S != nullptr))
@@ -380,12 +380,16 @@ extern "C" int lqrrt_engine_extend_multi(lqrrt_engine** engines, int n, int wave
     // that begins a wave (the longest kind); two groups on two host threads and two streams overlap their launches on the GPU:
     // 16 trees 3.3e6 -> 4.0e6 attempts/s, 32 trees 4.0e6 -> 4.9e6; more threads are slower again (4: 2.8e6 / 3.9e6), 64 trees reach
     // 5.3e6 either way (profiles/r05_multi.txt).  LQRRT_MULTI_THREADS overrides; a group holds at most MULTI_MAX engines.
-    static const int threads_env = getenv("LQRRT_MULTI_THREADS") ? atoi(getenv("LQRRT_MULTI_THREADS")) : 0;
+    const int threads_env = sw().multi_threads;
     int G = threads_env > 0 ? threads_env : (n >= 4 ? 2 : 1);
     G = std::max(G, (n + MULTI_MAX - 1) / MULTI_MAX);
     G = std::min(G, n);
     TRY(use_device(e0));
-    if (G == 1) return multi_run_group(engines, n, wave, max_attempts, node_limit, until_size, pruning, stop_on_goal, out, (hipStream_t)stream, n);
+    if (G == 1) {
+        const int rc1 = multi_run_group(engines, n, wave, max_attempts, node_limit, until_size, pruning, stop_on_goal, out, (hipStream_t)stream, n);
+        if (rc1) { const std::string keep = g_err; (void)hipStreamSynchronize((hipStream_t)stream); g_err = keep; }   // nothing in flight after an error
+        return rc1;
+    }
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));           // what the caller queued is finished before the groups' own streams start
     std::vector<std::vector<lqrrt_engine*>> grp((size_t)G);
     std::vector<std::vector<int>> idx((size_t)G);
@@ -403,8 +407,11 @@ extern "C" int lqrrt_engine_extend_multi(lqrrt_engine** engines, int n, int wave
         if (!rc) rc = multi_run_group(grp[(size_t)g].data(), (int)grp[(size_t)g].size(), wave, max_attempts, node_limit, until_size, pruning,
                                       stop_on_goal, outs[(size_t)g].data(), lead->multi_stream, n);
         if (!rc && hipStreamSynchronize(lead->multi_stream) != hipSuccess) rc = fail(LQRRT_E_HIP, "a group's stream failed");
-        rcs[(size_t)g] = rc;
         if (rc) errs[(size_t)g] = g_err;                          // (the error text is per thread: hand it to the caller's)
+        // a group that failed mid-loop may still have launches in flight on its private stream: nothing may outlive the call
+        // (the caller resets the engines next, on another stream)
+        if (rc && lead->multi_stream) (void)hipStreamSynchronize(lead->multi_stream);
+        rcs[(size_t)g] = rc;
     };
     multi_pool().run(G, work);                                    // group 0 on this thread, the others on the pool's (persistent) threads
     for (int g = 0; g < G; ++g)

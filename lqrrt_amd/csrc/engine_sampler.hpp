@@ -52,8 +52,7 @@ static void pregenerate_candidates(lqrrt_engine* e, int rows) {
 // been generated ahead it is copied to pinned memory (a slice per call), tested on a stream of its own while the rounds go on,
 // and filtered (a slice per call) -- the same rows, flags and tries rule as the refill's own loop, which then only appends.
 static int refill_ahead(lqrrt_engine* e) {
-    static const bool on = [] { const char* v = getenv("LQRRT_REFILL_AHEAD"); return !(v && atoi(v) == 0); }();
-    if (!on || e->explicit_samples || !e->has_sampler || !e->has_goal) return 0;
+    if (e->explicit_samples || !e->has_sampler || !e->has_goal) return 0;
     const int CH = SAMPLER_BLOCK, n = e->n, SLICE = 2048;
     if (e->rf_stage == 0) {
         if (e->pregen_rows < CH) return 0;
@@ -219,6 +218,7 @@ static int ensure_samples(lqrrt_engine* e, int64_t need_end, hipStream_t st) {
 }
 
 extern "C" int lqrrt_engine_push_samples(lqrrt_engine* e, const double* xs_host, int count) {
+    NOT_GENERIC(e);
     // explicit sample stream (a user xrand_gen function, planner.py:213-216): appended after what is queued
     if (!e || (count > 0 && !xs_host) || count < 0) return fail(LQRRT_E_ARG, "bad argument");
     if (!e->explicit_samples) {
@@ -240,6 +240,7 @@ extern "C" int lqrrt_engine_push_samples(lqrrt_engine* e, const double* xs_host,
 }
 
 extern "C" int lqrrt_engine_queued_samples(lqrrt_engine* e) {
+    NOT_GENERIC(e);
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     return (int)(e->pool_base + (int64_t)e->pool_rows_end.size() - e->cursor);
 }

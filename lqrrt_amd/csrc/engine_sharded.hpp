@@ -27,7 +27,7 @@ static RcclApi* rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        if (const char* forced = getenv("LQRRT_RCCL")) {
+        if (const char* forced = sw().rccl) {
             api.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
             if (!api.lib) { api.error = std::string("LQRRT_RCCL: cannot load ") + forced; return; }
         }
@@ -139,7 +139,7 @@ static int shard_buffers(lqrrt_engine* e, size_t doubles) {
 static double shard_tail_fraction() {
     // share of a rank's worst-case edge payload (per * H * (n + m) doubles) that its block reserves; the headline workload
     // fills ~16 % (27 % of the samples add a node, their edges average 60 % of the horizon); a full tail only costs re-steers
-    static const double f = getenv("LQRRT_SHARD_TAIL") ? std::min(1.0, std::max(0.0, atof(getenv("LQRRT_SHARD_TAIL")))) : 0.4;
+    const double f = std::min(1.0, std::max(0.0, sw().shard_tail));
     return f;
 }
 
@@ -150,8 +150,7 @@ static double shard_tail_fraction() {
 // Will the commit of a gathered wave of W samples run the fused rounds (engine_wave.hpp commit_impl, same predicate)?  Then the
 // unpack launch is not needed: round 0 takes every sample out of the blocks itself (kernels.hpp RoundArgs::gblk).
 static bool gathered_wave_fuses(const lqrrt_engine* e, int W) {
-    static const bool fold = [] { const char* v = getenv("LQRRT_SHARD_FOLD"); return !(v && atoi(v) == 0); }();
-    return fold && e->wave_matrix && !e->sync_mode && fused_rounds_enabled() && (int64_t)e->N + W <= (int64_t)e->cap && W <= 256;
+    return e->wave_matrix && !e->sync_mode && fused_rounds_enabled() && (int64_t)e->N + W <= (int64_t)e->cap && W <= 256;
 }
 
 static int allgather_nodes(lqrrt_engine* e, lqrrt_comm* c, int W, int per, int hd, int tb, hipStream_t st, bool may_fold = false) {
@@ -245,6 +244,7 @@ static int tree_sharded_wave(lqrrt_engine* e, lqrrt_comm* c, int W, hipStream_t 
 }
 
 extern "C" int lqrrt_allgather_nodes(lqrrt_engine* e, lqrrt_comm* c, int W, void* stream) {
+    NOT_GENERIC(e);
     // one sample-sharded wave up to (not including) its commit: speculate this rank's slice, exchange, unpack
     if (!e || !c) return fail(LQRRT_E_ARG, "null argument");
     if (W < 1 || W > e->maxW) return fail(LQRRT_E_ARG, "bad wave size");
@@ -255,6 +255,7 @@ extern "C" int lqrrt_allgather_nodes(lqrrt_engine* e, lqrrt_comm* c, int W, void
 extern "C" int lqrrt_engine_extend_sharded(lqrrt_engine* e, lqrrt_comm* c, int scheme, int wave, int64_t max_attempts,
                                            int64_t node_limit, int until_size, int pruning, int stop_on_goal,
                                            lqrrt_extend_stats* out, void* stream) {
+    NOT_GENERIC(e);
     if (!e || !c) return fail(LQRRT_E_ARG, "null argument");
     if (wave < 1) return fail(LQRRT_E_ARG, "wave must be >= 1");
     if (scheme != LQRRT_SHARD_SAMPLES && scheme != LQRRT_SHARD_TREE) return fail(LQRRT_E_ARG, "unknown sharding scheme %d", scheme);
@@ -307,6 +308,7 @@ extern "C" int lqrrt_engine_extend_sharded(lqrrt_engine* e, lqrrt_comm* c, int s
         }
         acc.attempts += ws.attempts; acc.accepted += ws.accepted; acc.waves += 1;
         acc.fix_rounds += ws.fix_rounds; acc.resteers += ws.resteers; acc.goal_hits += ws.goal_hits;
+        acc.chain_slots += ws.chain_slots;
         if (stop_on_goal && ws.goal_hits) { acc.stop_reason = LQRRT_STOP_GOAL; break; }
     }
     acc.tree_size = e->N;
@@ -318,6 +320,7 @@ extern "C" int lqrrt_engine_extend_sharded(lqrrt_engine* e, lqrrt_comm* c, int s
 }
 
 extern "C" int lqrrt_plan_best(lqrrt_engine* e, int32_t* end_node, int64_t* steps, int64_t* hits) {
+    NOT_GENERIC(e);
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     if (end_node) *end_node = e->best_end;
     if (steps) *steps = e->best_steps;
@@ -326,6 +329,7 @@ extern "C" int lqrrt_plan_best(lqrrt_engine* e, int32_t* end_node, int64_t* step
 }
 
 extern "C" int lqrrt_engine_counters(lqrrt_engine* e, lqrrt_extend_stats* out) {
+    NOT_GENERIC(e);
     if (!e || !out) return fail(LQRRT_E_ARG, "null argument");
     *out = e->tot;
     out->tree_size = e->N;
@@ -334,6 +338,7 @@ extern "C" int lqrrt_engine_counters(lqrrt_engine* e, lqrrt_extend_stats* out) {
 }
 
 extern "C" int lqrrt_profile_enable(lqrrt_engine* e, int on) {
+    NOT_GENERIC(e);
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     prof_flush(e);
     // on = level + 16 * (sampling interval - 1): e.g. 1 + 16*3 times every 4th NN scan launch
@@ -348,6 +353,7 @@ extern "C" int lqrrt_profile_enable(lqrrt_engine* e, int on) {
 
 extern "C" int lqrrt_profile_read(lqrrt_engine* e, double* nn_ms, int64_t* nn_launches, double* nn_bytes,
                                   double* steer_ms, int64_t* steer_launches) {
+    NOT_GENERIC(e);
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     prof_flush(e);
     if (nn_ms) *nn_ms = e->nn_ms;

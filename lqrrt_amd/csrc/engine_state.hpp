@@ -45,6 +45,13 @@ struct lqrrt_engine {
     int device = 0;
     int model = 0, n = 0, m = 0, nw = 0;
     int cap = 0, maxW = 0, H = 0;
+    // LQRRT_MODEL_GENERIC (engine_generic.hpp): no plugins compiled in -- node table, ignore set and nearest-neighbour stage only
+    bool generic = false;
+    GenericShape gsh{};
+    double* h_gres = nullptr;     // pinned + mapped {cost, id, sequence number}: the answer of a host-form query (lqrrt_nn_argmin_host)
+    double* h_gres_dev = nullptr;
+    double gseq = 0.0;
+    double* d_q = nullptr;        // compiled-in models: device staging of a host-form query [n + n*n] and its answer
     Params P;
     Geo geo{};
     Res res{};
@@ -181,8 +188,12 @@ struct lqrrt_engine {
     std::vector<char> proto_cache;
     hipStream_t multi_stream = nullptr;   // the stream of the group this engine leads when a multi call runs on several host threads
 
+    // HBM held by this engine (lqrrt_engine_footprint): everything allocated at creation, and the H-dependent pools (alloc_wave)
+    size_t bytes_fixed = 0, bytes_wave = 0, bytes_pinned = 0;
+
     // counters
     lqrrt_extend_stats tot{};
+    std::vector<int> chain_depth;       // commit_finish: depth of every committed sample in its wave's chain of in-wave parents
 
     // profiling
     int prof = 0;                       // 0 off, 1 NN scan only, 2 NN scan + steer

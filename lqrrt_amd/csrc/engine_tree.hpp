@@ -6,6 +6,7 @@ extern "C" int lqrrt_tree_reset(lqrrt_engine* e, const double* x0_host, void* st
     if (!e || !x0_host) return fail(LQRRT_E_ARG, "null argument");
     TRY(use_device(e));
     hipStream_t st = (hipStream_t)stream;
+    if (e->generic) return generic_reset(e, x0_host, st);
     double* d_x0 = e->d_pcost;    // scratch: the scan partials are idle while the tree is being reset
     HIPCHK(hipMemcpyAsync(d_x0, x0_host, sizeof(double) * e->n, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(e->tv.ignore, 0, sizeof(unsigned long long) * ((size_t)e->cap / 64 + 1), st));
@@ -51,6 +52,7 @@ extern "C" int lqrrt_tree_get_states(lqrrt_engine* e, int first, int count, doub
 }
 
 extern "C" int lqrrt_tree_get_gains(lqrrt_engine* e, int first, int count, double* out) {
+    NOT_GENERIC(e);
     TRY(range_ok(e, first, count));
     if (!count) return 0;
     TRY(use_device(e));
@@ -67,6 +69,7 @@ extern "C" int lqrrt_tree_get_parents(lqrrt_engine* e, int first, int count, int
 }
 
 extern "C" int lqrrt_tree_get_edge_lengths(lqrrt_engine* e, int first, int count, int32_t* out) {
+    NOT_GENERIC(e);
     TRY(range_ok(e, first, count));
     if (!count) return 0;
     TRY(use_device(e));
@@ -75,6 +78,7 @@ extern "C" int lqrrt_tree_get_edge_lengths(lqrrt_engine* e, int first, int count
 }
 
 extern "C" int lqrrt_tree_get_edge(lqrrt_engine* e, int id, double* x_host, double* u_host) {
+    NOT_GENERIC(e);
     TRY(range_ok(e, id, 1));
     TRY(use_device(e));
     const int len = e->h_elen[id];
@@ -93,6 +97,7 @@ extern "C" int lqrrt_tree_get_ignored(lqrrt_engine* e, int first, int count, uin
 }
 
 extern "C" int lqrrt_tree_get_edges(lqrrt_engine* e, int first, int count, double* x_host, double* u_host) {
+    NOT_GENERIC(e);
     TRY(range_ok(e, first, count));
     if (!count) return 0;
     TRY(use_device(e));
@@ -119,19 +124,25 @@ __global__ void k_tree_trig(TreeView tv, int count) {
 extern "C" int lqrrt_tree_load(lqrrt_engine* e, int count, const double* states, const double* K, const int32_t* pID,
                                const int32_t* edge_len, const double* xedge, const double* uedge, const uint8_t* ignored,
                                void* stream) {
-    if (!e || !states || !K || !pID) return fail(LQRRT_E_ARG, "null argument");
-    if (!e->has_res) return fail(LQRRT_E_STATE, "set_resolution first (the edge pools depend on horizon_iters)");
+    if (!e || !states || !pID || (!K && !e->generic)) return fail(LQRRT_E_ARG, "null argument");
+    if (!e->generic && !e->has_res) return fail(LQRRT_E_STATE, "set_resolution first (the edge pools depend on horizon_iters)");
     if (count < 1) return fail(LQRRT_E_ARG, "a tree has at least its seed node");
     if (count > e->cap) return fail(LQRRT_E_CAPACITY, "tree of %d nodes exceeds the engine capacity %d", count, e->cap);
     if (pID[0] != -1) return fail(LQRRT_E_ARG, "the seed node must have parent -1");
     for (int i = 1; i < count; ++i)
         if (pID[i] < 0 || pID[i] >= i) return fail(LQRRT_E_ARG, "The given parent ID, %d, doesn't exist.", pID[i]);   // tree.py:83-84
-    if (edge_len)
+    if (edge_len && !e->generic)
         for (int i = 0; i < count; ++i)
             if (edge_len[i] < 1 || edge_len[i] > e->H)
                 return fail(LQRRT_E_ARG, "edge of node %d has %d steps (horizon_iters is %d)", i, edge_len[i], e->H);
     TRY(use_device(e));
     hipStream_t st = (hipStream_t)stream;
+    if (e->generic) {                                       // states, parents and ignore flags only: gains and edges stay with the caller
+        TRY(generic_load(e, count, states, pID, ignored, st));
+        TRY(flush_ignore(e, st, false));
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    }
     HIPCHK(hipStreamSynchronize(st));                       // nothing of the old tree may still be in flight
     const int n = e->n, m = e->m, H = e->H;
     std::vector<double> soa((size_t)count);
@@ -235,6 +246,7 @@ extern "C" int lqrrt_tree_rewind(lqrrt_engine* e) {
 // the benches keep by rewinding to a mark between native calls; with many engines in one call every engine has to do that on its
 // own, inside the call -- lqrrt_engine_extend_multi rewinds an engine to its mark when a wave would begin above `size` nodes.  0: off.
 extern "C" int lqrrt_tree_set_rewind_above(lqrrt_engine* e, int size) {
+    NOT_GENERIC(e);
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     if (size < 0 || (size > 0 && (e->mark_N < 1 || size < e->mark_N))) return fail(LQRRT_E_ARG, "rewind size below the mark (or no mark)");
     e->rewind_above = size;

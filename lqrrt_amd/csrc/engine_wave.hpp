@@ -4,6 +4,7 @@
 // wave engine
 
 extern "C" int lqrrt_record_layout(lqrrt_engine* e, int32_t* o) {
+    NOT_GENERIC(e);
     if (!e || !o) return fail(LQRRT_E_ARG, "null argument");
     o[0] = e->L.R; o[1] = e->L.off_cost; o[2] = e->L.off_parent; o[3] = e->L.off_len; o[4] = e->L.off_flags;
     o[5] = e->L.off_xend; o[6] = e->L.off_trig; o[7] = e->L.off_K; o[8] = e->L.off_xseq; o[9] = e->L.off_useq;
@@ -12,6 +13,7 @@ extern "C" int lqrrt_record_layout(lqrrt_engine* e, int32_t* o) {
 }
 
 extern "C" int lqrrt_wave_records(lqrrt_engine* e, void** p) {
+    NOT_GENERIC(e);
     if (!e || !p) return fail(LQRRT_E_ARG, "null argument");
     *p = e->d_rec;
     return 0;
@@ -22,6 +24,7 @@ struct ShardOut { double* hdr; double* tail; int* cursor; int hd, tb; };
 static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, const ShardOut* so, bool native_loop = false);
 
 extern "C" int lqrrt_wave_speculate(lqrrt_engine* e, int W, int lo, int hi, void* stream) {
+    NOT_GENERIC(e);
     return speculate_impl(e, W, lo, hi, stream, nullptr);
 }
 
@@ -40,11 +43,10 @@ static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, 
     // the few words a goal hit changed travel with the scan's arguments (IgnPatch); anything else is uploaded
     IgnPatch patch;
     memset(&patch, 0, sizeof patch);
-    static const bool patch_on = [] { const char* v = getenv("LQRRT_IGNORE_PATCH"); return !(v && atoi(v) == 0); }();
     // (small waves only: the copy it replaces is a fixed ~5 us, the lookup costs the patched scan ~2 us at 100 samples and more at
     //  1024 -- synchronous mode is 4 % faster with the upload, profiles/r03_ab_round.txt)
     bool patch_rides = false;             // (the host's view of the device bitmap changes only once the scan that carries it is enqueued)
-    if (patch_on && e->ign_dirty && e->ign_patch_valid && cnt > 0 && W <= 256 && !e->ign_patch.empty() && scan_takes_patch(e)) {
+    if (e->ign_dirty && e->ign_patch_valid && cnt > 0 && W <= 256 && !e->ign_patch.empty() && scan_takes_patch(e)) {
         patch.n = (int)e->ign_patch.size();
         patch.wmin = patch.wmax = e->ign_patch[0];
         for (int k = 0; k < patch.n; ++k) {
@@ -59,8 +61,7 @@ static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, 
     const double hp1 = hostprof_on() ? now_us() : 0.0;
     const double* xs = wave_samples(e);
     const bool whole = (lo == 0 && hi == W);
-    static const int matrix_max = getenv("LQRRT_MATRIX_MAX_W") ? std::min(atoi(getenv("LQRRT_MATRIX_MAX_W")), (int)lqrrt_engine::MATRIX_MAX_W)
-                                                                : (int)lqrrt_engine::MATRIX_MAX_W;
+    const int matrix_max = std::min(sw().matrix_max_w, (int)lqrrt_engine::MATRIX_MAX_W);
     // (Riccati systems keep the matrix -- costs under the S about each sample -- in the native loops: the single-engine loop and the
     //  native all-gather.  The step-by-step entry point lqrrt_wave_speculate, which the Python-level sharded classes drive with one
     //  slice per rank, always takes the scan of the records for them: whether a rank's slice happens to be the whole wave must not
@@ -82,7 +83,7 @@ static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, 
         const double hp2 = hostprof_on() ? now_us() : 0.0;
         SteerFuse f;
         memset(&f, 0, sizeof f);
-        f.pcost = e->d_pcost; f.pidx = e->d_pidx; f.n_chunks = n_chunks; f.nv = nv;
+        f.part = (const Part*)e->d_pcost; f.n_chunks = n_chunks; f.nv = nv;
         f.changed = e->d_changed; f.stale = e->d_stale; f.par_out = e->d_par_done;
         f.M = (e->wave_matrix && whole) ? e->d_M : nullptr; f.W = W;
         f.xtrig = xtr;
@@ -102,6 +103,7 @@ static int speculate_impl(lqrrt_engine* e, int W, int lo, int hi, void* stream, 
 }
 
 extern "C" int lqrrt_wave_scan_nodes(lqrrt_engine* e, int W, int node_lo, int node_hi, double* best_dev, void* stream) {
+    NOT_GENERIC(e);
     if (!e || !best_dev) return fail(LQRRT_E_ARG, "null argument");
     if (W < 1 || W > e->maxW) return fail(LQRRT_E_ARG, "bad wave size");
     if (!e->has_res) return fail(LQRRT_E_STATE, "set_resolution first");
@@ -131,19 +133,19 @@ extern "C" int lqrrt_wave_scan_nodes(lqrrt_engine* e, int W, int node_lo, int no
 }
 
 extern "C" int lqrrt_wave_steer_candidates(lqrrt_engine* e, int W, int parts, const double* best_dev, void* stream) {
+    NOT_GENERIC(e);
     if (!e || !best_dev) return fail(LQRRT_E_ARG, "null argument");
     if (W < 1 || W > e->maxW || parts < 1 || parts > lqrrt_engine::MAXCH) return fail(LQRRT_E_ARG, "bad wave size / part count");
     if (e->N < 1 || !e->has_res) return fail(LQRRT_E_STATE, "no tree / resolution");
     TRY(use_device(e));
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_best_unpack, dim3((W * parts + 255) / 256), dim3(256), 0, st, best_dev, W, parts, e->d_pcost, e->d_pidx);
-    static const int matrix_max = getenv("LQRRT_MATRIX_MAX_W") ? std::min(atoi(getenv("LQRRT_MATRIX_MAX_W")), (int)lqrrt_engine::MATRIX_MAX_W)
-                                                                : (int)lqrrt_engine::MATRIX_MAX_W;
+    hipLaunchKernelGGL(k_best_unpack, dim3((W * parts + 255) / 256), dim3(256), 0, st, best_dev, W, parts, (Part*)e->d_pcost);
+    const int matrix_max = std::min(sw().matrix_max_w, (int)lqrrt_engine::MATRIX_MAX_W);
     e->wave_matrix = W <= matrix_max && !e->sync_mode;
     const double* xtr = wave_sample_trig(e);
     SteerFuse f;
     memset(&f, 0, sizeof f);
-    f.pcost = e->d_pcost; f.pidx = e->d_pidx; f.n_chunks = parts; f.nv = tree_view(e, true);
+    f.part = (const Part*)e->d_pcost; f.n_chunks = parts; f.nv = tree_view(e, true);
     f.changed = e->d_changed; f.stale = e->d_stale; f.par_out = e->d_par_done;
     f.M = e->wave_matrix ? e->d_M : nullptr; f.W = W;
     f.xtrig = xtr;
@@ -173,7 +175,7 @@ static int pick_wave(const lqrrt_engine* e, int wave_cap) {
     // k_decide + in-wave scan + listed re-steers, and the few waves the controller let grow that far cost more than they
     // brought -- demo_boat_novice at 5k nodes +28 %, the headline +2.6 %, nothing slower (tools/wave_cap_configs.py,
     // profiles/r03_wave_cap.txt).  LQRRT_EXACT_WAVE_MAX=1024 restores the old behaviour.
-    static const int exact_max = getenv("LQRRT_EXACT_WAVE_MAX") ? atoi(getenv("LQRRT_EXACT_WAVE_MAX")) : 256;
+    const int exact_max = sw().exact_wave_max;
     // (the sharded loops too: their gathered waves go through the same rounds; one collective per ~130 us wave either way)
     if (!e->sync_mode && exact_max >= 8) W = std::min(W, exact_max);
     if (W >= 64) W = (W / 64) * 64;
@@ -182,10 +184,8 @@ static int pick_wave(const lqrrt_engine* e, int wave_cap) {
 
 static void tune_wave(lqrrt_engine* e, int W, const lqrrt_extend_stats& ws, int wave_cap) {
     // (retuned for the multi-wavefront rollouts, tools/ab_bench.sh: cut 2.0 -> 1.0 and lo 5 -> 2 are worth +3 %)
-    static const double k_cut = getenv("LQRRT_CTL_CUT") ? atof(getenv("LQRRT_CTL_CUT")) : 1.0;
-    static const double k_min = getenv("LQRRT_CTL_MIN") ? atof(getenv("LQRRT_CTL_MIN")) : 128.0;
-    static const int k_hi = getenv("LQRRT_CTL_HI") ? atoi(getenv("LQRRT_CTL_HI")) : 10;
-    static const int k_lo = getenv("LQRRT_CTL_LO") ? atoi(getenv("LQRRT_CTL_LO")) : 2;
+    const double k_cut = sw().ctl_cut, k_min = sw().ctl_min;
+    const int k_hi = sw().ctl_hi, k_lo = sw().ctl_lo;
     double w = e->ctl_w >= 8.0 ? e->ctl_w : (double)W;
     if (ws.goal_hits && ws.attempts < W) {
         // cut by a goal hit after ws.attempts samples: the rest of the speculation was discarded
@@ -202,14 +202,7 @@ static void tune_wave(lqrrt_engine* e, int W, const lqrrt_extend_stats& ws, int 
 // Waits until k_decide number e->seq has published ctrl/summary into pinned host memory.  Spinning on
 // the sequence word costs ~2 us; a hipMemcpyAsync + hipStreamSynchronize round trip costs ~25 us.
 static bool fused_rounds_enabled() {
-    static const bool on = [] { const char* v = getenv("LQRRT_FUSED_ROUNDS"); return !(v && atoi(v) == 0); }();
-    return on;
-}
-// LQRRT_SECOND_CHOICE=0: a sample whose in-wave parent is being redone waits for it idly (rounds 2-3) instead of steering from its
-// best standing candidate in the meantime
-static bool second_choice_enabled() {
-    static const bool on = [] { const char* v = getenv("LQRRT_SECOND_CHOICE"); return !(v && atoi(v) == 0); }();
-    return on;
+    return sw().fused_rounds;
 }
 static int comm_async_error(lqrrt_engine* e);                  // engine_sharded.hpp
 static int wait_word(lqrrt_engine* e, hipStream_t st, int* word, int seq);
@@ -234,6 +227,7 @@ static int wait_word(lqrrt_engine* e, hipStream_t st, int* word, int seq) {
 }
 
 extern "C" int lqrrt_wave_suggest(lqrrt_engine* e, int wave_cap) {
+    NOT_GENERIC(e);
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     if (wave_cap < 1) return fail(LQRRT_E_ARG, "wave_cap must be >= 1");
     return pick_wave(e, wave_cap);
@@ -300,6 +294,17 @@ static int commit_finish(lqrrt_engine* e, int W, bool fused, int64_t max_commit,
         (void)id;
     }
     e->N += acc;
+    {   // dependency bound of this wave (lqrrt_extend_stats::chain_slots): 1 speculative rollout + the longest chain of in-wave parents
+        int deepest = 0;
+        if (!e->sync_mode) {
+            e->chain_depth.assign((size_t)C, 0);
+            for (int t = 0; t < C; ++t) {
+                if (len[t] > 0 && par[t] < 0 && ~par[t] < t) e->chain_depth[t] = e->chain_depth[~par[t]] + 1;
+                deepest = std::max(deepest, e->chain_depth[t]);
+            }
+        }
+        ws.chain_slots = 1 + deepest;
+    }
     if (hit) {
         if (!e->sync_mode) sync_hits.assign(1, acc - 1);      // exact mode: the goal hit is the last committed node
         for (int off : sync_hits) {                          // in commit order
@@ -335,6 +340,7 @@ static int commit_finish(lqrrt_engine* e, int W, bool fused, int64_t max_commit,
     ws.candidates = e->committed_row;
     e->tot.attempts += C; e->tot.accepted += acc; e->tot.waves += 1; e->tot.fix_rounds += ws.fix_rounds;
     e->tot.resteers += ws.resteers; e->tot.goal_hits += ws.goal_hits; e->tot.tree_size = e->N;
+    e->tot.chain_slots += ws.chain_slots;
     e->tot.candidates = e->committed_row;
     if (!e->sync_mode) tune_wave(e, W, ws, e->maxW);
     if (hostprof_on()) g_hp.book += now_us() - hb0;
@@ -346,6 +352,7 @@ static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_
 
 extern "C" int lqrrt_wave_commit(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_limit, int pruning,
                                  lqrrt_extend_stats* out, void* stream) {
+    NOT_GENERIC(e);
     return commit_impl(e, W, max_commit, node_limit, pruning, out, stream, false);
 }
 
@@ -407,7 +414,6 @@ static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_
         RoundArgs ra;
         memset(&ra, 0, sizeof ra);
         ra.on = 1; ra.W = W; ra.base = e->N;
-        ra.second_choice = second_choice_enabled() ? 1 : 0;
         ra.max_commit = max_commit;
         ra.room = node_limit >= 0 ? node_limit + 1 - (int64_t)e->N : -1;
         ra.M[0] = e->d_M; ra.M[1] = e->d_M2;
@@ -508,6 +514,7 @@ static int commit_impl(lqrrt_engine* e, int W, int64_t max_commit, int64_t node_
 
 extern "C" int lqrrt_engine_extend(lqrrt_engine* e, int wave, int64_t max_attempts, int64_t node_limit, int until_size,
                                    int pruning, int stop_on_goal, lqrrt_extend_stats* out, void* stream) {
+    NOT_GENERIC(e);
     if (!e) return fail(LQRRT_E_ARG, "null engine");
     if (wave < 1) return fail(LQRRT_E_ARG, "wave must be >= 1");
     lqrrt_extend_stats acc;
@@ -543,6 +550,7 @@ extern "C" int lqrrt_engine_extend(lqrrt_engine* e, int wave, int64_t max_attemp
         TRY(lqrrt_wave_commit(e, W, cap_attempts, lim, pruning, &ws, stream));
         acc.attempts += ws.attempts; acc.accepted += ws.accepted; acc.waves += 1;
         acc.fix_rounds += ws.fix_rounds; acc.resteers += ws.resteers; acc.goal_hits += ws.goal_hits;
+        acc.chain_slots += ws.chain_slots;
         if (stop_on_goal && ws.goal_hits) { acc.stop_reason = LQRRT_STOP_GOAL; break; }
     }
     acc.tree_size = e->N;

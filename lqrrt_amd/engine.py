@@ -70,6 +70,12 @@ class Engine(object):
         mask = np.ascontiguousarray(mask, dtype=np.uint32)
         nat.check(nat.lib().lqrrt_engine_set_cu_mask(self.h, nat.ptr(mask), int(mask.size)))
 
+    def footprint(self):
+        """dict(device_bytes, pinned_bytes): what this engine holds in HBM and in page-locked host memory (lqrrt_engine_footprint)."""
+        d, h = C.c_int64(), C.c_int64()
+        nat.check(nat.lib().lqrrt_engine_footprint(self.h, C.byref(d), C.byref(h)))
+        return dict(device_bytes=d.value, pinned_bytes=h.value)
+
     def sync_geometry(self):
         """Re-uploads parameters, hull points, obstacles and occupancy grid if the system object changed since
         this engine last saw it (system.revision; e.g. set_occupancy_grid between two plans)."""
@@ -455,3 +461,134 @@ class Engine(object):
         a, b, c, d, f = C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_int64()
         nat.check(nat.lib().lqrrt_profile_read(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(f)))
         return dict(nn_ms=a.value, nn_launches=b.value, nn_bytes=c.value, steer_ms=d.value, steer_launches=f.value)
+
+
+class NodeTable(object):
+    """
+    An LQRRT_MODEL_GENERIC engine (include/lqrrt_hip.h): the node table of a tree whose plugins are host callables -- SoA states,
+    cos/sin of the angular ones, parents, ignore set -- and the nearest-neighbour stage over it (planner.py:239-247, 340-350).
+    No dynamics, lqr or feasibility is compiled in; gains and edges stay with the caller (lqrrt_amd/callback.py).
+    """
+
+    def __init__(self, nstates, ncontrols, angle_dims=(), capacity=100008, device=0, max_wave=64):
+        nat.require_device()
+        self.n, self.m, self.device = int(nstates), int(ncontrols), device
+        self.angle_dims = tuple(sorted(int(d) for d in angle_dims))
+        d = nat.SystemDesc()
+        d.model, d.nstates, d.ncontrols = nat.MODEL_GENERIC, self.n, self.m
+        d.n_params = 1 + len(self.angle_dims)
+        d.params[0] = float(len(self.angle_dims))
+        for k, dim in enumerate(self.angle_dims):
+            d.params[1 + k] = float(dim)
+        h = C.c_void_p()
+        nat.check(nat.lib().lqrrt_engine_create(C.byref(d), device, int(capacity), int(max_wave), C.byref(h)))
+        self.h = h
+        self.capacity, self.max_wave = int(capacity), int(max_wave)
+        self._id, self._cost = C.c_int32(), C.c_double()
+        self._lib = nat.lib()
+        self._stream = nat.current_stream(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            nat.lib().lqrrt_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        return nat.check(self._lib.lqrrt_tree_size(self.h))
+
+    def reset(self, x0):
+        """Tree(seed_state, ...) (tree.py:50): the table holds the seed only, the ignore set is empty."""
+        x0 = nat.as_f64(x0, (self.n,))
+        self._stream = nat.current_stream(self.device)
+        nat.check(self._lib.lqrrt_tree_reset(self.h, nat.ptr(x0), self._stream))
+
+    def load(self, states, pID, ignored=None):
+        states = nat.as_f64(states)
+        N = len(states)
+        states = nat.as_f64(states, (N, self.n))
+        pID = np.ascontiguousarray(pID, dtype=np.int32)
+        ign = None if ignored is None else np.ascontiguousarray(ignored, dtype=np.uint8)
+        self._stream = nat.current_stream(self.device)
+        nat.check(self._lib.lqrrt_tree_load(self.h, N, nat.ptr(states), None, nat.ptr(pID), None, None, None,
+                                            nat.ptr(ign) if ign is not None else None, self._stream))
+
+    def append(self, parent, state):
+        """Tree.add_node's device half (tree.py:77-96): asynchronous, ordered before the next query."""
+        state = nat.as_f64(state, (self.n,))
+        nat.check(self._lib.lqrrt_tree_append(self.h, int(parent), nat.ptr(state), None, 1, None, None, self._stream))
+
+    def ignore(self, ids):
+        """planner.py:270: the nodes of a finished path join the ignore set."""
+        one = np.ones(1, dtype=np.uint8)
+        for i in ids:
+            nat.check(self._lib.lqrrt_tree_set_ignored(self.h, int(i), 1, nat.ptr(one)))
+
+    def ignored(self):
+        out = np.empty(self.size, dtype=np.uint8)
+        nat.check(self._lib.lqrrt_tree_get_ignored(self.h, 0, len(out), nat.ptr(out)))
+        return out.astype(bool)
+
+    def truncate(self, size):
+        nat.check(self._lib.lqrrt_tree_truncate(self.h, int(size)))
+
+    def states(self):
+        out = np.empty((self.size, self.n))
+        nat.check(self._lib.lqrrt_tree_get_states(self.h, 0, len(out), nat.ptr(out)))
+        return out
+
+    def parents(self):
+        out = np.empty(self.size, dtype=np.int32)
+        nat.check(self._lib.lqrrt_tree_get_parents(self.h, 0, len(out), nat.ptr(out)))
+        return out
+
+    def nearest(self, x, S=None, use_ignore=True):
+        """(id, cost) of the nearest eligible node to x under S (None = identity): one synchronous call, no copies."""
+        x = nat.as_f64(x, (self.n,))
+        Sp = None
+        if S is not None:
+            S = nat.as_f64(S, (self.n, self.n))
+            Sp = nat.ptr(S)
+        nat.check(self._lib.lqrrt_nn_argmin_host(self.h, nat.ptr(x), Sp, 1 if use_ignore else 0, C.byref(self._id), C.byref(self._cost),
+                                                 self._stream))
+        return self._id.value, self._cost.value
+
+    def nearest_from_errors(self, errors, S=None, use_ignore=True):
+        """The same selection for error rows erf(x, node i) the caller evaluated itself ([size][n])."""
+        errors = nat.as_f64(errors, (self.size, self.n))
+        Sp = None
+        if S is not None:
+            S = nat.as_f64(S, (self.n, self.n))
+            Sp = nat.ptr(S)
+        nat.check(self._lib.lqrrt_nn_argmin_errors(self.h, nat.ptr(errors), Sp, 1 if use_ignore else 0, C.byref(self._id),
+                                                   C.byref(self._cost), self._stream))
+        return self._id.value, self._cost.value
+
+    def nn_argmin(self, xs, S=None, use_ignore=True):
+        """Batched device form (lqrrt_nn_argmin): xs [W][n] -> ids [W], costs [W]."""
+        torch = _torch()
+        W = len(xs)
+        dev = "cuda:%d" % self.device
+        dxs = torch.from_numpy(nat.as_f64(xs, (W, self.n))).to(dev)
+        dS = torch.from_numpy(nat.as_f64(S, (self.n, self.n))).to(dev) if S is not None else None
+        ids = torch.empty(W, dtype=torch.int32, device=dev)
+        cost = torch.empty(W, dtype=torch.float64, device=dev)
+        nat.check(self._lib.lqrrt_nn_argmin(self.h, dxs.data_ptr(), W, dS.data_ptr() if dS is not None else None,
+                                            1 if use_ignore else 0, ids.data_ptr(), cost.data_ptr(), nat.current_stream(self.device)))
+        return ids.cpu().numpy(), cost.cpu().numpy()
+
+    def costs_to_go(self, x, S=None):
+        torch = _torch()
+        dev = "cuda:%d" % self.device
+        dx = torch.from_numpy(nat.as_f64(x, (self.n,))).to(dev)
+        dS = torch.from_numpy(nat.as_f64(S, (self.n, self.n))).to(dev) if S is not None else None
+        cost = torch.empty(self.size, dtype=torch.float64, device=dev)
+        nat.check(self._lib.lqrrt_costs_to_go(self.h, dx.data_ptr(), dS.data_ptr() if dS is not None else None, cost.data_ptr(),
+                                              nat.current_stream(self.device)))
+        return cost.cpu().numpy()

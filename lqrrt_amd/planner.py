@@ -14,9 +14,14 @@ inside the wave are steered again, to the fix-point.  'synchronous' mode skips t
 a wave of exactly `wave_size` sees the wave-start tree): not the reference's tree any more but the one
 oracle/lqrrt_oracle.c's orc_extend_sync defines, several times faster.
 
-dynamics / lqr / erf / is_feasible must be the plugin handles of ONE native system object
-(lqrrt_amd.systems); a GPU cannot call back into Python, so arbitrary callables raise ValueError.
-There is no CPU path: without the HIP library and a device, update_plan raises.
+Two kinds of plugins are accepted:
+  * the handles of ONE native system object (lqrrt_amd.systems: the reference's demo problems, the ROS behaviours, an
+    out-of-tree header): the whole loop body runs on the device as described above;
+  * arbitrary Python callables with the reference's signatures (planner.py:35-59, constraints.py:27) -- "callback mode"
+    (lqrrt_amd/callback.py): a GPU cannot call back into Python, so sampling, steering and feasibility run on the host in
+    the reference's order of events, one iteration at a time, and the device keeps the node table and does
+    Planner._costs_to_go + the nearest selection (95 % of the reference's time at 8k nodes).
+There is no CPU path in either: without the HIP library and a device, update_plan raises.
 """
 from __future__ import division
 
@@ -29,7 +34,8 @@ import scipy.interpolate
 from . import _native as nat
 from .constraints import Constraints
 from .engine import Engine
-from .systems import plugin_system
+from . import callback
+from .systems import native_system_of
 from .tree import Tree
 
 
@@ -48,6 +54,8 @@ class Planner:
     min_time, max_time, max_nodes, goal0, sys_time, printing: as in the reference (planner.py:61-82).
     wave_size, wave_mode, device: new and optional -- samples per wave (upper bound), 'exact' | 'synchronous',
         HIP device ordinal.
+    angle_dims: new and optional, callback mode only -- the states `erf` wraps to (-pi, pi]; checked against a probe of erf
+        (ValueError when they disagree).  None: the probe alone decides (lqrrt_amd/callback.py classify_erf).
     """
 
     def __init__(self, dynamics, lqr, constraints,
@@ -55,11 +63,13 @@ class Planner:
                  error_tol=0.05, erf=np.subtract,
                  min_time=0.5, max_time=1, max_nodes=1E5,
                  goal0=None, sys_time=time.time, printing=True,
-                 wave_size=1024, device=0, wave_mode='exact'):
+                 wave_size=1024, device=0, wave_mode='exact', angle_dims=None):
         if wave_mode not in ('exact', 'synchronous'):
             raise ValueError("wave_mode must be 'exact' or 'synchronous'")
         self.device, self.wave_size, self.wave_mode = device, int(wave_size), wave_mode
         self._engine = self._engine_key = None
+        self._callback_run = None
+        self.angle_dims = angle_dims
         self.tree = None
         self.set_system(dynamics, lqr, constraints, erf)
         self.set_resolution(horizon, dt, FPR, error_tol)
@@ -69,7 +79,15 @@ class Planner:
         self.killed = False
         self.stats = None
         self.xrand_gen_sees_tree = False        # True: a user sampling function is called once per iteration, on the current tree
-        self.warm_up()
+        # HBM pools are sized by max_nodes (Engine.footprint(): ~1.7 kB per node for the boats with horizon_iters = 20, i.e. ~170 MB at
+        # the reference's default of 1e5 nodes).  A planner built with an explicit max_nodes gets them now, outside any plan's time
+        # budget; one left at the default gets them with its first update_plan -- or when the caller asks (warm_up()) -- so that a fleet
+        # of planners built with defaults does not pin gigabytes before anyone plans.
+        if max_nodes != 1E5:
+            self.warm_up()
+        else:
+            self.warm_up_error = None if nat.available() else RuntimeError("lqrrt_amd: no engine created: %s" % (
+                "liblqrrt_hip.so is not built" if not os.path.exists(nat.LIB_PATH) else "no HIP device visible"))
 
     # ------------------------------------------------------------------------------------------ engine
     def warm_up(self):
@@ -79,6 +97,11 @@ class Planner:
         `self.warm_up_error` (None when the engine exists), so that a broken install can be diagnosed before the first plan;
         update_plan raises it in full."""
         self.warm_up_error = None
+        if self.callback_mode:
+            if not nat.available():
+                self.warm_up_error = RuntimeError("lqrrt_amd: no engine created: %s" % (
+                    "liblqrrt_hip.so is not built" if not os.path.exists(nat.LIB_PATH) else "no HIP device visible"))
+            return
         try:
             if nat.available():
                 self._get_engine()
@@ -115,6 +138,8 @@ class Planner:
 
         Returns True if it ran to completion, False if it was halted (killed, tree larger than max_nodes, no goal).
         """
+        if self.callback_mode:
+            return self._update_plan_callback(x0, sample_space, goal_bias, guide, xrand_gen, pruning, finish_on_goal, specific_time)
         run = self._plan_begin(x0, sample_space, goal_bias, guide, xrand_gen, pruning, finish_on_goal, specific_time)
         if run is None:
             return False
@@ -130,6 +155,19 @@ class Planner:
             if self._plan_after_call(run, st, time.perf_counter() - t_call):
                 break
         return self._plan_end(run)
+
+    def _update_plan_callback(self, x0, sample_space, goal_bias, guide, xrand_gen, pruning, finish_on_goal, specific_time, resume=None):
+        """update_plan for plugins that are host callables: the reference's loop on the host, the nearest-neighbour stage on the
+        device (lqrrt_amd/callback.py)."""
+        if self.goal is not None:
+            callback.require_device()
+        if self._erf_angles is False:                               # erf is classified once per erf, at its first use
+            self._erf_angles = callback.classify_erf(self.erf, self.nstates, self.angle_dims)
+        if self._callback_run is None:
+            self._callback_run = callback.CallbackRun(self)
+        if self.tree is not None and getattr(self.tree, "on_device", False):
+            self.tree._detach()                                     # a tree grown by the native engine before the plugins were swapped
+        return self._callback_run.run(x0, sample_space, goal_bias, guide, xrand_gen, pruning, finish_on_goal, specific_time, resume=resume)
 
     # The three phases of update_plan, separately callable so that several planners can share native calls (update_plans below):
     # set-up (planner.py:157-231), what follows each native call (:260-311 as far as the host is concerned), wrap-up (:313-336).
@@ -223,8 +261,11 @@ class Planner:
                 run.eng.push_samples(np.array([np.array(run.xrand_gen(self), dtype=np.float64) for _ in range(missing)]))
         return budget
 
-    def _plan_after_call(self, run, st, dt_call):
-        """Goal bookkeeping, clock, kill flag and exit rules after a native call (planner.py:260-323); True when the plan is over."""
+    def _plan_after_call(self, run, st, dt_call, wrap_up=True):
+        """Goal bookkeeping, clock, kill flag and exit rules after a native call (planner.py:260-323); True when the plan is over.
+        The wrap-up of a finished plan (plan extraction, finish_on_goal, fallback search, interpolators: milliseconds of host work and
+        copies out of HBM) follows at once, or -- wrap_up=False, several planners sharing native calls -- when the caller gets to it
+        (`_plan_wrap_up`), so that one planner's wrap-up is not charged to the others' clocks."""
         eng = run.eng
         if st.attempts > 0 and dt_call > 0:
             run.rate = st.attempts / dt_call if run.rate is None else 0.5 * run.rate + 0.5 * st.attempts / dt_call
@@ -241,9 +282,20 @@ class Planner:
 
         run.time_elapsed = self.sys_time() - run.time_start
 
+        run.outcome = None
         if self.killed:
-            return True
-        if self.plan_reached_goal and run.time_elapsed >= run.min_time:
+            run.outcome = "killed"
+        elif self.plan_reached_goal and run.time_elapsed >= run.min_time:
+            run.outcome = "goal"
+        elif run.time_elapsed >= run.max_time or self.tree.size > self.max_nodes:
+            run.outcome = "fallback"
+        if run.outcome is not None and wrap_up:
+            self._plan_wrap_up(run)
+        return run.outcome is not None
+
+    def _plan_wrap_up(self, run):
+        """What the reference does between leaving its loop and returning (planner.py:293-328) for a plan that `_plan_after_call` ended."""
+        if run.outcome == "goal":
             self._adopt_plan(run.best_end)
             run.adopted = True
             if run.finish_on_goal:
@@ -251,21 +303,18 @@ class Planner:
             if self.printing:
                 print("Tree size: {0}\nETA: {1} s".format(self.tree.size, np.round(self.T, 2)))
             self._prepare_interpolators()
-            return True
-        if run.time_elapsed >= run.max_time or self.tree.size > self.max_nodes:
+        elif run.outcome == "fallback":
             # no goal hit (or not enough time spent): plan to the node nearest the guide state (planner.py:311-323)
             if getattr(self.system, "riccati", False):
                 self.system._engine(self.dt)       # the lqr handle of a Riccati system linearises with THIS planner's dt
             Sguide = np.array(self.lqr(self.xguide, np.zeros(self.ncontrols))[0], dtype=np.float64)
             Sguide[:, np.isinf(np.asarray(self.constraints.goal_buffer, dtype=np.float64))] = 0
-            ids, _ = eng.nn_argmin(self.xguide.reshape(1, -1), S=Sguide, use_ignore=False)
+            ids, _ = run.eng.nn_argmin(self.xguide.reshape(1, -1), S=Sguide, use_ignore=False)
             self._adopt_plan(int(ids[0]))
             run.adopted = True
             if self.printing:
                 print("Didn't reach goal.\nTree size: {0}\nETA: {1} s".format(self.tree.size, np.round(self.T, 2)))
             self._prepare_interpolators()
-            return True
-        return False
 
     def _plan_end(self, run):
         eng = run.eng
@@ -409,10 +458,7 @@ class Planner:
                 raise ValueError("Expected dynamics to be a function.")
             if not _callable(lqr):
                 raise ValueError("Expected lqr to be a function.")
-            system = plugin_system(dynamics, "dynamics")
-            if plugin_system(lqr, "lqr") is not system:
-                raise ValueError("dynamics and lqr belong to different native systems.")
-            self.dynamics, self.lqr, self.system = dynamics, lqr, system
+            self.dynamics, self.lqr = dynamics, lqr
         if constraints is not None:
             if not isinstance(constraints, Constraints):
                 raise ValueError("Expected constraints to be an instance of the Constraints class.")
@@ -421,15 +467,31 @@ class Planner:
         if erf is not None:
             if not _callable(erf):
                 raise ValueError("Expected erf to be a function.")
-            if erf is np.subtract:
-                if self.system.wrap_dims:
-                    raise ValueError("This system has angular states; pass its .erf handle.")
-            elif plugin_system(erf, "erf") is not self.system:
-                raise ValueError("erf belongs to a different native system.")
             self.erf = erf
-        have = getattr(self, "constraints", None), getattr(self, "system", None)
-        if have[0] is not None and have[1] is not None and have[0].system is not have[1]:
-            raise ValueError("constraints.is_feasible belongs to a different native system.")
+            self._erf_angles = False                                # (callback mode: not classified yet)
+        self._resolve_mode()
+        self.plan_reached_goal = False
+
+    def _resolve_mode(self):
+        """Native mode when every plugin is a handle of ONE native system object (then the whole loop runs on the device), callback
+        mode as soon as one of them is a plain Python callable.  Handles of different native systems, or np.subtract as the erf of
+        a native system with angular states, are mistakes and raise."""
+        handles = [(getattr(self, "dynamics", None), "dynamics"), (getattr(self, "lqr", None), "lqr")]
+        erf = getattr(self, "erf", None)
+        cons = getattr(self, "constraints", None)
+        if erf is not None and erf is not np.subtract:
+            handles.append((erf, "erf"))
+        if cons is not None:
+            handles.append((cons.is_feasible, "is_feasible"))
+        systems = [native_system_of(f, kind) for f, kind in handles if f is not None]
+        if any(sysobj is None for sysobj in systems):
+            self.callback_mode, self.system = True, None
+            return
+        if len(set(id(sysobj) for sysobj in systems)) > 1:
+            raise ValueError("dynamics, lqr, erf and constraints.is_feasible belong to different native systems.")
+        self.callback_mode, self.system = False, (systems[0] if systems else None)
+        if self.system is not None and erf is np.subtract and self.system.wrap_dims:
+            raise ValueError("This system has angular states; pass its .erf handle.")
         self.plan_reached_goal = False
 
     def kill_update(self):
@@ -454,65 +516,139 @@ class _PlanRun(object):
 
 def update_plans(jobs):
     """
-    Several planners plan at once on one GPU: `jobs` is a list of dicts, each with the keys `planner`, `x0`, `sample_space` and,
-    optionally, update_plan's keyword arguments (goal_bias, guide, xrand_gen, pruning, finish_on_goal, specific_time) plus `seed`.
+    Several planners plan at once: `jobs` is a list of dicts, each with the keys `planner`, `x0`, `sample_space` and, optionally,
+    update_plan's keyword arguments (goal_bias, guide, xrand_gen, pruning, finish_on_goal, specific_time) plus `seed` and `group`.
     Every planner gets exactly what its own update_plan would give it -- its tree is the one it grows alone from the same sample
-    stream -- but the native calls are shared: lqrrt_engine_extend_multi advances all trees in lock step with two kernel launches
-    per tick whatever their number (csrc/engine_multi.hpp), which is how one MI355X is filled by planners that each use ~2 % of it
-    (a fleet's vehicles, the behaviours of one vehicle, restarts of one query: 16 trees 6 x, 64 trees 10 x the throughput of one).
-    `seed`: the default sampler of that planner draws from np.random.RandomState(seed) and np.random itself is left alone; without it
-    every planner starts from np.random's current state, as its own update_plan would, and np.random is left where the FIRST
-    planner's sampler stopped.  The planners must share the native system type, horizon, max_nodes, wave_size, pruning and device,
-    and run exact waves of an analytic-gain system (ValueError otherwise: plan those one by one).  Returns the list of
-    update_plan's return values.  Not in the reference: its Planner plans one tree on one core.
+    stream -- but the native calls are shared: lqrrt_engine_extend_multi advances all trees of a GROUP in lock step with two kernel
+    launches per tick whatever their number (csrc/engine_multi.hpp), which is how one MI355X is filled by planners that each use ~2 %
+    of it (a fleet's vehicles, the behaviours of one vehicle, restarts of one query: 16 trees 6 x, 64 trees 10 x the throughput of one).
+
+    Groups: the planners of one device form a group (a job's `group` key splits a device's planners further); every group runs its own
+    shared loop on a host thread of its own (the native call releases the GIL), with no exchange between groups -- planners on the 8
+    GPUs of a node are 8 independent fleets, which is the one multi-GPU form of this path that scales with the device count
+    (DESIGN.md section 8).  Within a group the planners must share the native system type, horizon, max_nodes, wave_size and pruning,
+    and run exact waves of an analytic-gain system (ValueError otherwise -- checked for EVERY job before any planner is touched).
+
+    `seed`: the default sampler of that planner draws from np.random.RandomState(seed) and np.random itself is left alone.  Without it
+    a planner starts from np.random's current state, as its own update_plan would: unseeded planners therefore grow THE SAME tree from
+    the same start (a warning is printed when that happens), and np.random is left where the first unseeded planner's sampler stopped.
+
+    Time: each planner's clock starts when its group's loop does and is read right after every native call, before anyone's wrap-up;
+    a call is sized by the smallest remaining budget of the group and the wrap-up of finished plans is deferred until the group's
+    loop has ended, so a planner overruns its max_time by at most one shared call (the same bound as a solo update_plan) whatever
+    the number of jobs.  A goal hit of ANY planner ends the running call early once some planner of the group is past its min_time
+    (the others just continue with the next call).  Returns the list of update_plan's return values.  Not in the reference: its
+    Planner plans one tree on one core.
     """
-    keys = ("goal_bias", "guide", "xrand_gen", "pruning", "finish_on_goal", "specific_time", "seed")
+    keys = ("goal_bias", "guide", "xrand_gen", "pruning", "finish_on_goal", "specific_time", "seed", "group")
     jobs = [dict(j) for j in jobs]
     if not jobs:
         return []
-    planners = [j["planner"] for j in jobs]
+    planners = [j.get("planner") for j in jobs]
     if len(set(id(p) for p in planners)) != len(planners):
         raise ValueError("update_plans: a planner appears twice.")
-    p0 = planners[0]
-    prun0 = jobs[0].get("pruning", True)
-    for p, j in zip(planners, jobs):
+    groups = {}
+    for k, (p, j) in enumerate(zip(planners, jobs)):
         unknown = set(j) - set(keys) - {"planner", "x0", "sample_space"}
         if unknown:
             raise ValueError("update_plans: unknown job key(s) %s." % sorted(unknown))
-        same = (type(p.system) is type(p0.system) and tuple(int(v) for v in p.hspan) == tuple(int(v) for v in p0.hspan)
-                and p.hfactor == p0.hfactor and int(p.max_nodes) == int(p0.max_nodes) and p.wave_size == p0.wave_size
-                and p.device == p0.device and bool(j.get("pruning", True)) == bool(prun0))
-        if not same:
-            raise ValueError("update_plans: the planners must share system type, horizon, max_nodes, wave_size, pruning and device.")
+        if not isinstance(p, Planner) or "x0" not in j or "sample_space" not in j:
+            raise ValueError("update_plans: every job needs a planner, x0 and sample_space.")
+        if p.callback_mode:
+            raise ValueError("update_plans: planners whose plugins are Python callables plan one by one (update_plan).")
         if p.wave_mode != "exact" or getattr(p.system, "riccati", False):
             raise ValueError("update_plans: exact waves of analytic-gain systems only.")
+        # what update_plan itself would refuse, before anything is reset (planner.py:183,196,216)
+        xg = j.get("xrand_gen")
+        if not (xg is None or type(xg) is int or _callable(xg)):
+            raise ValueError("Expected xrand_gen to be None, an integer >= 1,  or a function.")
+        if xg is None or type(xg) is int:
+            gb = j.get("goal_bias", 0)
+            if gb is not None and hasattr(gb, '__contains__') and len(gb) != p.nstates:
+                raise ValueError("Expected goal_bias to be scalar or have same length as state.")
+            if np.array(j["sample_space"], dtype=np.float64).shape != (p.nstates, 2):
+                raise ValueError("Expected sample_space to be list of nstates tuples.")
+        groups.setdefault((p.device, j.get("group")), []).append(k)
+    for members in groups.values():
+        p0, prun0 = planners[members[0]], bool(jobs[members[0]].get("pruning", True))
+        if len(members) > 128:
+            raise ValueError("update_plans: at most 128 planners per group (split them with the `group` key).")
+        for k in members:
+            p, j = planners[k], jobs[k]
+            same = (type(p.system) is type(p0.system) and tuple(int(v) for v in p.hspan) == tuple(int(v) for v in p0.hspan)
+                    and p.hfactor == p0.hfactor and int(p.max_nodes) == int(p0.max_nodes) and p.wave_size == p0.wave_size
+                    and bool(j.get("pruning", True)) == prun0)
+            if not same:
+                raise ValueError("update_plans: the planners of a group must share system type, horizon, max_nodes, wave_size, pruning and device.")
+    unseeded = [k for k, j in enumerate(jobs) if j.get("seed") is None and (j.get("xrand_gen") is None or type(j.get("xrand_gen")) is int)]
+    if len(unseeded) > 1 and any(getattr(planners[k], "printing", False) for k in unseeded):
+        print("update_plans: %d planners use the default sampler without a `seed`: they all start from np.random's current state." % len(unseeded))
+
     results = [None] * len(jobs)
-    runs = []
+    runs = {}
     for k, (p, j) in enumerate(zip(planners, jobs)):
         run = p._plan_begin(j["x0"], j["sample_space"], j.get("goal_bias", 0), j.get("guide"), j.get("xrand_gen"),
                             bool(j.get("pruning", True)), j.get("finish_on_goal", False), j.get("specific_time"), seed=j.get("seed"))
         if run is None:
             results[k] = False
         else:
-            runs.append((k, p, run))
-    # every planner's clock starts when the shared loop does: the others' set-up is not part of its time budget
-    for _, p, run in runs:
-        run.time_start, run.time_elapsed = p.sys_time(), 0
-    active = list(runs)
-    while active:
-        budget = min(p._plan_budget(run) for _, p, run in active)
-        stop = any(run.time_elapsed >= run.min_time for _, _, run in active)
-        t_call = time.perf_counter()
-        sts = Engine.extend_multi([run.eng for _, _, run in active], p0.wave_size, max_attempts=budget, node_limit=int(p0.max_nodes),
-                                  pruning=bool(prun0), stop_on_goal=bool(stop))
-        dt_call = time.perf_counter() - t_call
-        active = [(k, p, run) for (k, p, run), st in zip(active, sts) if not p._plan_after_call(run, st, dt_call)]
-    first = True
-    for k, p, run in runs:
-        if not first and not run.user_sampler and not run.own_stream:
-            run.own_stream = True                                # (np.random: left where the first planner's sampler stopped)
-        results[k] = p._plan_end(run)
-        first = False
+            runs[k] = run
+
+    def group_loop(members):
+        mine = [(k, planners[k], runs[k]) for k in members if k in runs]
+        if not mine:
+            return
+        p0, prun0 = mine[0][1], bool(jobs[mine[0][0]].get("pruning", True))
+        # every planner's clock starts when the shared loop does: the others' set-up is not part of its time budget
+        for _, p, run in mine:
+            run.time_start, run.time_elapsed = p.sys_time(), 0
+        active = list(mine)
+        try:
+            while active:
+                budget = min(p._plan_budget(run) for _, p, run in active)
+                stop = any(run.time_elapsed >= run.min_time for _, _, run in active)
+                t_call = time.perf_counter()
+                sts = Engine.extend_multi([run.eng for _, _, run in active], p0.wave_size, max_attempts=budget, node_limit=int(p0.max_nodes),
+                                          pruning=prun0, stop_on_goal=bool(stop))
+                dt_call = time.perf_counter() - t_call
+                # clocks and exit rules of ALL planners first (cheap), wrap-ups after the loop
+                active = [(k, p, run) for (k, p, run), st in zip(active, sts) if not p._plan_after_call(run, st, dt_call, wrap_up=False)]
+        except Exception:
+            # a failed native call leaves every engine of the group mid-wave (include/lqrrt_hip.h): nothing of these trees may be read
+            for _, p, run in mine:
+                p.tree._e, p.tree._snap = None, None
+                p._engine_key = None                                 # the next plan builds a fresh engine
+            raise
+        for _, p, run in mine:
+            p._plan_wrap_up(run)
+
+    order = sorted(groups, key=lambda g: min(groups[g]))
+    if len(order) == 1:
+        group_loop(groups[order[0]])
+    else:
+        import threading
+        errors = []
+
+        def guarded(members):
+            try:
+                group_loop(members)
+            except Exception as ex:                                  # surfaced on the caller's thread below
+                errors.append(ex)
+        threads = [threading.Thread(target=guarded, args=(groups[g],)) for g in order]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+    synced = False
+    for k in sorted(runs):
+        run = runs[k]
+        if not run.user_sampler and not run.own_stream:
+            if synced:
+                run.own_stream = True                                # (np.random: left where the first unseeded planner's sampler stopped)
+            synced = True
+        results[k] = planners[k]._plan_end(run)
     return results
 
 

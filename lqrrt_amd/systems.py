@@ -97,6 +97,11 @@ def plugin_system(fn, kind):
         "and wrapped by lqrrt_amd.systems.UserSystem -- INTEGRATION.md section 5." % (kind, kind))
 
 
+def native_system_of(fn, kind):
+    """The native system behind a plugin handle of that kind, or None for any other callable."""
+    return fn.system if isinstance(fn, _Plugin) and fn.kind == kind else None
+
+
 class NativeSystem(object):
     """Base class: owns the parameter block and a small engine used to evaluate the handles."""
     model = None

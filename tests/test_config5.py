@@ -197,3 +197,64 @@ def test_full_size_config5_invariants():
     np.testing.assert_array_equal(ign, want)
     end, steps, hits = eng.plan_best()
     assert hits == int(in_goal.sum()) > 0 and in_goal[end]
+
+
+def _inside_any_box(P, lo, hi, order=None):
+    """Closed-box membership of every point of P (B, 3) in 100k boxes, in NumPy: the boxes' half-extents are below 0.5, so a box that
+    holds p has lo_x in [p_x - 1.001, p_x] -- the candidates of a point are a contiguous run of the boxes sorted by lo_x, and those are
+    tested with the plain comparisons.  `order=None` tests every box for every point (the brute force proper; subsets only)."""
+    if order is None:
+        out = np.zeros(len(P), dtype=bool)
+        for a in range(0, len(P), 256):
+            p = P[a:a + 256, None, :]
+            out[a:a + 256] = np.any(np.all((p >= lo[None]) & (p <= hi[None]), axis=2), axis=1)
+        return out
+    slo, shi = lo[order], hi[order]
+    first = np.searchsorted(slo[:, 0], P[:, 0] - 1.001, side="left")
+    last = np.searchsorted(slo[:, 0], P[:, 0], side="right")
+    out = np.zeros(len(P), dtype=bool)
+    width = int((last - first).max())
+    for a in range(0, len(P), 2048):
+        f = first[a:a + 2048]
+        idx = np.minimum(f[:, None] + np.arange(width)[None, :], len(slo) - 1)
+        live = (f[:, None] + np.arange(width)[None, :]) < last[a:a + 2048, None]
+        p = P[a:a + 2048, None, :]
+        out[a:a + 2048] = np.any(live & np.all((p >= slo[idx]) & (p <= shi[idx]), axis=2), axis=1)
+    return out
+
+
+@pytest.mark.gpu
+def test_feasible_batch_full_obstacle_count_vs_numpy():
+    """is_feasible of config 5 at its full obstacle count: 100 000 states, most of them ON or one ulp beside a face of one of the 100 000
+    boxes, against NumPy (exact booleans).  The device looks boxes up through its CSR grid; NumPy tests the boxes themselves."""
+    import lqrrt_amd
+    s = lqrrt_amd.systems.DoubleIntegrator(n_boxes=100000, seed=0)
+    lo, hi = np.ascontiguousarray(s.obs[:, :3]), np.ascontiguousarray(s.obs[:, 3:])
+    assert float((hi - lo).max()) < 1.0
+    rng = np.random.RandomState(21)
+    B = 100000
+    X = np.zeros((B, 12))
+    X[:, 3:] = rng.uniform(-2, 2, (B, 9))
+    X[:, :3] = rng.uniform(-1.0, 101.0, (B, 3))                     # a slab of free-flying points, some outside the boxes' volume
+    pick = rng.randint(0, len(lo), B)
+    dim = rng.randint(0, 3, B)
+    side = rng.randint(0, 2, B)
+    kind = rng.randint(0, 4, B)                                     # 0: leave uniform | 1: on the face | 2: one ulp outside | 3: one ulp inside
+    inside_pt = lo[pick] + (hi[pick] - lo[pick]) * rng.random_sample((B, 3))
+    face = np.where(side == 0, lo[pick, dim], hi[pick, dim])
+    outward = np.where(side == 0, -np.inf, np.inf)
+    coord = np.where(kind == 1, face, np.where(kind == 2, np.nextafter(face, outward), np.nextafter(face, -outward)))
+    rows = np.nonzero(kind > 0)[0]
+    X[rows, :3] = inside_pt[rows]
+    X[rows, dim[rows]] = coord[rows]
+    order = np.argsort(lo[:, 0], kind="stable")
+    want_inside = _inside_any_box(X[:, :3], lo, hi, order)
+    sub = rng.choice(B, 3000, replace=False)
+    np.testing.assert_array_equal(want_inside[sub], _inside_any_box(X[sub, :3], lo, hi))      # the slab search == every box, on a subset
+    assert 0.3 < want_inside.mean() < 0.7                           # both answers are well represented
+    eng = s._engine()
+    got = np.concatenate([eng.feasible_batch(X[a:a + 25000]) for a in range(0, B, 25000)])
+    np.testing.assert_array_equal(got, ~want_inside)
+    # on-face points are inside (closed boxes), their outward neighbours are outside unless another box holds them
+    on_face = rows[kind[rows] == 1]
+    assert not got[on_face].any()

@@ -65,14 +65,3 @@ def test_rollout_wavefront_modes_match(wavefronts):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "50", str(50 + wavefronts)],
                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-
-
-def test_idle_deferral_of_rounds_2_and_3_matches():
-    """Since round 4 a sample whose wanted in-wave parent is being redone steers from its best STANDING candidate instead of
-    waiting idly (kernels.hpp, fused round prologue); LQRRT_SECOND_CHOICE=0 keeps the old schedule.  Both reach the same fixed
-    point -- the sequential loop's tree, planner.py:236-257 -- bit for bit.  Own process: the switch is read once."""
-    import subprocess
-    env = dict(os.environ, LQRRT_SECOND_CHOICE="0")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "50", "61"],
-                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

@@ -101,6 +101,27 @@ def test_bit_exact_double_integrator_dense_S():
     _compare(eng, stats, o)
 
 
+def test_bit_exact_config5_full_obstacle_count():
+    """BASELINE.json config 5 with its FULL obstacle table: 100 000 boxes, 5 000 nodes, against the sequential C oracle, whose
+    feasibility test is a brute-force sweep over every box (~1e10 box tests: about a minute of one host core).  The device finds the
+    boxes near a state through a CSR grid over their bounding volume (engine_geometry.hpp build_box_grid): a false ACCEPT there would
+    show in the brute-forced invariants of tests/test_config5.py, a false REJECT -- a feasible step called infeasible, a shorter edge,
+    another tree -- only here.  Parents, edge lengths, states, gains, edges, ignore set, counters: bit for bit."""
+    import coracle
+    s, eng, stats = _engine_run("double_integrator", 5000, 1024, n_boxes=100000, seed_boxes=0)
+    assert s.obs.shape == (100000, 6)
+    o = coracle.make(s, 5000 + 1024 + 8, seed=1)
+    assert o.extend(max_nodes=5000) == 2
+    assert eng.size == 5001
+    _compare(eng, stats, o)
+    # every edge row, not five edges: a truncated edge anywhere would show
+    xe, ue, ln = eng.edges()
+    for ID in range(0, eng.size, 7):
+        ox, ou = o.edge(ID)
+        assert int(ln[ID]) == len(ox)
+        np.testing.assert_array_equal(xe[ID, :len(ox)], ox)
+
+
 def test_bit_exact_boat_novice_5k_config3():
     """BASELINE.json config 3 (demo_boat_novice, 5k nodes).  With the demo's loose error_tol = [3,3,inf..]
     the tree saturates below 1000 nodes (the last 100 of 1000 nodes cost 75k attempts), so

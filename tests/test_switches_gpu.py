@@ -38,7 +38,7 @@ print("TREE", eng.size, stats.attempts, stats.goal_hits, h.hexdigest())
 
 def _run(env_extra):
     env = dict(os.environ)
-    for k in ("LQRRT_REFILL_AHEAD", "LQRRT_IGNORE_PATCH", "LQRRT_FUSED_ROUNDS", "LQRRT_STEER_WAVEFRONTS", "LQRRT_SECOND_CHOICE"):
+    for k in ("LQRRT_FUSED_ROUNDS", "LQRRT_STEER_WAVEFRONTS", "LQRRT_NN_WG4", "LQRRT_EXACT_WAVE_MAX", "LQRRT_MATRIX_MAX_W"):
         env.pop(k, None)
     env.update(env_extra)
     out = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
@@ -51,9 +51,11 @@ def test_switches_do_not_change_the_tree():
     base = _run({})
     size, attempts, hits = (int(x) for x in base.split()[1:4])
     assert size > 7000 and attempts > 20000 and hits > 10            # the run is long enough to go through every mechanism
-    for env in ({"LQRRT_REFILL_AHEAD": "0"}, {"LQRRT_IGNORE_PATCH": "0"}, {"LQRRT_FUSED_ROUNDS": "0"},
-                {"LQRRT_STEER_WAVEFRONTS": "2"}, {"LQRRT_SECOND_CHOICE": "0"},
-                {"LQRRT_REFILL_AHEAD": "0", "LQRRT_IGNORE_PATCH": "0", "LQRRT_STEER_WAVEFRONTS": "2", "LQRRT_SECOND_CHOICE": "0"}):
+    # (round 6 removed the switches whose A/B is settled -- LQRRT_SECOND_CHOICE, _IGNORE_PATCH, _REFILL_AHEAD, _SHARD_FOLD -- with the
+    #  code paths they selected; what is left are forms that are all still in use somewhere: large waves, sharded waves, large tables)
+    for env in ({"LQRRT_FUSED_ROUNDS": "0"}, {"LQRRT_STEER_WAVEFRONTS": "2"}, {"LQRRT_NN_WG4": "1"},
+                {"LQRRT_EXACT_WAVE_MAX": "1024", "LQRRT_MATRIX_MAX_W": "128"},
+                {"LQRRT_FUSED_ROUNDS": "0", "LQRRT_STEER_WAVEFRONTS": "2", "LQRRT_NN_WG4": "1"}):
         assert _run(env) == base, env
 
 

@@ -52,9 +52,11 @@ def test_user_system_host_description():
     s = plan_unicycle.make_system()
     d, keep = s.desc()
     assert (d.model, d.nstates, d.ncontrols, d.n_params, d.n_obstacles) == (100, 4, 2, 6, 24)
-    with pytest.raises(ValueError):
-        import lqrrt_amd
-        lqrrt_amd.Planner(lambda x, u, dt: x, s.lqr, lqrrt_amd.Constraints(4, 2, s.goal_buffer, s.is_feasible), horizon=2)
+    import lqrrt_amd
+    native = lqrrt_amd.Planner(s.dynamics, s.lqr, lqrrt_amd.Constraints(4, 2, s.goal_buffer, s.is_feasible), horizon=2, erf=s.erf)
+    assert not native.callback_mode and native.system is s
+    mixed = lqrrt_amd.Planner(lambda x, u, dt: x, s.lqr, lqrrt_amd.Constraints(4, 2, s.goal_buffer, s.is_feasible), horizon=2, erf=s.erf)
+    assert mixed.callback_mode                       # one plain Python callable: the host loop (lqrrt_amd/callback.py)
 
 
 USER_ORACLE = os.path.join(ROOT, "examples", "user_system", "liblqrrt_unicycle_oracle.so")

@@ -103,8 +103,11 @@ def main():
     print("accepted: %.1f %%; attempts whose parent was created within the last 64 / 256 / 1024 attempts: %.1f / %.1f / %.1f %%"
           % (100.0 * acc[k0:k1].mean(), *[100.0 * np.mean([t - dep_parent[t] <= w and dep_parent[t] >= 0 for t in T]) for w in (64, 256, 1024)]))
 
-    def wave_depths(a, b, cut_hits):
-        """dependency depth of every attempt of the wave [a, b) against the snapshot at a"""
+    def wave_depths(a, b, cut_hits, hit_lag=1):
+        """dependency depth of every attempt of the wave [a, b) against the snapshot at a.  hit_lag: rounds between the round that
+        makes a goal hit final and the round in which the samples it affects re-select (1: the device applies it itself; 2: the HOST
+        applies it -- it hears of the hit when that round closes, by which time the next round is already enqueued, so the changed
+        ignore words ride with the round after)"""
         depth = {}
         for t in range(a, b):
             d = 0
@@ -114,7 +117,7 @@ def main():
             if not cut_hits:
                 for h in dep_hits[t]:
                     if h >= a:
-                        d = max(d, depth[h] + 1)
+                        d = max(d, depth[h] + hit_lag)
             depth[t] = d
         return depth
 
@@ -146,6 +149,38 @@ def main():
         s = 1024.0 / len(T)
         print("   W  = %4d: %5.1f waves, %5.1f repair rounds -> %5.1f full slots (+ %4.1f confirm + append launches)"
               % (W, waves * s, rounds * s, (waves + rounds) * s, waves * s))
+    # Round 6: schedule B re-priced as it could be BUILT today -- hits applied by the host (the host hears every
+    # round's summary and already passes ignore words as scan arguments), only the samples whose chosen node lies on the new path
+    # re-select (that is what dep_hits holds: the hits that changed a sample's choice), the second-choice rule for deferred samples
+    # (it removes idle rounds, not dependencies: the bound is unchanged by it).  Every uncut wave still needs the scan of its
+    # goal-biased remainder after a hit; that scan rides with a round and is not counted as a slot.
+    print("B'. waves not cut at goal hits, hits applied by the HOST (two rounds after the hit is final):")
+    resB = {}
+    for W in (128, 256, 512, 1024):
+        a, waves, rounds = k0, 0, 0
+        while a < k1:
+            b = min(a + W, k1)
+            dp = wave_depths(a, b, False, hit_lag=2)
+            rounds += max(dp.values())
+            waves += 1
+            a = b
+        s = 1024.0 / len(T)
+        resB[W] = (waves + rounds) * s
+        print("   W  = %4d: %5.1f waves, %5.1f repair rounds -> %5.1f full slots" % (W, waves * s, rounds * s, (waves + rounds) * s))
+    a, wavesA, roundsA = k0, 0, 0
+    while a < k1:
+        b = min(a + 256, k1)
+        hit = np.nonzero(is_hit[a:b])[0]
+        if len(hit):
+            b = a + hit[0] + 1
+        roundsA += max(wave_depths(a, b, True).values())
+        wavesA += 1
+        a = b
+    slotsA = (wavesA + roundsA) * 1024.0 / len(T)
+    print("   schedule A (today's, W <= 256): %.1f slots; best buildable B': %.1f slots at W = %d -> bound on the gain in slots: %+.1f %%"
+          % (slotsA, min(resB.values()), min(resB, key=resB.get), 100.0 * (slotsA / min(resB.values()) - 1.0)))
+    print("   (a slot of a 1024-sample wave is not the slot of a 256-sample wave: beyond 256 samples a wave leaves the fused rounds -- the round")
+    print("    prologue keeps 4 x 64 flags in registers -- and beyond 341 rollouts the chain rollout's three wavefronts share SIMDs)")
     print("C. sliding window (every launch is a round for all samples in flight; a sample is final in the round that decides it from final")
     print("   inputs; a final hit is applied when that round closes; entrants are scanned `lag` rounds after the slot was freed):")
     for lag in (1, 2):

@@ -10,7 +10,7 @@ for seed in 801 802 803 804; do run 400 $seed; done
 echo "# LQRRT_POISON=1, seeds 811 812" >> $out
 for seed in 811 812; do LQRRT_POISON=1 run 400 $seed; done
 for sw in LQRRT_STEER_WAVEFRONTS=2 LQRRT_STEER_WAVEFRONTS=3 LQRRT_DARE_WAVEFRONTS=1 LQRRT_DARE_WAVEFRONTS=4 LQRRT_NN_WG4=1 \
-          LQRRT_SHARD_FOLD=0 LQRRT_SECOND_CHOICE=0 LQRRT_FUSED_ROUNDS=0 LQRRT_IGNORE_PATCH=0 LQRRT_MATRIX_MAX_W=0; do
+           LQRRT_FUSED_ROUNDS=0 LQRRT_MATRIX_MAX_W=0; do
   echo "# $sw, seed 821, 300 cases" >> $out
   env $sw timeout 1500 python tools/fuzz_parity.py 300 821 2>&1 | grep -v amdgpu.ids | tail -1 >> $out
 done
