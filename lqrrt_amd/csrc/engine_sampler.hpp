@@ -38,7 +38,19 @@ static inline void candidate_row(lqrrt_engine* e, double* c) {
 static const int SAMPLER_BLOCK = 16384;
 // A refill draws ~230k MT19937 numbers (~0.6 ms on the host) while the GPU idles; the host, on the other hand, idles while
 // the GPU works through repair rounds.  This generates up to `rows` candidates of the NEXT refill during such a wait.
+// mt_base is the generator positioned at candidate row base_row <= committed_row; whoever needs the stream AT the committed row
+// (lqrrt_engine_get_mt19937 when a plan ends or is killed, a change of goal / sampler / world) replays the rows in between.  After a
+// long plan that replay was milliseconds on the path of a kill (2.4 M draws after 0.4 s of planning): the base is moved up in the
+// host's waits for the repair rounds instead, a few hundred rows at a time, so that what is left to replay is one wave's worth.
+static void advance_stream_base(lqrrt_engine* e, int64_t max_rows) {
+    const int64_t todo = std::min(max_rows, e->committed_row - e->base_row);
+    if (todo <= 0) return;
+    for (int64_t i = 0; i < todo * (int64_t)(e->n + 1); ++i) (void)e->mt_base.next_double();
+    e->base_row += todo;
+}
+
 static void pregenerate_candidates(lqrrt_engine* e, int rows) {
+    advance_stream_base(e, 4 * (int64_t)rows);
     if (e->explicit_samples || !e->has_sampler || !e->has_goal || e->pregen_rows >= SAMPLER_BLOCK) return;
     if (e->rf_stage == 1) return;                                 // the full block in `pregen` is being copied out: leave it alone
     if (e->pregen.size() < (size_t)SAMPLER_BLOCK * e->n) e->pregen.resize((size_t)SAMPLER_BLOCK * e->n);

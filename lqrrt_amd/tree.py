@@ -51,7 +51,14 @@ class _Snapshot(object):
     def __init__(self, e):
         self.size = e.size
         self._state, self._pid, self._K = e.states(), e.parents(), e.gains()
-        self._xe, self._ue, self._ln = e.edges(pinned=True)
+        # The edges leave HBM through page-locked staging (PCIe speed) and are kept COMPACTED in ordinary memory: rows beyond an edge's
+        # length are dropped (a tree's edges fill ~40 % of the fixed-stride pools) and the staging buffers go back to torch's caching host
+        # allocator, which hands the same blocks to the next detach -- a kept Tree pins nothing.
+        xe, ue, ln = e.edges(pinned=True)
+        live = np.arange(xe.shape[1])[None, :] < ln[:, None]
+        self._xe, self._ue = xe[live], ue[live]
+        self._off = np.concatenate(([0], np.cumsum(ln, dtype=np.int64)))
+        del xe, ue
 
     def states(self):
         return self._state
@@ -63,8 +70,8 @@ class _Snapshot(object):
         return self._K
 
     def edge(self, i):
-        n = int(self._ln[i])
-        return self._xe[i, :n], self._ue[i, :n]
+        a, b = int(self._off[i]), int(self._off[i + 1])
+        return self._xe[a:b], self._ue[a:b]
 
 
 class Tree:
@@ -200,6 +207,17 @@ class Tree:
         """Node IDs from the seed (first element, 0) down to ID (last element) -- tree.py:100-117."""
         if ID >= self.size or ID < 0:
             raise ValueError("The given ID, {}, doesn't exist.".format(ID))
+        if self._e is not None and "pID" not in self._fresh() and ID < self._ndev():
+            # a tree that is still growing on the device: follow the parents one read at a time (a path is tens of nodes; the whole
+            # parent array of a 200k-node tree is a 5 ms copy -- on the path of kill_update, tests/test_control_gpu.py)
+            e, chain = self._dev(), [int(ID)]
+            while True:
+                parent = int(e.parents(chain[-1], 1)[0])
+                if parent == -1:
+                    break
+                chain.append(parent)
+            chain.reverse()
+            return chain
         parents = self.pID
         chain = [int(ID)]
         while parents[chain[-1]] != -1:

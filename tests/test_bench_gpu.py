@@ -52,6 +52,18 @@ def test_bench_line_fields():
     assert rp["max"] < 1.5 * rp["min"]                              # back-to-back regions on one box agree
     # whatever is copied from a committed profile says so
     assert d["roofline"]["traffic"] is None or d["roofline"]["traffic_static_from"].startswith("profiles/")
+    # round 6, all live: the kernel that holds the GPU time, the dependency bound the run measures for it, the scan against its own best
+    dk = d["dominant_kernel"]
+    assert "k_steer" in dk["name"] and 0.7 < dk["share_of_event_timed_gpu_time"] < 1.0 and 2.0 < dk["launches_per_wave"] < 12.0
+    cb = d["chain_bound"]
+    assert 20.0 < cb["chain_slots_per_1024"] <= cb["launches_run_per_1024"]          # a lower bound on what the loop runs
+    assert 8.0 < cb["rollout_probe"]["full_horizon_rollout_launch_us"] < 60.0 and cb["rollout_probe"]["full_horizon_launches"] > 0
+    assert 0.1 < cb["frac_of_chain_bound"] < 1.0
+    ob = d["roofline"]["vs_own_best"]
+    assert ob["pairs_per_s_best"] > ob["pairs_per_s_in_loop"] > 0 and abs(ob["frac"] - ob["pairs_per_s_in_loop"] / ob["pairs_per_s_best"]) < 1e-12
+    assert not any(k.endswith("static_from") for k in list(dk) + list(cb) + list(ob))
+    cm = c["callback_mode"]                                             # plain Python plugins, nearest-neighbour stage on the GPU
+    assert cm["value"] > 3 * c["value"] and cm["vs_numpy_oracle_same_plugins"] == cm["value"] / c["value"]
 
 
 def test_bench_sharded_code_path_world_of_one():

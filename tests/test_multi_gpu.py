@@ -299,3 +299,83 @@ def test_update_plans_mixed_jobs_on_the_car():
         assert a.plan_reached_goal == b.plan_reached_goal and list(a.node_seq) == list(b.node_seq)
         np.testing.assert_array_equal(np.array(a.x_seq), np.array(b.x_seq))
         np.testing.assert_array_equal(np.array(a.u_seq), np.array(b.u_seq))
+
+
+def test_update_plans_groups_are_independent_fleets():
+    """Planners of different devices form groups that run their own shared loops on host threads, with nothing exchanged between them
+    (the multi-GPU form of this path that scales: one fleet per device).  On a one-GPU box the `group` key makes two groups of device
+    0 stand in for two devices: every planner still grows the tree it grows alone, and groups may differ in what a group must share
+    (here: the node limit)."""
+    import lqrrt_amd
+
+    def mk(max_nodes, device=0):
+        s = lqrrt_amd.systems.SYSTEMS["boat_advanced"](0)
+        cons = lqrrt_amd.Constraints(s.nstates, s.ncontrols, s.goal_buffer, s.is_feasible)
+        kw = dict(s.plan_kwargs)
+        kw.update(error_tol=s.error_tol, erf=s.erf, min_time=2, max_time=3, max_nodes=max_nodes, goal0=s.goal,
+                  sys_time=lambda: 0.0, printing=False, wave_size=256, device=device)
+        return s, lqrrt_amd.Planner(s.dynamics, s.lqr, cons, **kw)
+
+    import torch
+    two = torch.cuda.device_count() >= 2
+    plan = [(900, 0, "a", 21), (900, 0, "a", 22), (900, 0, "a", 23), (1300, 1 if two else 0, "b", 24), (1300, 1 if two else 0, "b", 25)]
+    solo = []
+    for nodes, dev, _, sd in plan:
+        s, p = mk(nodes, dev)
+        np.random.seed(sd)
+        assert p.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10) is False
+        solo.append(p)
+    fleet = [mk(nodes, dev) for nodes, dev, _, _ in plan]
+    res = lqrrt_amd.update_plans([dict(planner=p, x0=s.x0, sample_space=s.sample_space, goal_bias=s.goal_bias, xrand_gen=10, seed=sd, group=grp)
+                                  for (s, p), (_, _, grp, sd) in zip(fleet, plan)])
+    assert res == [False] * len(plan)
+    for (s, p), q in zip(fleet, solo):
+        assert p.tree.size == q.tree.size and list(p.tree.pID) == list(q.tree.pID)
+        np.testing.assert_array_equal(p.tree.state, q.tree.state)
+        assert list(p.node_seq) == list(q.node_seq) and p.T == q.T
+    print("groups ran on %s" % ("two devices" if two else "one device (two groups of device 0)"))
+    # without the group key the two node limits cannot share native calls: refused before any planner is touched
+    untouched = [mk(nodes, 0) for nodes, _, _, _ in plan]
+    trees_before = [p.tree for _, p in untouched]
+    with pytest.raises(ValueError):
+        lqrrt_amd.update_plans([dict(planner=p, x0=s.x0, sample_space=s.sample_space, seed=1) for s, p in untouched])
+    assert [p.tree for _, p in untouched] == trees_before
+
+
+def test_update_plans_holds_every_planner_to_its_time_budget():
+    """with many jobs the wrap-up of finished planners must not be charged to the others' clocks.  16 planners, real clock,
+    a 0.25 s budget each: every planner's own elapsed time at its exit decision is within one shared native call of the budget, and
+    the whole call returns within the budget plus the (deferred) wrap-ups."""
+    import time
+    import lqrrt_amd
+    s0 = lqrrt_amd.systems.SYSTEMS["boat_advanced"](0)
+    fleet = []
+    for k in range(16):
+        s = lqrrt_amd.systems.SYSTEMS["boat_advanced"](0)
+        cons = lqrrt_amd.Constraints(s.nstates, s.ncontrols, s.goal_buffer, s.is_feasible)
+        kw = dict(s.plan_kwargs)
+        kw.update(error_tol=s.error_tol, erf=s.erf, min_time=0.25, max_time=0.25, max_nodes=60000, goal0=s.goal, sys_time=time.time,
+                  printing=False, wave_size=256)
+        fleet.append(lqrrt_amd.Planner(s.dynamics, s.lqr, cons, **kw))
+    jobs = [dict(planner=p, x0=s0.x0, sample_space=s0.sample_space, goal_bias=s0.goal_bias, seed=40 + k) for k, p in enumerate(fleet)]
+    lqrrt_amd.update_plans(jobs)                                    # warm: engines, kernels, sampler pools
+    exits = []
+    orig = lqrrt_amd.Planner._plan_after_call
+
+    def spy(self, run, st, dt_call, wrap_up=True):
+        over = orig(self, run, st, dt_call, wrap_up)
+        if over:
+            exits.append(run.time_elapsed)
+        return over
+    lqrrt_amd.Planner._plan_after_call = spy
+    try:
+        t0 = time.time()
+        res = lqrrt_amd.update_plans(jobs)
+        wall = time.time() - t0
+    finally:
+        lqrrt_amd.Planner._plan_after_call = orig
+    assert len(res) == 16 and len(exits) == 16
+    assert all(0.25 <= e < 0.25 + 0.03 for e in exits), exits       # the exit decision: at most one shared call past the budget
+    assert wall < 0.25 + 0.15, wall                                 # + 16 deferred wrap-ups (plan extraction, interpolators)
+    for p in fleet:
+        assert len(p.x_seq) == len(p.t_seq) and p.tree.size > 100

@@ -36,12 +36,34 @@ def build(header, out):
     done = subprocess.run(cmd + [kr.REMARK_FLAG], cwd=csrc, stderr=subprocess.PIPE, text=True)
     if done.returncode != 0:
         sys.stderr.write(done.stderr)
+        if asm is not None:
+            asm[0].wait()
+            if os.path.exists(asm[1]):
+                os.remove(asm[1])
         raise subprocess.CalledProcessError(done.returncode, cmd)
+    # the compiler's own diagnostics (warnings in the user's header: the one place users write device code) are passed on; the
+    # resource-usage remarks asked for above are not
+    noise = ("remark:", "-Rpass-analysis", "argument unused during compilation", "In file included from")
+    keep, skip = [], 0
+    for ln in done.stderr.splitlines():
+        if any(t in ln for t in noise):
+            skip = 2 if "remark:" in ln else 0                      # a remark is followed by its source line and a caret line
+            continue
+        if skip > 0 and (ln.strip().startswith(("|", "^")) or "|" in ln[:12]):
+            skip -= 1
+            continue
+        skip = 0
+        keep.append(ln)
+    if any(ln.strip() for ln in keep):
+        sys.stderr.write("\n".join(keep) + "\n")
     if "Function Name" in done.stderr:
         kr.store("remarks", [define], done.stderr)
-    if asm is not None and asm[0].wait() == 0:
-        os.replace(asm[1], kr.cache_file("s", [define]))
-        kr.prune(protect=(kr.source_key([define]),))
+    if asm is not None:
+        if asm[0].wait() == 0:
+            os.replace(asm[1], kr.cache_file("s", [define]))
+            kr.prune(protect=(kr.source_key([define]),))
+        elif os.path.exists(asm[1]):
+            os.remove(asm[1])
     return os.path.abspath(out)
 
 
