@@ -13,7 +13,7 @@
 static int generic_width(const lqrrt_engine* e) { return e->n < 8 ? 7 : 12; }
 
 // partial minima of a generic scan: per sample, per 256-node workgroup, {eligible, overall}
-static size_t generic_blocks(const lqrrt_engine* e) { return ((size_t)e->cap + 255) / 256; }
+static size_t generic_blocks(const lqrrt_engine* e) { return std::min<size_t>(((size_t)e->cap + 255) / 256, 4096); }
 
 static int generic_create(lqrrt_engine* e, const lqrrt_system_desc* sys) {
     // params[0] = number of angular states, params[1 ..] their indices (ascending, distinct)
@@ -88,7 +88,7 @@ static int generic_nn(lqrrt_engine* e, const GenericQuery* q, bool dense, const 
                       int32_t* id_dev, double* cost_dev, hipStream_t st, double seq, const double* errors_dev = nullptr) {
     GenericView v = generic_view(e, use_ignore);
     v.errors = errors_dev;
-    const int nb = (e->N + 255) / 256;
+    const int nb = std::min((e->N + 255) / 256, 4096);       // beyond a million nodes a workgroup strides over several 256-node tiles
     dim3 grid(nb, W);
     GenericQuery q0;
     if (!q) { memset(&q0, 0, sizeof q0); q = &q0; }

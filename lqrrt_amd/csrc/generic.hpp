@@ -76,7 +76,7 @@ __device__ __forceinline__ double generic_cost(const GenericView& v, const Gener
     return quad_cost<GenN<N>, DENSE>(e, Sd);
 }
 
-// grid = (ceil(count / 256), W), block = 256.  BYVAL: the one query is `q`, an argument of the launch (its S is read by the scalar unit
+// grid = (min(ceil(count / 256), 4096), W), block = 256, grid-stride over the nodes.  BYVAL: the one query is `q`, an argument of the launch (its S is read by the scalar unit
 // straight from the argument block); else xs [W][n] on the device and Sdev, one dense matrix for all samples (device) or null.
 // (Two instantiations rather than a run-time choice of where S lives: a pointer that may point into the argument block makes the
 // compiler copy the block to scratch.)
@@ -97,15 +97,15 @@ __global__ __launch_bounds__(256) void k_generic_scan(GenericView v, GenericShap
         if ((int)threadIdx.x < 2 * sh.nw) gtrig[threadIdx.x] = q.trig[threadIdx.x];
     }
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
     Best2 b{INFINITY, INFINITY, -1, -1};
-    if (i < v.count) {
+    // grid-stride over the nodes (coalesced: consecutive lanes, consecutive nodes); ascending ids per lane + strict '<' keep the lowest id
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < v.count; i += 256 * (int)gridDim.x) {
         double c;
         if constexpr (BYVAL) c = generic_cost<N, DENSE>(v, sh, xg, gtrig, q.S, i);
         else c = generic_cost<N, DENSE>(v, sh, xg, gtrig, Sdev, i);
         const bool el = !v.ignore || ((v.ignore[i >> 6] >> (i & 63)) & 1ull) == 0;
-        b.ca = c; b.ia = i;
-        if (el) { b.c = c; b.i = i; }
+        if (b.ia < 0 || c < b.ca) { b.ca = c; b.ia = i; }
+        if (el && (b.i < 0 || c < b.c)) { b.c = c; b.i = i; }
     }
     best2_wave(b);
     __shared__ double rc[4], rca[4];

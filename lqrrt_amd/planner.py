@@ -78,7 +78,11 @@ class Planner:
         self.printing = printing
         self.killed = False
         self.stats = None
-        self.xrand_gen_sees_tree = False        # True: a user sampling function is called once per iteration, on the current tree
+        # A user sampling function (xrand_gen = a callable, planner.py:213-216) is called once per iteration on the tree the previous
+        # iteration left, like the reference calls it (planner.py:236): one sample per native call.  False: a function that never looks at
+        # planner.tree / plan_reached_goal may be called a batch AHEAD of the waves that consume its samples (same samples, same tree, no
+        # host turn per iteration).
+        self.xrand_gen_sees_tree = True
         # HBM pools are sized by max_nodes (Engine.footprint(): ~1.7 kB per node for the boats with horizon_iters = 20, i.e. ~170 MB at
         # the reference's default of 1e5 nodes).  A planner built with an explicit max_nodes gets them now, outside any plan's time
         # budget; one left at the default gets them with its first update_plan -- or when the caller asks (warm_up()) -- so that a fleet
@@ -184,11 +188,10 @@ class Planner:
 
         run.user_sampler = not (xrand_gen is None or type(xrand_gen) is int)
         if run.user_sampler:
-            # planner.py:213-216.  The function is called once per sample, in order, but by default a batch ahead of the wave
-            # that consumes the samples: it then sees the tree as of the batch start, not of the previous iteration (the default
-            # sampler never looks at the tree).  A function that does read planner.tree / planner.plan_reached_goal sets
-            # `planner.xrand_gen_sees_tree = True`: one sample per native call, the reference's order of events exactly
-            # (planner.py:236 -- sample, extend, goal bookkeeping, next sample), at the price of a host turn per iteration.
+            # planner.py:213-216.  The function is called once per sample, in order: by default once per native call of ONE attempt --
+            # the reference's order of events exactly (planner.py:236: sample, extend, goal bookkeeping, next sample), so it may read
+            # planner.tree / planner.plan_reached_goal.  `planner.xrand_gen_sees_tree = False` lets a function that does not look at
+            # the tree be called a batch ahead of the wave that consumes the samples (it then sees the tree as of the batch start).
             if not _callable(xrand_gen):
                 raise ValueError("Expected xrand_gen to be None, an integer >= 1,  or a function.")
         else:

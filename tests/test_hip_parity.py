@@ -386,7 +386,7 @@ def test_finish_on_goal_and_user_sampler():
 
 def test_user_sampler_that_reads_the_tree():
     """planner.py:236: `xrand = xrand_gen(self)` runs at the top of EVERY iteration, so a sampling function may look at the
-    tree the previous iteration left.  With planner.xrand_gen_sees_tree = True the HIP planner keeps that order of events (one
+    tree the previous iteration left.  By default (planner.xrand_gen_sees_tree = True) the HIP planner keeps that order of events (one
     sample per native call); the function below samples around a random EXISTING node and stops exploring once a plan exists,
     so any staleness of the view changes the sample stream and with it the tree.  Against the NumPy oracle, iteration by
     iteration."""
@@ -407,7 +407,7 @@ def test_user_sampler_that_reads_the_tree():
 
     c = _system("car")
     p = _planner(c, 250, wave_size=64)          # fake clock at 0: the plan ends when the tree outgrows max_nodes
-    p.xrand_gen_sees_tree = True
+    assert p.xrand_gen_sees_tree is True        # the reference's order of events is the default
     fn, seen = make_sampler(5, c.sample_space)
     assert p.update_plan(c.x0, c.sample_space, xrand_gen=fn) is False
     rc = SYSTEMS["car"](0)
@@ -418,11 +418,12 @@ def test_user_sampler_that_reads_the_tree():
     assert p.tree.size == ref.tree.size and list(p.tree.pID) == list(ref.tree.pID)
     np.testing.assert_allclose(p.tree.state, np.array(ref.tree.state), rtol=0, atol=ATOL)
     assert p.plan_reached_goal == ref.plan_reached_goal
-    # the default (batched) form calls the function the same number of times but ahead of the wave: it must still run
+    # the batched form (opt-in, for functions that do not look at the tree) calls the function ahead of the wave: it must still run
     q = _planner(c, 250, wave_size=64)
+    q.xrand_gen_sees_tree = False
     fn_q, seen_q = make_sampler(5, c.sample_space)
     q.update_plan(c.x0, c.sample_space, xrand_gen=fn_q)
-    assert q.tree.size > 1 and seen_q != seen_ref             # (a stale view: which is why the switch exists)
+    assert q.tree.size > 1 and seen_q != seen_ref             # (a stale view: which is why it is not the default)
 
 
 def test_replanning_and_control_surface():

@@ -376,6 +376,8 @@ def test_update_plans_holds_every_planner_to_its_time_budget():
         lqrrt_amd.Planner._plan_after_call = orig
     assert len(res) == 16 and len(exits) == 16
     assert all(0.25 <= e < 0.25 + 0.03 for e in exits), exits       # the exit decision: at most one shared call past the budget
-    assert wall < 0.25 + 0.15, wall                                 # + 16 deferred wrap-ups (plan extraction, interpolators)
+    # outside every planner's clock, inside this wall time: set-up (16 trees of the previous plans detached: bulk copies out of HBM)
+    # and the 16 deferred wrap-ups (plan extraction, interpolators)
+    assert wall < 0.25 + 0.5, wall
     for p in fleet:
         assert len(p.x_seq) == len(p.t_seq) and p.tree.size > 100

@@ -93,7 +93,7 @@ def main():
         "fetch_correction": 2.0,
         "hbm_bytes_per_launch": (2.0 * kf["per_launch"]["FETCH_SIZE"] + kw["per_launch"]["WRITE_SIZE"]) * 1024.0,
         "steady_state_avg_launch_ns": 0.5 * (kf["avg_ns"] + kw["avg_ns"]),
-        "note": "writes dominate: every (sample, node chunk) pair stores one 12-byte partial minimum, sample-major so that the steer "
+        "note": "writes dominate: every (sample, node chunk) pair stores ONE 16-byte partial minimum (round 6; two stores of 8 + 4 bytes before: WRITE_SIZE 3.37 -> 2.30 MB per launch), sample-major so that the steer prologue reads a sample's partials contiguously; every lane's store is its own memory transaction"
                 "prologue reads a sample's partials contiguously; the scattered 8-byte stores count as 64-byte memory transactions",
     }
     json.dump(traffic, open(os.path.join(out, "%s_nn_traffic.json" % rnd), "w"), indent=1)
