@@ -68,7 +68,8 @@ extern "C" {
                                              * host, in the reference's order (lqrrt_amd/callback.py), and the engine holds what the
                                              * reference spends 74-95 % of its time on: the node table (SoA states + cos/sin of the angular
                                              * ones, parents, ignore set) and Planner._costs_to_go + the nearest selection
-                                             * (planner.py:239-247, 340-350).  lqrrt_system_desc: nstates 1..LQRRT_MAX_STATES, ncontrols (kept,
+                                             * (planner.py:239-247, 340-350).  lqrrt_system_desc: nstates 1..64 (beyond LQRRT_MAX_STATES the state dimension is a run-time value of the
+                                             * kernels: host-form queries only), ncontrols (kept,
                                              * not used), params[0] = number of angular states (erf wraps them, e.g. demo_car.py:115-126),
                                              * params[1..] = their indices, ascending; no geometry.  Entry points that work: lqrrt_engine_create /
                                              * destroy, lqrrt_tree_reset / load / append / truncate / mark / rewind / size / set_ignored /

@@ -21,7 +21,8 @@ which is said once when `printing` is on.
 
 Results: the tree of the reference's own Planner on the same np.random stream -- parents, edge lengths and the generator's
 end state exactly, floating point to what the user's NumPy functions reproduce (tests/test_callback_gpu.py replays the
-reference's fixtures from plain Python plugins).  There is no CPU path: without the HIP library and a device this mode raises.
+reference's fixtures from plain Python plugins).  Up to 64 states per node (12 with compile-time kernels, beyond that the state
+dimension is a run-time value of the scan).  There is no CPU path: without the HIP library and a device this mode raises.
 """
 from __future__ import division
 

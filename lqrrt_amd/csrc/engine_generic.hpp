@@ -18,18 +18,33 @@ static size_t generic_blocks(const lqrrt_engine* e) { return std::min<size_t>(((
 static int generic_create(lqrrt_engine* e, const lqrrt_system_desc* sys) {
     // params[0] = number of angular states, params[1 ..] their indices (ascending, distinct)
     const int n = sys->nstates;
-    if (n < 1 || n > LQRRT_MAX_STATES) return fail(LQRRT_E_ARG, "LQRRT_MODEL_GENERIC: nstates must be 1..%d, got %d", LQRRT_MAX_STATES, n);
+    if (n < 1 || n > GENERIC_WIDE_MAX) return fail(LQRRT_E_ARG, "LQRRT_MODEL_GENERIC: nstates must be 1..%d, got %d", (int)GENERIC_WIDE_MAX, n);
     if (sys->ncontrols < 0) return fail(LQRRT_E_ARG, "LQRRT_MODEL_GENERIC: bad ncontrols");
     if (sys->n_params < 1) return fail(LQRRT_E_ARG, "LQRRT_MODEL_GENERIC: params[0] must hold the number of angular states");
     const int nw = (int)sys->params[0];
     if (nw < 0 || nw > n || sys->n_params < 1 + nw || (double)nw != sys->params[0]) return fail(LQRRT_E_ARG, "LQRRT_MODEL_GENERIC: bad number of angular states");
     memset(&e->gsh, 0, sizeof e->gsh);
     e->gsh.n = n; e->gsh.nw = nw;
+    e->wide = n > LQRRT_MAX_STATES;
+    e->h_wk.assign((size_t)n, -1);
+    int prev = -1;
     for (int k = 0; k < nw; ++k) {
         const int d = (int)sys->params[1 + k];
-        if (d < 0 || d >= n || (double)d != sys->params[1 + k] || (k > 0 && d <= e->gsh.wd[k - 1]))
+        if (d < 0 || d >= n || (double)d != sys->params[1 + k] || d <= prev)
             return fail(LQRRT_E_ARG, "LQRRT_MODEL_GENERIC: angular state indices must be distinct, ascending and < nstates");
-        e->gsh.wd[k] = d;
+        prev = d;
+        if (k < MAXN) e->gsh.wd[k] = d;
+        e->h_wk[(size_t)d] = k;
+    }
+    if (e->wide) {
+        // wide tables: the state dimension is a run-time value of the kernels (generic.hpp, k_generic_scan_wide)
+        const size_t qn = (size_t)n + 2 * (size_t)nw + (size_t)n * n;
+        TRY(dalloc(&e->d_wk, (size_t)n));
+        HIPCHK(hipMemcpy(e->d_wk, e->h_wk.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+        for (int s2 = 0; s2 < 2; ++s2) {
+            TRY(dalloc(&e->d_wq[s2], qn));
+            if (hipHostMalloc((void**)&e->h_wq[s2], sizeof(double) * qn, hipHostMallocDefault) != hipSuccess) return fail(LQRRT_E_HIP, "hipHostMalloc failed");
+        }
     }
     e->generic = true;
     e->n = n; e->m = sys->ncontrols; e->nw = nw;
@@ -88,6 +103,20 @@ static int generic_nn(lqrrt_engine* e, const GenericQuery* q, bool dense, const 
                       int32_t* id_dev, double* cost_dev, hipStream_t st, double seq, const double* errors_dev = nullptr) {
     GenericView v = generic_view(e, use_ignore);
     v.errors = errors_dev;
+    if (e->wide) {
+        if (xs) return fail(LQRRT_E_STATE, "the device-form batch query serves tables of up to %d states; use lqrrt_nn_argmin_host", LQRRT_MAX_STATES);
+        const int nbw = std::min((e->N + 63) / 64, 4096);
+        WideArgs a;
+        a.q = e->d_wq[0]; a.wk = e->d_wk; a.n = e->n; a.nw = e->gsh.nw;
+        const size_t lds = sizeof(double) * 64 * (size_t)e->n;
+        if (dense) hipLaunchKernelGGL((k_generic_scan_wide<true>), dim3(nbw), dim3(64), lds, st, v, a, e->d_pcost, e->d_pidx);
+        else hipLaunchKernelGGL((k_generic_scan_wide<false>), dim3(nbw), dim3(64), lds, st, v, a, e->d_pcost, e->d_pidx);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_generic_reduce, dim3(1), dim3(64), 0, st, e->d_pcost, e->d_pidx, nbw, id_dev, cost_dev, e->h_gres_dev, seq);
+        HIPCHK(hipGetLastError());
+        e->wide_append_pending = false;          // the caller waits for this query: everything queued before it has completed by then
+        return 0;
+    }
     const int nb = std::min((e->N + 255) / 256, 4096);       // beyond a million nodes a workgroup strides over several 256-node tiles
     dim3 grid(nb, W);
     GenericQuery q0;
@@ -111,6 +140,7 @@ static int generic_nn(lqrrt_engine* e, const GenericQuery* q, bool dense, const 
 }
 
 static int generic_costs(lqrrt_engine* e, const double* x_dev, const double* S_dev, double* cost_dev, hipStream_t st) {
+    if (e->wide) return fail(LQRRT_E_STATE, "lqrrt_costs_to_go serves generic tables of up to %d states", LQRRT_MAX_STATES);
     const GenericView v = generic_view(e, false);
     if (S_dev) {
         if (!e->d_Sop) TRY(dalloc(&e->d_Sop, (size_t)MAXN * MAXN));
@@ -127,7 +157,32 @@ static int generic_costs(lqrrt_engine* e, const double* x_dev, const double* S_d
     return 0;
 }
 
+// wide tables: x | trig | S of a query (slot 0) or x | trig of a new node (slot 1) into the slot's staging, copy queued on `st`
+static int wide_stage(lqrrt_engine* e, int slot, const double* x, const double* S, hipStream_t st) {
+    const int n = e->n, nw = e->gsh.nw;
+    double* h = e->h_wq[slot];
+    for (int j = 0; j < n; ++j) {
+        h[j] = x ? x[j] : 0.0;
+        const int k = e->h_wk[(size_t)j];
+        if (k >= 0) lq_sincos(h[j], &h[n + 2 * k + 1], &h[n + 2 * k]);
+    }
+    size_t count = (size_t)n + 2 * (size_t)nw;
+    if (S) { memcpy(h + count, S, sizeof(double) * n * n); count += (size_t)n * n; }
+    HIPCHK(hipMemcpyAsync(e->d_wq[slot], h, sizeof(double) * count, hipMemcpyHostToDevice, st));
+    return 0;
+}
+
 static int generic_put_node(lqrrt_engine* e, int i, int parent, const double* state, hipStream_t st) {
+    if (e->wide) {
+        // (slot 1's previous copy has completed: every append is followed by a query that waits for the stream's work up to itself,
+        //  and a second append without a query in between is ordered behind it by a stream wait)
+        if (e->wide_append_pending) HIPCHK(hipStreamSynchronize(st));
+        TRY(wide_stage(e, 1, state, nullptr, st));
+        e->wide_append_pending = true;
+        hipLaunchKernelGGL(k_generic_append_wide, dim3(1), dim3(192), 0, st, e->tv.state, e->tv.trig, e->tv.pID, e->cap, i, parent, e->n, e->gsh.nw, e->d_wq[1]);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     GenericQuery q;
     generic_fill_query(e, state, nullptr, &q);
     hipLaunchKernelGGL(k_generic_append, dim3(1), dim3(64), 0, st, e->tv.state, e->tv.trig, e->tv.pID, e->cap, i, parent, e->gsh, q);
@@ -162,7 +217,8 @@ static int generic_load(lqrrt_engine* e, int count, const double* states, const 
         HIPCHK(hipMemcpy(e->tv.state + (size_t)d * e->cap, soa.data(), sizeof(double) * count, hipMemcpyHostToDevice));
     }
     HIPCHK(hipMemcpy(e->tv.pID, pID, sizeof(int) * count, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_generic_trig, dim3((count + 255) / 256), dim3(256), 0, st, e->tv.state, e->tv.trig, e->cap, 0, count, e->gsh);
+    if (e->wide) hipLaunchKernelGGL(k_generic_trig_wide, dim3((count + 255) / 256), dim3(256), 0, st, e->tv.state, e->tv.trig, e->cap, count, e->n, e->d_wk);
+    else hipLaunchKernelGGL(k_generic_trig, dim3((count + 255) / 256), dim3(256), 0, st, e->tv.state, e->tv.trig, e->cap, 0, count, e->gsh);
     HIPCHK(hipGetLastError());
     e->h_pid.assign(pID, pID + count);
     e->h_elen.assign(count, 1);

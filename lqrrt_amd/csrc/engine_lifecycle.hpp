@@ -43,6 +43,11 @@ static void free_all(lqrrt_engine* e) {
     if (e->h_round) (void)hipHostFree(e->h_round);
     if (e->h_gres) (void)hipHostFree(e->h_gres);
     if (e->d_q) (void)hipFree(e->d_q);
+    if (e->d_wk) (void)hipFree(e->d_wk);
+    for (int s2 = 0; s2 < 2; ++s2) {
+        if (e->d_wq[s2]) (void)hipFree(e->d_wq[s2]);
+        if (e->h_wq[s2]) (void)hipHostFree(e->h_wq[s2]);
+    }
 }
 
 static int alloc_wave(lqrrt_engine* e) {

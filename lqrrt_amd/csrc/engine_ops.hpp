@@ -206,7 +206,8 @@ static int generic_query_host(lqrrt_engine* e, const double* x_host, const doubl
                               int32_t* id_out, double* cost_out, hipStream_t st) {
     TRY(flush_ignore(e, st, false));            // (the staging buffer is free: every earlier host-form call waited for its answer)
     GenericQuery q;
-    if (x_host) generic_fill_query(e, x_host, S_host, &q);
+    if (e->wide) TRY(wide_stage(e, 0, x_host, S_host, st));     // (slot 0 is free: the previous query was waited for)
+    else if (x_host) generic_fill_query(e, x_host, S_host, &q);
     else {
         const double zero[MAXN] = {0.0};
         generic_fill_query(e, zero, S_host, &q);

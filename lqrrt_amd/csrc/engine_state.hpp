@@ -52,6 +52,13 @@ struct lqrrt_engine {
     double* h_gres_dev = nullptr;
     double gseq = 0.0;
     double* d_q = nullptr;        // compiled-in models: device staging of a host-form query [n + n*n] and its answer
+    // wide generic tables (12 < n <= 64, generic.hpp): angular-state map, query / append staging (two slots each: an append may still be
+    // copying when the next query is being filled)
+    bool wide = false, wide_append_pending = false;
+    int* d_wk = nullptr;
+    std::vector<int> h_wk;
+    double* d_wq[2] = {nullptr, nullptr};
+    double* h_wq[2] = {nullptr, nullptr};
     Params P;
     Geo geo{};
     Res res{};

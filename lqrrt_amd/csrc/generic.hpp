@@ -192,4 +192,97 @@ __global__ void k_generic_trig(const double* __restrict__ state, double* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Wide problems (12 < n <= GENERIC_WIDE_MAX states): the same scan with the state dimension as a RUN-TIME value.  One wavefront per
+// workgroup; a lane keeps its node's error vector in its own column of LDS (e[j][lane]: no barrier, no bank conflict), the query
+// (x | cos/sin of its angular states | S, row stride n) comes from a small device buffer the host fills per call.  NumPy's summation
+// order as in numpy_row_sum: 8 running sums over blocks of 8, pairwise combination, the remainder one by one (n < 128).
+constexpr int GENERIC_WIDE_MAX = 64;
+
+struct WideArgs {
+    const double* q;        // x[n] | trig[2 nw] | S[n*n]
+    const int* wk;          // [n]: number k of the angular state j, or -1
+    int n, nw;
+};
+
+template <class F>
+__device__ __forceinline__ double numpy_row_sum_rt(int n, F term) {
+    if (n < 8) {
+        double r = term(0);
+        for (int i = 1; i < n; ++i) r += term(i);
+        return r;
+    }
+    double r0 = term(0), r1 = term(1), r2 = term(2), r3 = term(3), r4 = term(4), r5 = term(5), r6 = term(6), r7 = term(7);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 += term(i + 0); r1 += term(i + 1); r2 += term(i + 2); r3 += term(i + 3);
+        r4 += term(i + 4); r5 += term(i + 5); r6 += term(i + 6); r7 += term(i + 7);
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += term(i);
+    return res;
+}
+
+template <bool DENSE>
+__global__ __launch_bounds__(64) void k_generic_scan_wide(GenericView v, WideArgs a, double* __restrict__ pcost, int* __restrict__ pidx) {
+    extern __shared__ double e_l[];                                  // [n][64]
+    const int lane = threadIdx.x, n = a.n;
+    const double* qx = a.q;
+    const double* qt = a.q + n;
+    const double* S = a.q + n + 2 * a.nw;
+    Best2 b{INFINITY, INFINITY, -1, -1};
+    for (int i = blockIdx.x * 64 + lane; i < v.count; i += 64 * (int)gridDim.x) {
+        for (int j = 0; j < n; ++j) {
+            double ej;
+            if (v.errors) ej = v.errors[(size_t)i * n + j];
+            else {
+                const int k = a.wk[j];
+                if (k >= 0) ej = wrap_err_c(qt[2 * k], qt[2 * k + 1], v.trig[(size_t)(2 * k) * v.cap + i], v.trig[(size_t)(2 * k + 1) * v.cap + i]);
+                else ej = qx[j] - v.state[(size_t)j * v.cap + i];
+            }
+            e_l[j * 64 + lane] = ej;
+        }
+        const double c = numpy_row_sum_rt(n, [&](int k) {
+            const double ek = e_l[k * 64 + lane];
+            if constexpr (DENSE) {
+                double t = e_l[lane] * S[k];
+                for (int j = 1; j < n; ++j) t += e_l[j * 64 + lane] * S[(size_t)j * n + k];
+                return t * ek;
+            } else {
+                return ek * ek;
+            }
+        });
+        const bool el = !v.ignore || ((v.ignore[i >> 6] >> (i & 63)) & 1ull) == 0;
+        if (b.ia < 0 || c < b.ca) { b.ca = c; b.ia = i; }
+        if (el && (b.i < 0 || c < b.c)) { b.c = c; b.i = i; }
+    }
+    best2_wave(b);
+    if (lane == 0) {
+        const size_t o = (size_t)blockIdx.x * 2;
+        pcost[o] = b.c; pidx[o] = b.i; pcost[o + 1] = b.ca; pidx[o + 1] = b.ia;
+    }
+}
+
+// node i := q (x | trig) of a wide table
+__global__ void k_generic_append_wide(double* __restrict__ state, double* __restrict__ trig, int* __restrict__ pID, int cap, int i, int parent,
+                                      int n, int nw, const double* __restrict__ q) {
+    const int t = threadIdx.x;
+    if (t < n) state[(size_t)t * cap + i] = q[t];
+    if (t < 2 * nw) trig[(size_t)t * cap + i] = q[n + t];
+    if (t == 0) pID[i] = parent;
+}
+
+__global__ void k_generic_trig_wide(const double* __restrict__ state, double* __restrict__ trig, int cap, int count, int n, const int* __restrict__ wk) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    for (int j = 0; j < n; ++j) {
+        const int k = wk[j];
+        if (k < 0) continue;
+        double s, c;
+        lq_sincos(state[(size_t)j * cap + i], &s, &c);
+        trig[(size_t)(2 * k) * cap + i] = c;
+        trig[(size_t)(2 * k + 1) * cap + i] = s;
+    }
+}
+
 }  // namespace lq

@@ -473,6 +473,8 @@ class NodeTable(object):
     def __init__(self, nstates, ncontrols, angle_dims=(), capacity=100008, device=0, max_wave=64):
         nat.require_device()
         self.n, self.m, self.device = int(nstates), int(ncontrols), device
+        if not 1 <= self.n <= 64:
+            raise ValueError("the device node table holds 1 to 64 states per node, got %d" % self.n)
         self.angle_dims = tuple(sorted(int(d) for d in angle_dims))
         d = nat.SystemDesc()
         d.model, d.nstates, d.ncontrols = nat.MODEL_GENERIC, self.n, self.m

@@ -137,7 +137,8 @@ def test_node_table_against_numpy():
     * diffs, axis=1), argmin with lowest-id ties), for identity and dense S, with and without angular states and an ignore set."""
     from lqrrt_amd.engine import NodeTable
     rs = np.random.RandomState(5)
-    for n, angles in ((1, ()), (4, (0, 1)), (5, (2,)), (6, (2,)), (7, ()), (9, (0, 4, 8)), (12, ()), (12, (3, 11))):
+    for n, angles in ((1, ()), (4, (0, 1)), (5, (2,)), (6, (2,)), (7, ()), (9, (0, 4, 8)), (12, ()), (12, (3, 11)),
+                      (13, ()), (14, (1, 13)), (20, (0, 5, 19)), (33, (2,)), (64, ())):        # beyond 12 states: run-time width
         N = 3000
         t = NodeTable(n, 2, angles, capacity=N + 64)
         nodes = rs.uniform(-6, 6, (N, n))
@@ -179,6 +180,10 @@ def test_node_table_against_numpy():
                     # the caller-evaluated form: same selection on the same rows, now exactly (no device atan2 involved)
                     got2, c2 = t.nearest_from_errors(e, S, use_ignore=use_ignore)
                     assert got2 == want or costs[got2] == costs[want]
+            if n > 12:
+                with pytest.raises(Exception):
+                    t.nn_argmin(np.array(queries), S)                        # the batched device form serves up to 12 states
+                continue
             ids, cs = t.nn_argmin(np.array(queries), S, use_ignore=True)
             for x, i, c in zip(queries, ids, cs):
                 assert (int(i), c) == t.nearest(x, S, use_ignore=True)       # batched device form == host form, bit for bit
@@ -284,3 +289,47 @@ def test_callback_mode_control_surface():
     np.random.seed(1)
     p2.update_plan(s.x0, s.sample_space, goal_bias=s.goal_bias, xrand_gen=10)
     assert list(p2.tree.pID) == native_parents                                        # one problem, two routes, one tree
+
+
+def test_a_fourteen_state_problem_through_callback_mode():
+    """More states than any compiled-in system has (LQRRT_MAX_STATES = 12): a 7-DoF double integrator with one angular joint, plain
+    Python plugins.  lqrrt.Planner (node table with a run-time state dimension) against the NumPy oracle's planner driven by the same
+    functions: the same tree, node for node."""
+    from lqrrt_oracle import RefConstraints, RefPlanner
+    dof = 7
+    n, m = 2 * dof, dof
+    Kgain = np.hstack((4.0 * np.eye(dof), 3.0 * np.eye(dof)))
+    balls = np.array([[3.0, 3.0, 1.0], [6.0, 2.0, 1.2], [2.0, 7.0, 0.8]])
+
+    def dynamics(x, u, dt):
+        u = np.clip(u, -5, 5)
+        return x + np.concatenate((x[dof:], u)) * dt
+
+    def lqr(x, u):
+        return np.eye(n), Kgain
+
+    def erf(g, x):
+        e = np.subtract(g, x)
+        e[6] = np.arctan2(np.sin(e[6]), np.cos(e[6]))
+        return e
+
+    def is_feasible(x, u):
+        return bool(np.all(np.hypot(balls[:, 0] - x[0], balls[:, 1] - x[1]) > balls[:, 2]))
+    goal = np.concatenate(([8, 8, 1, -1, 0.5, 0, 2.5], np.zeros(dof)))
+    buf = np.concatenate(([1.0, 1.0], np.full(n - 2, np.inf)))
+    space = [(0, 10)] * 2 + [(-2, 2)] * 4 + [(-np.pi, np.pi)] + [(-1, 1)] * dof
+    bias = [0.3, 0.3] + [0.0] * (n - 2)
+    kw = dict(horizon=1.0, dt=0.1, FPR=0.5, error_tol=np.concatenate(([0.3, 0.3], np.full(n - 2, np.inf))), erf=erf, min_time=2, max_time=3,
+              max_nodes=400, goal0=goal, printing=False, sys_time=lambda: 0.0)        # fake clock: ends by the node limit
+    import lqrrt
+    p = lqrrt.Planner(dynamics, lqr, lqrrt.Constraints(n, m, buf, is_feasible), **kw)
+    o = RefPlanner(dynamics, lqr, RefConstraints(n, m, buf, is_feasible), **kw)
+    np.random.seed(8)
+    rp = p.update_plan(np.zeros(n), space, goal_bias=bias, xrand_gen=10)
+    assert p._erf_angles == (6,) and p._callback_run.table.n == 14
+    np.random.seed(8)
+    ro = o.update_plan(np.zeros(n), space, goal_bias=bias, xrand_gen=10)
+    assert rp is False and ro is False and p.tree.size == o.tree.size == 401
+    assert list(p.tree.pID) == list(o.tree.pID)
+    np.testing.assert_array_equal(p.tree.state, np.array(o.tree.state))
+    assert p.plan_reached_goal == o.plan_reached_goal and list(p.node_seq) == list(o.node_seq)
