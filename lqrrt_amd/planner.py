@@ -142,6 +142,9 @@ class Planner:
 
         Returns True if it ran to completion, False if it was halted (killed, tree larger than max_nodes, no goal).
         """
+        # the feasibility function may have been swapped on the Constraints object itself since set_system (the ROS node does:
+        # lqrrt_node.py:65 planner.constraints.set_feasibility_function(...)): the mode follows the plugins as they are NOW
+        self._resolve_mode()
         if self.callback_mode:
             return self._update_plan_callback(x0, sample_space, goal_bias, guide, xrand_gen, pruning, finish_on_goal, specific_time)
         run = self._plan_begin(x0, sample_space, goal_bias, guide, xrand_gen, pruning, finish_on_goal, specific_time)
@@ -557,6 +560,7 @@ def update_plans(jobs):
             raise ValueError("update_plans: unknown job key(s) %s." % sorted(unknown))
         if not isinstance(p, Planner) or "x0" not in j or "sample_space" not in j:
             raise ValueError("update_plans: every job needs a planner, x0 and sample_space.")
+        p._resolve_mode()
         if p.callback_mode:
             raise ValueError("update_plans: planners whose plugins are Python callables plan one by one (update_plan).")
         if p.wave_mode != "exact" or getattr(p.system, "riccati", False):

@@ -73,14 +73,17 @@ def test_bench_sharded_code_path_world_of_one():
     assert d["value"] > 1e4
 
 
-def test_bench_sharded_run_reports_three_curves():
+def test_bench_sharded_run_reports_four_curves():
     """A sharded run (here: a world of one through the native loop and a real RCCL communicator) prints, next to the exact-mode
-    value, the synchronous mode sample-sharded and BASELINE config 5 tree-sharded."""
+    value, the synchronous mode sample-sharded, BASELINE config 5 tree-sharded and -- the one that scales -- a fleet of independent
+    planners per device."""
     d = _run(["--no-cpu", "--units", "16"], env={"LQRRT_FORCE_SHARDED": "1"})
     assert "native loop" in d["config"]["parallelism"]
     assert d["synchronous_mode"]["value"] > d["value"] and "sample-sharded" in d["synchronous_mode"]["parallelism"]
     c5 = d["config5_tree_sharded"]
     assert c5["value"] > 1e4 and c5["workload"] == "double_integrator_100k_boxes_50k"
+    fl = d["fleet_per_device"]
+    assert fl["trees"] == 64 and fl["trees_per_device"] == 64 and fl["scaling"] == "weak" and fl["value"] > 3 * d["value"]
 
 
 def test_bench_config5_workload():

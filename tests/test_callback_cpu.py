@@ -85,6 +85,13 @@ def test_plain_callables_select_callback_mode():
     assert native.callback_mode
     native.set_system(boat.dynamics, boat.lqr)
     assert not native.callback_mode
+    # ... and through a feasibility function swapped on the Constraints object itself (lqrrt_node.py:65), at the next update_plan
+    assert not native.callback_mode
+    native.set_goal(None)
+    ncons.set_feasibility_function(feas)
+    assert native.update_plan(boat.x0, boat.sample_space) is False and native.callback_mode
+    ncons.set_feasibility_function(boat.is_feasible)
+    assert native.update_plan(boat.x0, boat.sample_space) is False and not native.callback_mode
     # update_plans is for native planners
     p.set_goal(boat.goal)
     with pytest.raises(ValueError):
