@@ -272,8 +272,13 @@ class CallbackRun(object):
                 break
             if elapsed >= max_time or p.tree.size > p.max_nodes:
                 # nearest node to the guide state, states with an infinite goal buffer not counted (planner.py:311-323)
-                Sguide = np.array(p.lqr(p.xguide, zero_u)[0], dtype=np.float64)
-                Sguide[:, np.isinf(np.asarray(p.constraints.goal_buffer, dtype=np.float64))] = 0
+                # (the columns are zeroed IN PLACE in whatever the user's lqr returned, as planner.py:314-316 does: a plugin that hands out
+                #  one shared S -- behaviors/car.py:65,78 -- sees it changed in later plans, with the reference and here alike)
+                Sguide = p.lqr(p.xguide, zero_u)[0]
+                for i, gbuf in enumerate(p.constraints.goal_buffer):
+                    if np.isinf(gbuf):
+                        Sguide[:, i] = 0
+                Sguide = np.array(Sguide, dtype=np.float64)
                 if p._erf_angles is not None:
                     closest = table.nearest(p.xguide, np.ascontiguousarray(Sguide), use_ignore=False)[0]
                 else:

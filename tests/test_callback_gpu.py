@@ -333,3 +333,45 @@ def test_a_fourteen_state_problem_through_callback_mode():
     assert list(p.tree.pID) == list(o.tree.pID)
     np.testing.assert_array_equal(p.tree.state, np.array(o.tree.state))
     assert p.plan_reached_goal == o.plan_reached_goal and list(p.node_seq) == list(o.node_seq)
+
+
+@pytest.mark.parametrize("name", ["boat", "car", "escape"])
+def test_ros_behaviour_fixture_from_plain_python_plugins(golden_dir, name):
+    """The ROS package's three behaviours (demos/lqrrt_ros/behaviors/*.py) as plain Python plugins: adaptive horizon (planner.py:418-425),
+    the node's occupancy-grid feasibility (lqrrt_node.py:719-745) and, for 'car', a cost-to-go matrix that is NOT the identity
+    (S = diag(1,1,1,0,0,0), car.py:65) -- the dense form of the device's nearest-neighbour kernel against the reference's own decisions."""
+    from systems_np import RosBoat
+    g = _load(golden_dir, "ros_%s.npz" % name)
+    rs = RosBoat(name)
+    rs.set_occupancy_grid(g["grid"], g["origin"], float(g["cpm"]), float(g["threshold"]))
+    rs.goal = [float(v) for v in g["goal"]]
+    rs.sample_space = [tuple(r) for r in g["sample_space"]]
+    p = make_callback_planner(rs, 300, min_time=2, max_time=3)
+    assert p.callback_mode
+    log = []
+    from lqrrt_amd import callback
+    orig = callback.CallbackRun.nearest
+
+    def nearest(self, x, pruning):
+        i = orig(self, x, pruning)
+        log.append(i)
+        return i
+    callback.CallbackRun.nearest = nearest
+    try:
+        np.random.seed(1)
+        ret = p.update_plan(rs.x0, rs.sample_space, goal_bias=rs.goal_bias, xrand_gen=10)
+    finally:
+        callback.CallbackRun.nearest = orig
+    assert ret == bool(g["returned"]) and p.stats["attempts"] == int(g["iterations"])
+    np.testing.assert_array_equal(np.array(log, dtype=np.int32), g["nearest"])
+    np.testing.assert_array_equal(np.array(p.tree.pID, dtype=np.int32), g["pID"])
+    assert hashlib.sha1(np.array(p.tree.pID, np.int64).tobytes()).hexdigest()[:16] == str(g["pid_hash"])
+    np.testing.assert_array_equal(np.array([len(e) for e in p.tree.x_seq], dtype=np.int32), g["edge_len"])
+    err = np.abs(p.tree.state - g["state"]).max(axis=1)
+    assert np.median(err) < 1e-12 and (err.max() < ATOL or name == "car")       # (car: the reference's own sensitivity, tests/test_ros_behaviors.py)
+    assert p.horizon_iters == int(g["horizon_iters_final"])
+    assert bool(p.plan_reached_goal) == bool(g["reached_goal"])
+    np.testing.assert_array_equal(np.array(p.node_seq, dtype=np.int32), g["node_seq"])
+    if name == "car":
+        S = np.asarray(rs.lqr(rs.x0, np.zeros(3))[0], dtype=np.float64)
+        assert not np.array_equal(S, np.eye(6))                                    # the dense-S kernel was the one that ran
