@@ -36,7 +36,7 @@ from .constraints import Constraints
 from .engine import Engine
 from . import callback
 from .systems import native_system_of
-from .tree import Tree
+from .tree import Tree, held_elsewhere
 
 
 def _callable(f):
@@ -116,13 +116,26 @@ class Planner:
             self._engine = self._engine_key = None
             self.warm_up_error = ex
 
+    def _retire_tree(self):
+        """The engine is about to be reused: the previous plan's Tree keeps its contents (copied out of HBM once -- tens of milliseconds
+        for a 100k-node tree) IF anybody still holds it (the ROS node does, lqrrt_node.py:477); a tree that only this planner refers to
+        is simply dropped, like the reference drops its Tree at planner.py:172."""
+        t = self.tree
+        if t is None or not getattr(t, "on_device", False):
+            return
+        del t
+        if held_elsewhere(self, "tree"):
+            self.tree._detach()
+        else:
+            self.tree._e, self.tree._generation = None, None        # nobody can read it again
+            self.tree = None
+
     def _get_engine(self):
         """The native engine for the current system / capacity / device (recreated when one of them changed)."""
         capacity = int(self.max_nodes) + self.wave_size + 8
         key = (id(self.system), capacity, self.wave_size, self.device)
         if self._engine is None or self._engine_key != key:
-            if self.tree is not None:
-                self.tree._detach()
+            self._retire_tree()
             if self._engine is not None:
                 self._engine.close()
             self._engine = Engine(self.system, capacity=capacity, max_wave=self.wave_size, device=self.device)
@@ -172,8 +185,7 @@ class Planner:
             self._erf_angles = callback.classify_erf(self.erf, self.nstates, self.angle_dims)
         if self._callback_run is None:
             self._callback_run = callback.CallbackRun(self)
-        if self.tree is not None and getattr(self.tree, "on_device", False):
-            self.tree._detach()                                     # a tree grown by the native engine before the plugins were swapped
+        self._retire_tree()                                         # a tree grown by the native engine before the plugins were swapped
         return self._callback_run.run(x0, sample_space, goal_bias, guide, xrand_gen, pruning, finish_on_goal, specific_time, resume=resume)
 
     # The three phases of update_plan, separately callable so that several planners can share native calls (update_plans below):
@@ -215,8 +227,7 @@ class Planner:
         self.xguide = np.copy(self.goal) if guide is None else np.array(guide, dtype=np.float64)
 
         # the device tree is about to be overwritten: a Tree object from the previous plan keeps its contents
-        if self.tree is not None:
-            self.tree._detach()
+        self._retire_tree()
         eng = run.eng = self._get_engine()
         run.own_stream = seed is not None                           # (update_plans: a sample stream per planner, np.random untouched)
         if run.own_stream and not run.user_sampler:

@@ -74,6 +74,26 @@ class _Snapshot(object):
         return self._xe[a:b], self._ue[a:b]
 
 
+def held_elsewhere(owner, attr):
+    """Does anybody besides `owner.<attr>` still hold that tree or one of its feature sequences?  CPython reference counts, calibrated
+    against a freshly built tree counted by the very same expression from the very same kind of name (a local of this function), so
+    that nothing is assumed about the tree's references to itself or about the interpreter's call overhead.  If nobody does, the
+    contents of a tree that is about to lose its engine can never be read again and need not be copied out of HBM.  (An interpreter
+    without sys.getrefcount: "yes".)"""
+    import sys
+    if not hasattr(sys, "getrefcount"):
+        return True
+
+    def counts(t):
+        return [sys.getrefcount(t)] + [sys.getrefcount(getattr(t, name)) for name in ("x_seq", "u_seq", "lqr")]
+    tree = getattr(owner, attr)
+    probe = Tree(np.zeros(tree.nstates), None)
+    base, mine = counts(probe), counts(tree)      # both held by one local of this function; the tree also by the owner's attribute
+    if mine[0] - base[0] > 1:
+        return True
+    return any(m > b for m, b in zip(mine[1:], base[1:]))
+
+
 class Tree:
     """
     Tree(seed_state, seed_lqr): seed_state is the state of the root, seed_lqr the (S, K) tuple of local LQR

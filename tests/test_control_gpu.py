@@ -85,3 +85,38 @@ def test_pools_are_sized_when_they_are_needed():
     boat2, q = _boat_planner()
     q.warm_up()                                        # the explicit form
     assert q._engine is not None
+
+
+def test_previous_tree_is_copied_out_only_if_somebody_holds_it():
+    """The engine is reused by the next plan.  A Tree the caller kept (the ROS node does: lqrrt_node.py:477) is snapshotted to the host
+    first and stays what it was; a tree nobody refers to any more is simply dropped -- no copy out of HBM (tens of milliseconds for a
+    100k-node tree, between two plans of a replanning loop)."""
+    import lqrrt_amd.tree as tree_mod
+    boat, p = _boat_planner(min_time=0.0, max_time=1.0, max_nodes=3000, sys_time=lambda: 0.0)
+    calls = []
+    orig = tree_mod.Tree._detach
+
+    def counting(self):
+        if self._e is not None:
+            calls.append(self.size)
+        return orig(self)
+    tree_mod.Tree._detach = counting
+    try:
+        np.random.seed(1)
+        p.update_plan(boat.x0, boat.sample_space, goal_bias=boat.goal_bias)
+        np.random.seed(2)
+        p.update_plan(boat.x0, boat.sample_space, goal_bias=boat.goal_bias)          # nobody kept the first tree
+        assert calls == []
+        kept = p.tree
+        state, parents, edge7 = np.array(kept.state), list(kept.pID), [np.array(v) for v in kept.x_seq[7]]
+        rows = p.tree.u_seq                                                           # holding a feature sequence counts as holding the tree
+        np.random.seed(3)
+        p.update_plan(boat.x0, boat.sample_space, goal_bias=boat.goal_bias)
+        assert calls == [kept.size] and kept is not p.tree and not kept.on_device
+        np.testing.assert_array_equal(kept.state, state)
+        assert list(kept.pID) == parents and len(rows) == kept.size
+        for a, b in zip(kept.x_seq[7], edge7):
+            np.testing.assert_array_equal(a, b)
+        assert not np.array_equal(p.tree.state[:50], state[:50])                       # the new plan grew another tree
+    finally:
+        tree_mod.Tree._detach = orig
