@@ -112,7 +112,7 @@ static int generic_nn(lqrrt_engine* e, const GenericQuery* q, bool dense, const 
         if (dense) hipLaunchKernelGGL((k_generic_scan_wide<true>), dim3(nbw), dim3(64), lds, st, v, a, e->d_pcost, e->d_pidx);
         else hipLaunchKernelGGL((k_generic_scan_wide<false>), dim3(nbw), dim3(64), lds, st, v, a, e->d_pcost, e->d_pidx);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_generic_reduce, dim3(1), dim3(64), 0, st, e->d_pcost, e->d_pidx, nbw, id_dev, cost_dev, e->h_gres_dev, seq);
+        hipLaunchKernelGGL(k_generic_reduce, dim3(1), dim3(256), 0, st, e->d_pcost, e->d_pidx, nbw, id_dev, cost_dev, e->h_gres_dev, seq);
         HIPCHK(hipGetLastError());
         e->wide_append_pending = false;          // the caller waits for this query: everything queued before it has completed by then
         return 0;
@@ -133,7 +133,7 @@ static int generic_nn(lqrrt_engine* e, const GenericQuery* q, bool dense, const 
     else { if (dense) { GENERIC_SCAN(S_DENSE, true); } else { GENERIC_SCAN(S_IDENT, true); } }
 #undef GENERIC_SCAN
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_generic_reduce, dim3(W), dim3(64), 0, st, e->d_pcost, e->d_pidx, nb, id_dev, cost_dev,
+    hipLaunchKernelGGL(k_generic_reduce, dim3(W), dim3(256), 0, st, e->d_pcost, e->d_pidx, nb, id_dev, cost_dev,
                        xs ? nullptr : e->h_gres_dev, seq);
     HIPCHK(hipGetLastError());
     return 0;

@@ -121,20 +121,28 @@ __global__ __launch_bounds__(256) void k_generic_scan(GenericView v, GenericShap
     }
 }
 
-// one wavefront per sample: the workgroups' minima -> the nearest eligible node (lowest id among equal costs: the stable order
-// of planner.py:240), or the overall nearest when every node is ignored (planner.py:241,245).  host_out: mapped pinned memory
-// {cost, id as double, sequence number as double}, written last -> first so that the host may poll the sequence number.
-__global__ __launch_bounds__(64) void k_generic_reduce(const double* __restrict__ pcost, const int* __restrict__ pidx, int nb,
-                                                       int* __restrict__ out_id, double* __restrict__ out_cost,
-                                                       volatile double* host_out, double seq) {
-    const int w = blockIdx.x, lane = threadIdx.x;
+// One workgroup of four wavefronts per sample: the scan workgroups' minima -> the nearest eligible node (lowest id among equal costs: the
+// stable order of planner.py:240), or the overall nearest when every node is ignored (planner.py:241,245).  host_out: mapped pinned
+// memory {cost, id as double, sequence number as double}, written last -> first so that the host may poll the sequence number.
+// (Four wavefronts: a scan of a million nodes and more leaves 4096 partials, which one wavefront took 30 us to walk through.)
+__global__ __launch_bounds__(256) void k_generic_reduce(const double* __restrict__ pcost, const int* __restrict__ pidx, int nb,
+                                                        int* __restrict__ out_id, double* __restrict__ out_cost,
+                                                        volatile double* host_out, double seq) {
+    const int w = blockIdx.x, tid = threadIdx.x;
     Best2 b{INFINITY, INFINITY, -1, -1};
-    for (int k = lane; k < nb; k += 64) {
+    for (int k = tid; k < nb; k += 256) {
         const size_t o = ((size_t)w * nb + k) * 2;
         best2_take(b, pcost[o], pidx[o], pcost[o + 1], pidx[o + 1]);
     }
     best2_wave(b);
-    if (lane == 0) {
+    __shared__ double rc[4], rca[4];
+    __shared__ int ri[4], ria[4];
+    const int wv = tid >> 6;
+    if ((tid & 63) == 0) { rc[wv] = b.c; ri[wv] = b.i; rca[wv] = b.ca; ria[wv] = b.ia; }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) best2_take(b, rc[k], ri[k], rca[k], ria[k]);
         const bool fb = b.i < 0;
         const int id = fb ? b.ia : b.i;
         const double c = fb ? b.ca : b.c;

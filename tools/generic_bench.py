@@ -42,13 +42,6 @@ def main():
             if dense:
                 A = rng.uniform(-1, 1, (a.n, a.n))
                 S = A.dot(A.T) + a.n * np.eye(a.n)
-            want = None
-            if N <= 1000000:
-                e = q - nodes
-                for d in angles:
-                    e[:, d] = np.arctan2(np.sin(e[:, d]), np.cos(e[:, d]))
-                c = np.sum(e.dot(np.eye(a.n) if S is None else S) * e, axis=1)
-                want = int(np.argmin(c))
             got = t.nearest(q, S)[0]
             t0 = time.perf_counter()
             for _ in range(200):
@@ -71,6 +64,13 @@ def main():
             ev1.record()
             torch.cuda.synchronize()
             dev_us = 1e3 * ev0.elapsed_time(ev1) / a.reps
+            want = None                                              # (checked AFTER the timing: seconds of NumPy leave the GPU idle)
+            if N <= 1000000:
+                e = q - nodes
+                for d in angles:
+                    e[:, d] = np.arctan2(np.sin(e[:, d]), np.cos(e[:, d]))
+                c = np.sum(e.dot(np.eye(a.n) if S is None else S) * e, axis=1)
+                want = int(np.argmin(c))
             nbytes = N * (8 * a.n + 16 * len(angles)) + N / 8
             print(json.dumps(dict(N=N, n=a.n, angular=len(angles), S="dense" if dense else "identity", host_query_us=round(host_us, 2),
                                   device_scan_plus_reduce_us=round(dev_us, 2), table_bytes=int(nbytes), GBps=round(nbytes / dev_us / 1e3, 1),
