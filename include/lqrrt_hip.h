@@ -278,6 +278,12 @@ int lqrrt_tree_get_edge_lengths(lqrrt_engine* e, int first, int count, int32_t* 
 /* edge of one node: x [len][n], u [len][m]; returns len (root: 1, tree.py:69-70) */
 int lqrrt_tree_get_edge(lqrrt_engine* e, int id, double* x_host, double* u_host);
 int lqrrt_tree_get_ignored(lqrrt_engine* e, int first, int count, uint8_t* out_host);
+/* Tree.climb (tree.py:100-117) on the engine's host mirror of the parent array: node ids from the seed (first) down to `id` (last)
+ * into out_ids [cap]; returns their number (LQRRT_E_CAPACITY when cap is too small).  No device access. */
+int lqrrt_tree_climb(lqrrt_engine* e, int id, int32_t* out_ids, int cap);
+/* Tree.trajectory's reads (tree.py:121-132) for a whole list of nodes at once: gathered on the device, two copies out.
+ * x [count][H][n], u [count][H][m] (rows beyond a node's edge length unspecified), len [count]; any output may be NULL. */
+int lqrrt_tree_get_edges_of(lqrrt_engine* e, const int32_t* ids_host, int count, double* x_host, double* u_host, int32_t* len_host);
 /* edges of nodes [first, first+count) in one copy: x [count][H][n], u [count][H][m] (H = horizon_iters; rows beyond a
  * node's edge length are unspecified) */
 int lqrrt_tree_get_edges(lqrrt_engine* e, int first, int count, double* x_host, double* u_host);

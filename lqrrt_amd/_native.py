@@ -91,6 +91,8 @@ SIGNATURES = {
     "lqrrt_tree_get_edge_lengths": (_I, [_P, _I, _I, _P]),
     "lqrrt_tree_get_edge": (_I, [_P, _I, _P, _P]),
     "lqrrt_tree_get_ignored": (_I, [_P, _I, _I, _P]),
+    "lqrrt_tree_climb": (_I, [_P, _I, _P, _I]),
+    "lqrrt_tree_get_edges_of": (_I, [_P, _P, _I, _P, _P, _P]),
     "lqrrt_feasible_batch": (_I, [_P, _P, _P, _I, _P, _P]),
     "lqrrt_dynamics_batch": (_I, [_P, _P, _P, _I, _P, _P]),
     "lqrrt_gain_batch": (_I, [_P, _P, _P, _I, _P, _P]),

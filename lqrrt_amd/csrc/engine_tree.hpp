@@ -106,6 +106,61 @@ extern "C" int lqrrt_tree_get_edges(lqrrt_engine* e, int first, int count, doubl
     return 0;
 }
 
+// Tree.climb (tree.py:100-117) on the host mirror of the parent array: node ids from the seed (first) down to `id` (last).  Returns the
+// count, or LQRRT_E_CAPACITY when `cap` ids do not hold the path.  No device access.
+extern "C" int lqrrt_tree_climb(lqrrt_engine* e, int id, int32_t* out_ids, int cap) {
+    TRY(range_ok(e, id, 1));
+    if (!out_ids || cap < 1) return fail(LQRRT_E_ARG, "null argument");
+    int count = 0;
+    for (int v = id; v != -1; v = e->h_pid[(size_t)v]) {
+        if (count >= cap) return fail(LQRRT_E_CAPACITY, "path longer than %d nodes", cap);
+        out_ids[count++] = v;
+    }
+    std::reverse(out_ids, out_ids + count);
+    return count;
+}
+
+// edges of an arbitrary list of nodes in TWO copies: gathered on the device into [count][H][n] / [count][H][m], then copied out
+__global__ void k_gather_edges(TreeView tv, const int* __restrict__ ids, int count, int n, int m, double* __restrict__ xo, double* __restrict__ uo) {
+    const int k = blockIdx.x;
+    if (k >= count) return;
+    const size_t id = (size_t)ids[k];
+    const int H = tv.H;
+    for (int q = threadIdx.x; q < H * n; q += blockDim.x) xo[(size_t)k * H * n + q] = tv.xedge[id * H * n + q];
+    for (int q = threadIdx.x; q < H * m; q += blockDim.x) uo[(size_t)k * H * m + q] = tv.uedge[id * H * m + q];
+}
+
+// Tree.trajectory's reads (tree.py:121-132) for a whole path at once: x [count][H][n], u [count][H][m] (rows beyond a node's edge length
+// unspecified), len [count].  (One lqrrt_tree_get_edge per node is two blocking copies each: 5 ms for a 90-node plan -- at the end of
+// every update_plan, and between kill_update and the return of a killed one.)
+extern "C" int lqrrt_tree_get_edges_of(lqrrt_engine* e, const int32_t* ids, int count, double* x_host, double* u_host, int32_t* len_host) {
+    NOT_GENERIC(e);
+    if (!e || !ids || count < 0) return fail(LQRRT_E_ARG, "bad argument");
+    if (!count) return 0;
+    for (int k = 0; k < count; ++k) TRY(range_ok(e, ids[k], 1));
+    TRY(use_device(e));
+    const size_t xn = (size_t)count * e->H * e->n, un = (size_t)count * e->H * e->m;
+    double* d_x = nullptr; double* d_u = nullptr; int* d_ids = nullptr;
+    const size_t keep = g_dalloc_bytes;
+    int rc = dalloc(&d_x, xn);
+    if (!rc) rc = dalloc(&d_u, un);
+    if (!rc) rc = dalloc(&d_ids, (size_t)count);
+    g_dalloc_bytes = keep;                                   // (transient: not part of the engine's footprint)
+    if (!rc && hipMemcpy(d_ids, ids, sizeof(int) * count, hipMemcpyHostToDevice) != hipSuccess) rc = fail(LQRRT_E_HIP, "hipMemcpy failed");
+    if (!rc) {
+        hipLaunchKernelGGL(k_gather_edges, dim3(count), dim3(128), 0, nullptr, e->tv, d_ids, count, e->n, e->m, d_x, d_u);
+        if (hipGetLastError() != hipSuccess) rc = fail(LQRRT_E_HIP, "k_gather_edges failed to launch");
+    }
+    if (!rc && x_host && hipMemcpy(x_host, d_x, sizeof(double) * xn, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(LQRRT_E_HIP, "hipMemcpy failed");
+    if (!rc && u_host && hipMemcpy(u_host, d_u, sizeof(double) * un, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(LQRRT_E_HIP, "hipMemcpy failed");
+    if (d_x) (void)hipFree(d_x);
+    if (d_u) (void)hipFree(d_u);
+    if (d_ids) (void)hipFree(d_ids);
+    if (!rc && len_host)
+        for (int k = 0; k < count; ++k) len_host[k] = e->h_elen[(size_t)ids[k]];
+    return rc;
+}
+
 // trig table of loaded nodes: the same lq_sincos the steer kernel applies to a new end state (trig_of)
 template <class S>
 __global__ void k_tree_trig(TreeView tv, int count) {

@@ -264,6 +264,27 @@ class Engine(object):
         nat.check(nat.lib().lqrrt_tree_get_ignored(self.h, first, count, nat.ptr(out)))
         return out.astype(bool)
 
+    def climb(self, ID):
+        """Node ids from the seed down to ID (tree.py:100-117), from the engine's host mirror of the parents: no device access."""
+        cap = 4096
+        while True:
+            out = np.empty(cap, dtype=np.int32)
+            rc = nat.lib().lqrrt_tree_climb(self.h, int(ID), nat.ptr(out), cap)
+            if rc == nat.E_CAPACITY and cap < self.size + 1:
+                cap = min(4 * cap, self.size + 1)
+                continue
+            return out[:nat.check(rc)].tolist()
+
+    def edges_of(self, ids):
+        """[(x [len][n], u [len][m])] of the listed nodes: one gather on the device, two copies out (lqrrt_tree_get_edges_of)."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        H = max(self.horizon_iters or 1, 1)
+        x = np.empty((len(ids), H, self.n))
+        u = np.empty((len(ids), H, self.m))
+        ln = np.empty(len(ids), dtype=np.int32)
+        nat.check(nat.lib().lqrrt_tree_get_edges_of(self.h, nat.ptr(ids), len(ids), nat.ptr(x), nat.ptr(u), nat.ptr(ln)))
+        return [(x[k, :ln[k]].copy(), u[k, :ln[k]].copy()) for k in range(len(ids))]
+
     # -- batched operators (host arrays in, host arrays out; device memory via torch) ----------
     def _dev(self, a, shape):
         torch = _torch()

@@ -228,16 +228,9 @@ class Tree:
         if ID >= self.size or ID < 0:
             raise ValueError("The given ID, {}, doesn't exist.".format(ID))
         if self._e is not None and "pID" not in self._fresh() and ID < self._ndev():
-            # a tree that is still growing on the device: follow the parents one read at a time (a path is tens of nodes; the whole
-            # parent array of a 200k-node tree is a 5 ms copy -- on the path of kill_update, tests/test_control_gpu.py)
-            e, chain = self._dev(), [int(ID)]
-            while True:
-                parent = int(e.parents(chain[-1], 1)[0])
-                if parent == -1:
-                    break
-                chain.append(parent)
-            chain.reverse()
-            return chain
+            # a tree that is still growing on the device: the engine's host mirror of the parents answers (the whole parent array of a
+            # 200k-node tree is a 5 ms copy -- on the path of kill_update and at the end of every plan, tests/test_control_gpu.py)
+            return self._dev().climb(ID)
         parents = self.pID
         chain = [int(ID)]
         while parents[chain[-1]] != -1:
@@ -248,6 +241,14 @@ class Tree:
     def trajectory(self, IDs):
         """(x_seq_full, u_seq_full): the edges of the listed nodes laid end to end -- tree.py:121-132."""
         xs, us = [], []
+        src = self._src()
+        if self._e is not None and len(IDs) > 2:
+            # the whole path's edges in one gather (two copies) instead of two blocking copies per node
+            c, n = self._fresh(), self._ndev()
+            missing = [int(i) for i in IDs if int(i) < n and ("edge", int(i)) not in c]
+            if missing:
+                for i, (x, u) in zip(missing, src.edges_of(missing)):
+                    c[("edge", i)] = (list(x), list(u))
         for ID in IDs:
             ex, eu = self._edge(int(ID))
             xs += list(ex)

@@ -120,3 +120,27 @@ def test_previous_tree_is_copied_out_only_if_somebody_holds_it():
         assert not np.array_equal(p.tree.state[:50], state[:50])                       # the new plan grew another tree
     finally:
         tree_mod.Tree._detach = orig
+
+
+def test_path_extraction_reads_the_path_not_the_tree():
+    """Tree.climb on the engine's host mirror (lqrrt_tree_climb) and Tree.trajectory through one device-side gather
+    (lqrrt_tree_get_edges_of) give what the node-by-node reads give."""
+    boat, p = _boat_planner(min_time=0.0, max_time=1.0, max_nodes=6000, sys_time=lambda: 0.0)
+    np.random.seed(4)
+    p.update_plan(boat.x0, boat.sample_space, goal_bias=boat.goal_bias)
+    eng, tree = p._engine, p.tree
+    parents = eng.parents()
+    for end in (0, 1, tree.size // 2, tree.size - 1, int(p.node_seq[-1])):
+        walk = [end]
+        while parents[walk[-1]] != -1:
+            walk.append(int(parents[walk[-1]]))
+        walk.reverse()
+        assert eng.climb(end) == walk == tree.climb(end)
+        xs, us = tree.trajectory(walk)
+        want_x = np.vstack([eng.edge(i)[0] for i in walk])
+        want_u = np.vstack([eng.edge(i)[1] for i in walk])
+        np.testing.assert_array_equal(np.array(xs), want_x)
+        np.testing.assert_array_equal(np.array(us), want_u)
+    with pytest.raises(ValueError):
+        eng.climb(tree.size)
+    np.testing.assert_array_equal(np.array(p.x_seq), np.vstack([eng.edge(i)[0] for i in p.node_seq]))
