@@ -112,3 +112,26 @@ def test_callback_mode_without_a_device():
     p.set_goal([1, 1])
     with pytest.raises(RuntimeError):
         p.update_plan([0, 0], [(0, 1), (0, 1)])                    # planning needs the GPU: no CPU path
+
+
+def test_held_elsewhere_counts_references():
+    """tree.held_elsewhere decides whether the previous plan's tree must be copied out of HBM before the engine is reused: only when
+    somebody besides the planner's attribute still holds the tree or one of its feature sequences."""
+    from lqrrt_amd.tree import Tree, held_elsewhere
+
+    class Owner(object):
+        pass
+    o = Owner()
+    o.tree = Tree(np.zeros(3), None)
+    assert held_elsewhere(o, "tree") is False
+    kept = o.tree
+    assert held_elsewhere(o, "tree") is True
+    del kept
+    for name in ("x_seq", "u_seq", "lqr"):
+        rows = getattr(o.tree, name)
+        assert held_elsewhere(o, "tree") is True, name
+        del rows
+    box = [o.tree]
+    assert held_elsewhere(o, "tree") is True
+    del box
+    assert held_elsewhere(o, "tree") is False
